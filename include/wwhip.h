@@ -1,0 +1,207 @@
+/*
+ * wwhip.h -- C-ABI of libwwhip.so: the MI355X (gfx950) hot path of the wakeword
+ * training inner loop.
+ *
+ * The reference (sarpel/wakeword_trainer_home) is pure Python and has no FFI layer
+ * (SURVEY.md F2); this ABI is what a maintainer binds with ctypes underneath the
+ * reference's own Python interfaces (INTEGRATION.md shows the stub).  Every entry
+ * point cites the reference interface whose device work it replaces.
+ *
+ * Conventions
+ *   - extern "C"; every function returns int: 0 = ok, <0 = WW_E_* ; the message for
+ *     the calling thread's last failure is ww_last_error().
+ *   - All tensor arguments are DEVICE pointers owned by the caller (PyTorch-allocated);
+ *     the library never frees or retains them.  Scratch is caller-provided.
+ *   - Every launch goes to the hipStream_t passed as `stream` (void*; NULL = default
+ *     stream).  No entry point synchronises the device or allocates device memory,
+ *     except ww_ctx_create (uploads constant tables once).
+ *   - Activations inside the conv stack are channels-last  [B][H][W][64] fp32 -- the
+ *     memory format the reference trains in (src/training/trainer.py:71,165).
+ *   - A ww_ctx is used by one host thread at a time (the training thread).
+ */
+#ifndef WWHIP_H
+#define WWHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WW_ABI_VERSION 1
+
+#define WW_OK 0
+#define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
+#define WW_E_HIP (-2)         /* a HIP runtime call failed */
+#define WW_E_WORKSPACE (-3)   /* caller workspace too small */
+#define WW_E_UNSUPPORTED (-4) /* valid request outside what the kernels implement */
+
+typedef struct ww_ctx ww_ctx;
+typedef void *ww_stream_t; /* hipStream_t */
+
+int ww_abi_version(void);
+const char *ww_last_error(void);
+int ww_ctx_create(int device, ww_ctx **out);
+int ww_ctx_destroy(ww_ctx *ctx);
+
+/* ------------------------------------------------------------------ features
+ * Replaces FeatureExtractor.__call__ (src/data/feature_extraction.py -- ABSENT from the
+ * reference snapshot; contract from src/evaluation/evaluator.py:86-94,122-128 and the
+ * shape law of src/export/onnx_exporter.py:316-320: (1, n_feat, N//hop + 1)), batched.
+ * Spec: DESIGN.md "Feature spec" (periodic Hann, center/reflect, |rFFT|^2, HTK mel,
+ * log(mel+eps); MFCC = orthonormal DCT-II).  n_mfcc == 0 selects log-mel.            */
+typedef struct {
+    int32_t sample_rate; /* src/config/defaults.py:15  (16000) */
+    int32_t n_fft;       /* :18 (1024; the only size implemented) */
+    int32_t hop;         /* :19 (160) */
+    int32_t n_mels;      /* :20 (128; BASELINE config 2 uses 40); <= 128 */
+    int32_t n_mfcc;      /* :17 ; 0 = log-mel output, else <= n_mels */
+    float f_min;
+    float f_max;   /* <= 0 -> sample_rate/2 */
+    float log_eps; /* 1e-6 */
+} ww_feat_cfg;
+
+/* Replaces SpecAugment.__call__ (src/data/augmentation.py -- ABSENT; ctor pinned by
+ * tests/test_training_pipeline.py:252-257, probabilities by src/config/defaults.py:90-91).
+ * Integer index law: DESIGN.md "SpecAugment spec" / oracle/specaugment.py.            */
+typedef struct {
+    int32_t freq_mask_param;
+    int32_t time_mask_param;
+    int32_t n_freq_masks; /* n_freq_masks + n_time_masks <= 16 */
+    int32_t n_time_masks;
+    float freq_mask_prob;
+    float time_mask_prob;
+} ww_specaug_cfg;
+
+#define WW_WAVE_F32 0
+#define WW_WAVE_I16 1
+
+int ww_feat_num_frames(int n_samples, int hop);
+
+/* wave (B,N) f32|i16  ->  out (B,1,n_feat,T) f32, optionally SpecAugment-masked in the
+ * same pass.  mask_idx (nullable): int32 (B, n_f+n_t, 2) rows (start,width).           */
+int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int B, int N, const ww_feat_cfg *cfg,
+                  float *out, const ww_specaug_cfg *sa, uint64_t seed, uint64_t step,
+                  uint64_t sample_offset, int32_t *mask_idx, ww_stream_t stream);
+
+/* In-place SpecAugment on ready-made features x (B,1,F,T).                             */
+int ww_specaug_apply(ww_ctx *ctx, float *x, int B, int F, int T, const ww_specaug_cfg *sa,
+                     uint64_t seed, uint64_t step, uint64_t sample_offset, int32_t *mask_idx,
+                     ww_stream_t stream);
+
+/* ------------------------------------------------------------------ conv stack layers
+ * Replace nn.Conv2d / nn.BatchNorm2d(train) / nn.ReLU as the reference composes them
+ * (stem form: src/models/architectures.py:99-102; depthwise-separable blocks are the
+ * torchvision MobileNetV3 building block the reference imports at :91-95).
+ *
+ * A "layer" here = conv producing the PRE-BatchNorm tensor y, plus the per-channel batch
+ * statistics of y.  BatchNorm+ReLU of a layer is applied by its CONSUMER while loading
+ * (scale/shift vector `ss` = [scale(64) | shift(64)]), so normalised activations never
+ * touch HBM.  `mr` = [mean(64) | rstd(64)] is kept for backward.                        */
+typedef struct {
+    const float *gamma;  /* (64) BatchNorm2d.weight */
+    const float *beta;   /* (64) BatchNorm2d.bias */
+    float *running_mean; /* (64) updated when training != 0 */
+    float *running_var;  /* (64) */
+    float momentum;      /* 0.1 */
+    float eps;           /* 1e-5 */
+    int32_t training;    /* 1: batch statistics (+running update); 0: running statistics */
+} ww_bn_t;
+
+#define WW_C 64              /* channel width of the conv stack */
+#define WW_MAX_PARTIALS 1024 /* rows of a reduction slab */
+/* scratch for one layer call: partial-sum slabs */
+size_t ww_layer_scratch_bytes(void);
+
+/* x (B,Hin,Win) f32 (C=1)  ->  y (B,Ho,Wo,64), Ho=(Hin+1)/2, Wo=(Win+1)/2 ; 3x3 s2 p1 */
+int ww_conv_stem_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int Hin, int Win, float *y,
+                     const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch, ww_stream_t stream);
+/* depthwise 3x3 p1 on relu(bn(y_in)) */
+int ww_dwconv3x3_fwd(ww_ctx *ctx, const float *y_in, const float *ss_in, const float *w, int B, int H, int W,
+                     float *y, const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch,
+                     ww_stream_t stream);
+/* pointwise 1x1 (64->64) on relu(bn(y_in)); f32 MFMA */
+int ww_pwconv1x1_fwd(ww_ctx *ctx, const float *y_in, const float *ss_in, const float *w, int B, int H, int W,
+                     float *y, const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch,
+                     ww_stream_t stream);
+/* AdaptiveAvgPool2d(1) of relu(bn(y)):  pool (B,3,64) = [sum relu(z) | sum_{z>0} yhat | count_{z>0}] */
+int ww_gap_fwd(ww_ctx *ctx, const float *y, const float *ss, const float *mr, int B, int H, int W, float *pool,
+               ww_stream_t stream);
+/* dropout(Philox) + nn.Linear(64,2) (classifier of cnn_small; reference head form
+ * src/models/architectures.py:105-111).  pd (B,64) = dropped pooled vector (kept for bwd) */
+int ww_head_fwd(ww_ctx *ctx, const float *pool, int B, int HW, const float *fc_w, const float *fc_b,
+                float dropout_p, int training, uint64_t seed, uint64_t step, uint64_t sample_offset, float *pd,
+                float *logits, ww_stream_t stream);
+
+/* ---- backward.  `coef` (192) = per-channel [A | Bc | Cc] with  dy = A*dz + Bc*y + Cc
+ * (BatchNorm backward folded into one fma chain); produced for the INPUT layer of each
+ * call together with that layer's dgamma/dbeta.                                          */
+int ww_head_bwd(ww_ctx *ctx, const float *dlogits, const float *pd, const float *pool, int B, int HW,
+                const float *fc_w, float dropout_p, int training, uint64_t seed, uint64_t step,
+                uint64_t sample_offset, const float *gamma_last, const float *mr_last, float *dfc_w,
+                float *dfc_b, float *dpool, float *coef_last, float *dgamma_last, float *dbeta_last,
+                ww_stream_t stream);
+/* g == NULL -> this is the last conv layer: dz = dpool[b][c] * [z>0] (dpool carries 1/HW) */
+int ww_pwconv1x1_bwd(ww_ctx *ctx, const float *g, const float *dpool, const float *y_out, const float *ss_out,
+                     const float *coef, const float *y_in, const float *ss_in, const float *mr_in,
+                     const float *gamma_in, const float *w, int B, int H, int W, float *g_in, float *dw,
+                     float *coef_in, float *dgamma_in, float *dbeta_in, void *scratch, ww_stream_t stream);
+int ww_dwconv3x3_bwd(ww_ctx *ctx, const float *g, const float *y_out, const float *coef, const float *y_in,
+                     const float *ss_in, const float *mr_in, const float *gamma_in, const float *w, int B,
+                     int H, int W, float *g_in, float *dw, float *coef_in, float *dgamma_in,
+                     float *dbeta_in, void *scratch, ww_stream_t stream);
+int ww_conv_stem_bwd(ww_ctx *ctx, const float *g, const float *y_out, const float *coef, const float *x, int B,
+                     int Hin, int Win, float *dw, void *scratch, ww_stream_t stream);
+
+/* ------------------------------------------------------------------ whole model
+ * cnn_small (added to create_model, src/models/architectures.py:437):
+ * stem + 4 x (dw,pw) + GAP + dropout + Linear(64,2).  params/grads: arrays of
+ * WW_CNN_SMALL_NPTR device pointers in state_dict order:
+ *   0 stem.conv.weight  1 stem.bn.weight  2 stem.bn.bias  3 stem.bn.running_mean  4 stem.bn.running_var
+ *   5+10i .. : blocks.i.dw.weight, dw_bn.{weight,bias,running_mean,running_var},
+ *              blocks.i.pw.weight, pw_bn.{weight,bias,running_mean,running_var}      (i = 0..3)
+ *   45 classifier.weight   46 classifier.bias
+ * (grads: running_* slots are ignored).                                                  */
+#define WW_CNN_SMALL_NPTR 47
+size_t ww_cnn_small_workspace_bytes(int B, int F, int T);
+int ww_cnn_small_fwd(ww_ctx *ctx, void *const *params, const float *x, int B, int F, int T, int training,
+                     float bn_momentum, float bn_eps, float dropout_p, uint64_t seed, uint64_t step,
+                     uint64_t sample_offset, void *ws, size_t ws_bytes, float *logits, ww_stream_t stream);
+/* must follow a training-mode ww_cnn_small_fwd on the same ws/x */
+int ww_cnn_small_bwd(ww_ctx *ctx, void *const *params, void *const *grads, const float *x, const float *dlogits,
+                     int B, int F, int T, float dropout_p, uint64_t seed, uint64_t step, uint64_t sample_offset,
+                     void *ws, size_t ws_bytes, ww_stream_t stream);
+
+/* ------------------------------------------------------------------ loss + step glue
+ * Replaces LabelSmoothingCrossEntropy.forward (src/models/losses.py:66-98), the eps==0
+ * nn.CrossEntropyLoss branch (:256) and FocalLoss.forward (:170-197) for C == 2, plus their
+ * autograd, plus the per-batch accuracy / confusion counters of
+ * src/training/trainer.py:196-200 + src/training/metrics.py:105-116.                     */
+#define WW_LOSS_CE 0
+#define WW_LOSS_FOCAL 1
+typedef struct {
+    float loss;
+    float grad_norm; /* written by ww_grad_norm_clip */
+    int32_t correct, tp, tn, fp, fn;
+    int32_t nonfinite;  /* != 0 if the loss is not finite (trainer.py:177) */
+    int32_t bad_target; /* != 0 if any target is outside [0,2) (losses.py:72) */
+    int32_t count;      /* B */
+} ww_step_stats;
+int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64_t *targets, int B, int loss_kind,
+                        float label_smoothing, float focal_alpha, float focal_gamma, float *loss_out,
+                        float *dlogits, ww_step_stats *stats, ww_stream_t stream);
+/* Replaces clip_gradients -> torch.nn.utils.clip_grad_norm_
+ * (src/training/optimizer_factory.py:446-452) on one flat gradient bucket.  max_norm <= 0:
+ * only the norm is computed.  norm_out (nullable) receives the pre-clip L2 norm.          */
+int ww_grad_norm_clip(ww_ctx *ctx, float *flat_grads, size_t n, float max_norm, float *norm_out,
+                      ww_stream_t stream);
+/* floor(p * 2^32) clamped to [0, 2^32] -- the integer probability threshold of the specs  */
+uint64_t ww_prob_threshold(double p);
+/* Philox4x32-10, exported so host tests can pin the device RNG's law (oracle/philox.py)   */
+void ww_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WWHIP_H */

@@ -71,6 +71,6 @@ class CNNSmallOracle(nn.Module):
             keep = dropout_keep_mask(pooled.shape[0], pooled.shape[1], self.p,
                                      self.dropout_seed, self.dropout_step)
             self.dropout_step += 1
-            scale = np.float32(1.0 / (1.0 - self.p))
+            scale = np.float32(1.0 / (1.0 - float(np.float32(self.p))))
             pooled = pooled * torch.from_numpy(keep.astype(np.float32) * scale).to(pooled)
         return self.classifier(pooled)

@@ -34,10 +34,12 @@ def philox4x32_10(ctr, key):
 def prob_threshold(p: float) -> int:
     """Integer threshold T such that (u32 draw < T) happens with probability p.
 
-    T = floor(p * 2**32) clamped to [0, 2**32]; compared as uint64 so p=1.0
-    is always true.  Same double arithmetic on the C side (ww_prob_threshold).
+    T = floor(float32(p) * 2**32) clamped to [0, 2**32]; compared as uint64 so p=1.0
+    is always true.  p crosses the C-ABI as a float32 (ww_specaug_cfg / dropout_p), so the
+    spec takes the float32 value of p; the product itself is exact in double
+    (ww_prob_threshold on the C side).
     """
-    t = int(np.floor(float(p) * 4294967296.0))
+    t = int(np.floor(float(np.float32(p)) * 4294967296.0))
     return max(0, min(t, 1 << 32))
 
 

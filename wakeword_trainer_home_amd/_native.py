@@ -1,0 +1,394 @@
+"""ctypes binding of libwwhip.so (include/wwhip.h) -- the only door to the HIP hot path.
+
+There is deliberately NO fallback: if the shared library is missing, or a tensor is not
+on an MI355X, these wrappers raise.  PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
+_lib = None
+_ctx = {}
+
+ABI_VERSION = 1
+LOSS_CE, LOSS_FOCAL = 0, 1
+WAVE_F32, WAVE_I16 = 0, 1
+CNN_SMALL_NPTR = 47
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class FeatCfg(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("hop", C.c_int32), ("n_mels", C.c_int32),
+                ("n_mfcc", C.c_int32), ("f_min", C.c_float), ("f_max", C.c_float), ("log_eps", C.c_float)]
+
+
+class SpecAugCfg(C.Structure):
+    _fields_ = [("freq_mask_param", C.c_int32), ("time_mask_param", C.c_int32), ("n_freq_masks", C.c_int32),
+                ("n_time_masks", C.c_int32), ("freq_mask_prob", C.c_float), ("time_mask_prob", C.c_float)]
+
+
+class BN(C.Structure):
+    _fields_ = [("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float), ("training", C.c_int32)]
+
+
+class StepStats(C.Structure):
+    _fields_ = [("loss", C.c_float), ("grad_norm", C.c_float), ("correct", C.c_int32), ("tp", C.c_int32),
+                ("tn", C.c_int32), ("fp", C.c_int32), ("fn", C.c_int32), ("nonfinite", C.c_int32),
+                ("bad_target", C.c_int32), ("count", C.c_int32)]
+
+
+STEP_STATS_BYTES = C.sizeof(StepStats)
+
+_vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
+_SIGS = {
+    "ww_abi_version": (C.c_int, []),
+    "ww_last_error": (C.c_char_p, []),
+    "ww_ctx_create": (C.c_int, [_i, C.POINTER(_vp)]),
+    "ww_ctx_destroy": (C.c_int, [_vp]),
+    "ww_feat_num_frames": (C.c_int, [_i, _i]),
+    "ww_logmel_fwd": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(FeatCfg), _vp, C.POINTER(SpecAugCfg), _u64, _u64, _u64,
+                                _vp, _vp]),
+    "ww_specaug_apply": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(SpecAugCfg), _u64, _u64, _u64, _vp, _vp]),
+    "ww_layer_scratch_bytes": (_sz, []),
+    "ww_conv_stem_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
+    "ww_dwconv3x3_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
+    "ww_pwconv1x1_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
+    "ww_gap_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ww_head_fwd": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _f, _i, _u64, _u64, _u64, _vp, _vp, _vp]),
+    "ww_head_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _f, _i, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp, _vp]),
+    "ww_pwconv1x1_bwd": (C.c_int, [_vp] + [_vp] * 10 + [_i, _i, _i] + [_vp] * 7),
+    "ww_dwconv3x3_bwd": (C.c_int, [_vp] + [_vp] * 8 + [_i, _i, _i] + [_vp] * 7),
+    "ww_conv_stem_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ww_cnn_small_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ww_cnn_small_fwd": (C.c_int, [_vp, C.POINTER(_vp), _vp, _i, _i, _i, _i, _f, _f, _f, _u64, _u64, _u64, _vp, _sz,
+                                   _vp, _vp]),
+    "ww_cnn_small_bwd": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i, _i, _i, _f, _u64, _u64, _u64, _vp,
+                                   _sz, _vp]),
+    "ww_ce2_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "ww_grad_norm_clip": (C.c_int, [_vp, _vp, _sz, _f, _vp, _vp]),
+    "ww_prob_threshold": (_u64, [C.c_double]),
+    "ww_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """dlopen libwwhip.so (once).  Raises NativeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise NativeError(
+                f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or `make -C {_LIB_PATH.parent}`); there is no CPU fallback for the HIP hot path")
+        lib = C.CDLL(os.fspath(_LIB_PATH))
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.ww_abi_version() != ABI_VERSION:
+            raise NativeError(f"libwwhip ABI {lib.ww_abi_version()} != binding {ABI_VERSION}: rebuild")
+        _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = _lib.ww_last_error().decode(errors="replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise NativeError(f"{what} failed ({rc}): {msg}")
+
+
+def ctx(device) -> int:
+    """Per-device ww_ctx handle (created on first use)."""
+    lib = load()
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _ctx:
+        h = _vp()
+        with torch.cuda.device(idx):
+            _check(lib.ww_ctx_create(idx, C.byref(h)), "ww_ctx_create")
+        _ctx[idx] = h
+    return _ctx[idx]
+
+
+def _dev(*tensors):
+    d = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NativeError("the HIP hot path needs tensors on an MI355X ('cuda') device; got a CPU tensor "
+                              "(there is no CPU fallback)")
+        if not t.is_contiguous():
+            raise ValueError("non-contiguous tensor passed to the native path")
+        d = t.device if d is None else d
+        if t.device != d:
+            raise ValueError("tensors on different devices")
+    return d
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def num_frames(n, hop):
+    return load().ww_feat_num_frames(n, hop)
+
+
+def prob_threshold(p):
+    return load().ww_prob_threshold(float(p))
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    load().ww_philox4x32_10(c, k, o)
+    return list(o)
+
+
+def make_feat_cfg(sample_rate=16000, n_fft=1024, hop=160, n_mels=40, n_mfcc=0, f_min=0.0, f_max=0.0, log_eps=1e-6):
+    return FeatCfg(sample_rate, n_fft, hop, n_mels, n_mfcc, f_min, f_max, log_eps)
+
+
+def make_specaug_cfg(freq_mask_param=15, time_mask_param=35, n_freq_masks=2, n_time_masks=2, freq_mask_prob=1.0,
+                     time_mask_prob=1.0):
+    return SpecAugCfg(freq_mask_param, time_mask_param, n_freq_masks, n_time_masks, freq_mask_prob, time_mask_prob)
+
+
+def logmel_fwd(wave, cfg: FeatCfg, specaug: SpecAugCfg = None, seed=0, step=0, sample_offset=0, want_idx=False):
+    """wave (B,N) f32|i16 cuda -> (B,1,F,T) f32 [, mask_idx (B,K,2) i32]."""
+    dev = _dev(wave)
+    if wave.dim() != 2:
+        raise ValueError(f"waveform batch must be (B,N), got {tuple(wave.shape)}")
+    if wave.dtype == torch.float32:
+        dt = WAVE_F32
+    elif wave.dtype == torch.int16:
+        dt = WAVE_I16
+    else:
+        raise ValueError(f"waveform dtype must be float32 or int16, got {wave.dtype}")
+    B, N = wave.shape
+    if cfg.hop <= 0:
+        raise ValueError("hop must be positive")
+    T = 1 + N // cfg.hop
+    F = cfg.n_mfcc if cfg.n_mfcc > 0 else cfg.n_mels
+    out = torch.empty((B, 1, F, T), dtype=torch.float32, device=dev)
+    idx = None
+    if want_idx and specaug is not None:
+        idx = torch.zeros((B, specaug.n_freq_masks + specaug.n_time_masks, 2), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_logmel_fwd(ctx(dev), _p(wave), dt, B, N, C.byref(cfg), _p(out),
+                                    C.byref(specaug) if specaug is not None else None, seed, step, sample_offset,
+                                    _p(idx), _stream(dev)), "ww_logmel_fwd")
+    return (out, idx) if want_idx else out
+
+
+def specaug_apply_(x, specaug: SpecAugCfg, seed=0, step=0, sample_offset=0, want_idx=False):
+    """in-place on x (B,1,F,T) or (B,F,T) f32 cuda."""
+    dev = _dev(x)
+    if x.dtype != torch.float32 or x.dim() not in (3, 4) or (x.dim() == 4 and x.shape[1] != 1):
+        raise ValueError(f"features must be float32 (B,1,F,T) or (B,F,T), got {x.dtype} {tuple(x.shape)}")
+    B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
+    idx = None
+    if want_idx:
+        idx = torch.zeros((B, specaug.n_freq_masks + specaug.n_time_masks, 2), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_specaug_apply(ctx(dev), _p(x), B, F, T, C.byref(specaug), seed, step, sample_offset, _p(idx),
+                                       _stream(dev)), "ww_specaug_apply")
+    return idx
+
+
+def layer_scratch(dev):
+    return torch.empty(load().ww_layer_scratch_bytes() // 4, dtype=torch.float32, device=dev)
+
+
+def make_bn(gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, training=True):
+    return BN(_p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps, 1 if training else 0)
+
+
+def conv_stem_fwd(x, w, bn: BN, scratch):
+    dev = _dev(x, w, scratch)
+    B, Hin, Win = x.shape[0], x.shape[-2], x.shape[-1]
+    Ho, Wo = (Hin + 1) // 2, (Win + 1) // 2
+    y = torch.empty((B, Ho, Wo, 64), dtype=torch.float32, device=dev)
+    ss = torch.empty(128, dtype=torch.float32, device=dev)
+    mr = torch.empty(128, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_conv_stem_fwd(ctx(dev), _p(x), _p(w), B, Hin, Win, _p(y), C.byref(bn), _p(ss), _p(mr),
+                                       _p(scratch), _stream(dev)), "ww_conv_stem_fwd")
+    return y, ss, mr
+
+
+def _conv_fwd(name, y_in, ss_in, w, bn, scratch):
+    dev = _dev(y_in, ss_in, w, scratch)
+    B, H, W, Cc = y_in.shape
+    if Cc != 64:
+        raise ValueError("conv stack width is 64")
+    y = torch.empty_like(y_in)
+    ss = torch.empty(128, dtype=torch.float32, device=dev)
+    mr = torch.empty(128, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(getattr(load(), name)(ctx(dev), _p(y_in), _p(ss_in), _p(w), B, H, W, _p(y), C.byref(bn), _p(ss), _p(mr),
+                                     _p(scratch), _stream(dev)), name)
+    return y, ss, mr
+
+
+def dwconv3x3_fwd(y_in, ss_in, w, bn, scratch):
+    return _conv_fwd("ww_dwconv3x3_fwd", y_in, ss_in, w, bn, scratch)
+
+
+def pwconv1x1_fwd(y_in, ss_in, w, bn, scratch):
+    return _conv_fwd("ww_pwconv1x1_fwd", y_in, ss_in, w, bn, scratch)
+
+
+def gap_fwd(y, ss, mr):
+    dev = _dev(y, ss, mr)
+    B, H, W, _ = y.shape
+    pool = torch.empty((B, 3, 64), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_gap_fwd(ctx(dev), _p(y), _p(ss), _p(mr), B, H, W, _p(pool), _stream(dev)), "ww_gap_fwd")
+    return pool
+
+
+def head_fwd(pool, HW, fc_w, fc_b, dropout_p=0.0, training=True, seed=0, step=0, sample_offset=0):
+    dev = _dev(pool, fc_w, fc_b)
+    B = pool.shape[0]
+    pd = torch.empty((B, 64), dtype=torch.float32, device=dev)
+    logits = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_head_fwd(ctx(dev), _p(pool), B, HW, _p(fc_w), _p(fc_b), dropout_p, int(training), seed, step,
+                                  sample_offset, _p(pd), _p(logits), _stream(dev)), "ww_head_fwd")
+    return pd, logits
+
+
+def head_bwd(dlogits, pd, pool, HW, fc_w, gamma_last, mr_last, dropout_p=0.0, training=True, seed=0, step=0,
+             sample_offset=0):
+    dev = _dev(dlogits, pd, pool, fc_w, gamma_last, mr_last)
+    B = pool.shape[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    dfc_w, dfc_b = torch.empty((2, 64), **f32), torch.empty(2, **f32)
+    dpool, coef = torch.empty((B, 64), **f32), torch.empty(192, **f32)
+    dgamma, dbeta = torch.empty(64, **f32), torch.empty(64, **f32)
+    with torch.cuda.device(dev):
+        _check(load().ww_head_bwd(ctx(dev), _p(dlogits), _p(pd), _p(pool), B, HW, _p(fc_w), dropout_p, int(training),
+                                  seed, step, sample_offset, _p(gamma_last), _p(mr_last), _p(dfc_w), _p(dfc_b),
+                                  _p(dpool), _p(coef), _p(dgamma), _p(dbeta), _stream(dev)), "ww_head_bwd")
+    return dfc_w, dfc_b, dpool, coef, dgamma, dbeta
+
+
+def pwconv1x1_bwd(g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, gamma_in, w, scratch):
+    dev = _dev(g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, gamma_in, w, scratch)
+    B, H, W, _ = y_out.shape
+    f32 = dict(dtype=torch.float32, device=dev)
+    g_in, dw = torch.empty_like(y_in), torch.empty((64, 64), **f32)
+    coef_in, dgamma, dbeta = torch.empty(192, **f32), torch.empty(64, **f32), torch.empty(64, **f32)
+    with torch.cuda.device(dev):
+        _check(load().ww_pwconv1x1_bwd(ctx(dev), _p(g), _p(dpool), _p(y_out), _p(ss_out), _p(coef), _p(y_in), _p(ss_in),
+                                       _p(mr_in), _p(gamma_in), _p(w), B, H, W, _p(g_in), _p(dw), _p(coef_in),
+                                       _p(dgamma), _p(dbeta), _p(scratch), _stream(dev)), "ww_pwconv1x1_bwd")
+    return g_in, dw, coef_in, dgamma, dbeta
+
+
+def dwconv3x3_bwd(g, y_out, coef, y_in, ss_in, mr_in, gamma_in, w, scratch):
+    dev = _dev(g, y_out, coef, y_in, ss_in, mr_in, gamma_in, w, scratch)
+    B, H, W, _ = y_out.shape
+    f32 = dict(dtype=torch.float32, device=dev)
+    g_in, dw = torch.empty_like(y_in), torch.empty((64, 1, 3, 3), **f32)
+    coef_in, dgamma, dbeta = torch.empty(192, **f32), torch.empty(64, **f32), torch.empty(64, **f32)
+    with torch.cuda.device(dev):
+        _check(load().ww_dwconv3x3_bwd(ctx(dev), _p(g), _p(y_out), _p(coef), _p(y_in), _p(ss_in), _p(mr_in),
+                                       _p(gamma_in), _p(w), B, H, W, _p(g_in), _p(dw), _p(coef_in), _p(dgamma),
+                                       _p(dbeta), _p(scratch), _stream(dev)), "ww_dwconv3x3_bwd")
+    return g_in, dw, coef_in, dgamma, dbeta
+
+
+def conv_stem_bwd(g, y_out, coef, x, scratch):
+    dev = _dev(g, y_out, coef, x, scratch)
+    B, Hin, Win = x.shape[0], x.shape[-2], x.shape[-1]
+    dw = torch.empty((64, 1, 3, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_conv_stem_bwd(ctx(dev), _p(g), _p(y_out), _p(coef), _p(x), B, Hin, Win, _p(dw), _p(scratch),
+                                       _stream(dev)), "ww_conv_stem_bwd")
+    return dw
+
+
+def cnn_small_workspace_bytes(B, F, T):
+    return load().ww_cnn_small_workspace_bytes(B, F, T)
+
+
+def ptr_array(tensors):
+    arr = (_vp * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def cnn_small_fwd(params, x, ws, logits, training, bn_momentum=0.1, bn_eps=1e-5, dropout_p=0.0, seed=0, step=0,
+                  sample_offset=0):
+    dev = _dev(x, ws, logits)
+    B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
+    with torch.cuda.device(dev):
+        _check(load().ww_cnn_small_fwd(ctx(dev), params, _p(x), B, F, T, int(training), bn_momentum, bn_eps, dropout_p,
+                                       seed, step, sample_offset, _p(ws), ws.numel() * ws.element_size(), _p(logits),
+                                       _stream(dev)), "ww_cnn_small_fwd")
+
+
+def cnn_small_bwd(params, grads, x, dlogits, ws, dropout_p=0.0, seed=0, step=0, sample_offset=0):
+    dev = _dev(x, ws, dlogits)
+    B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
+    with torch.cuda.device(dev):
+        _check(load().ww_cnn_small_bwd(ctx(dev), params, grads, _p(x), _p(dlogits), B, F, T, dropout_p, seed, step,
+                                       sample_offset, _p(ws), ws.numel() * ws.element_size(), _stream(dev)),
+               "ww_cnn_small_bwd")
+
+
+def ce2_loss_fwd_bwd(logits, targets, kind=LOSS_CE, label_smoothing=0.0, focal_alpha=0.25, focal_gamma=2.0,
+                     stats=None):
+    """-> (loss (1,) f32, dlogits (B,2) f32, stats uint8[STEP_STATS_BYTES])."""
+    dev = _dev(logits, targets, stats)
+    if logits.dim() != 2 or logits.shape[1] != 2 or logits.dtype != torch.float32:
+        raise ValueError(f"native loss needs float32 logits of shape (B,2), got {logits.dtype} {tuple(logits.shape)}")
+    if targets.dim() != 1 or targets.shape[0] != logits.shape[0] or targets.dtype != torch.int64:
+        raise ValueError("targets must be int64 of shape (B,)")
+    B = logits.shape[0]
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dl = torch.empty_like(logits)
+    if stats is None:
+        stats = torch.zeros(STEP_STATS_BYTES, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_ce2_loss_fwd_bwd(ctx(dev), _p(logits), _p(targets), B, kind, label_smoothing, focal_alpha,
+                                          focal_gamma, _p(loss), _p(dl), _p(stats), _stream(dev)),
+               "ww_ce2_loss_fwd_bwd")
+    return loss, dl, stats
+
+
+def grad_norm_clip_(flat, max_norm, norm_out=None):
+    dev = _dev(flat, norm_out)
+    if norm_out is None:
+        norm_out = torch.empty(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_grad_norm_clip(ctx(dev), _p(flat), flat.numel(), float(max_norm), _p(norm_out), _stream(dev)),
+               "ww_grad_norm_clip")
+    return norm_out
+
+
+def decode_stats(stats_cpu: torch.Tensor) -> dict:
+    s = StepStats.from_buffer_copy(bytes(stats_cpu.numpy().tobytes()))
+    return {k: getattr(s, k) for k, _ in StepStats._fields_}

@@ -1,0 +1,483 @@
+// Backward kernels of the depthwise-separable conv stack (channels-last, C = 64, fp32).
+//
+// Stored tensors per layer l: y_l (PRE-BatchNorm conv output, written by forward) and
+// g_l = dL/dz_l (gradient w.r.t. the BatchNorm output, ReLU mask already applied).
+// One fused kernel per conv layer l does, in a single pass over HBM:
+//     dy_l   = A*g_l + Bc*y_l + Cc              (BatchNorm backward folded into 3 per-channel
+//                                                constants produced by the previous finalize)
+//     dW_l  += a_{l-1}^T (*) dy_l               a_{l-1} = relu(bn(y_{l-1})) recomputed on load
+//     da     = conv^T(dy_l, W_l)
+//     g_{l-1} = da * [z_{l-1} > 0]  -> HBM ;  sum g_{l-1}, sum g_{l-1}*yhat_{l-1} -> slab
+// i.e. reads g_l, y_l, y_{l-1} and writes g_{l-1}: 4 tensor passes per layer.
+// Weight-gradient and statistic partials are per-block slabs summed in double by the
+// finalize kernels (bit-reproducible; no float atomics).
+#include "ww_internal.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int PW_TILE = 128;
+constexpr int PW_LD = 68;
+
+// ------------------------------------------------------------------------------------- head
+// single block: thread = (channel c, part of 4 over the batch)
+__global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ dlogits, const float *__restrict__ pd,
+                                                  const float *__restrict__ pool, int B, int HW,
+                                                  const float *__restrict__ fc_w, float drop_scale,
+                                                  uint64_t drop_thresh, int use_dropout, uint32_t seed_lo,
+                                                  uint32_t seed_hi, uint32_t step_lo, uint32_t step_hi,
+                                                  uint64_t sample_offset, const float *__restrict__ gamma,
+                                                  const float *__restrict__ mr, float *__restrict__ dfc_w,
+                                                  float *__restrict__ dfc_b, float *__restrict__ dpool,
+                                                  float *__restrict__ coef, float *__restrict__ dgamma,
+                                                  float *__restrict__ dbeta) {
+    __shared__ double sh[6][256];
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const float w0 = fc_w[c], w1 = fc_w[64 + c];
+    const float inv_hw = 1.0f / (float)HW;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int b = part; b < B; b += 4) {
+        const float dl0 = dlogits[(size_t)b * 2], dl1 = dlogits[(size_t)b * 2 + 1];
+        const float pv = pd[(size_t)b * 64 + c];
+        a0 += (double)dl0 * pv;
+        a1 += (double)dl1 * pv;
+        b0 += dl0;
+        b1 += dl1;
+        float dp = fmaf(dl0, w0, dl1 * w1);
+        if (use_dropout) {
+            uint32_t rr[4];
+            ww_philox(step_lo, step_hi, (uint32_t)(sample_offset + (uint64_t)b), (WW_TAG_DROPOUT << 24) | (uint32_t)(c >> 2),
+                      seed_lo, seed_hi, rr);
+            dp = ((uint64_t)rr[c & 3] >= drop_thresh) ? dp * drop_scale : 0.f;
+        }
+        dp *= inv_hw;  // d mean / d element
+        dpool[(size_t)b * 64 + c] = dp;
+        s1 += (double)dp * pool[(size_t)b * 192 + 128 + c];  // * count_{z>0}
+        s2 += (double)dp * pool[(size_t)b * 192 + 64 + c];   // * sum_{z>0} yhat
+    }
+    sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1; sh[2][threadIdx.x] = b0;
+    sh[3][threadIdx.x] = b1; sh[4][threadIdx.x] = s1; sh[5][threadIdx.x] = s2;
+    __syncthreads();
+    if (part == 0) {
+        double t[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[k] = sh[k][c] + sh[k][64 + c] + sh[k][128 + c] + sh[k][192 + c];
+        dfc_w[c] = (float)t[0];
+        dfc_w[64 + c] = (float)t[1];
+        if (c == 0) {
+            dfc_b[0] = (float)t[2];
+            dfc_b[1] = (float)t[3];
+        }
+        const double count = (double)B * HW;
+        const double mean = mr[c], rstd = mr[64 + c], g = gamma[c];
+        const double c1 = t[4] / count, c2 = t[5] / count, A = g * rstd;
+        coef[c] = (float)A;
+        coef[64 + c] = (float)(-A * rstd * c2);
+        coef[128 + c] = (float)(A * (mean * rstd * c2 - c1));
+        dgamma[c] = (float)t[5];
+        dbeta[c] = (float)t[4];
+    }
+}
+
+// -------------------------------------------------------------------------------- pointwise
+// LDS: dyt[128][68] | yit[128][68]  (dynamic, 69632 B).
+// Wave roles inside a 128-pixel tile (4 waves):
+//   dX : wave (rh, n)  -> pixels [64rh, 64rh+64) x input channels [32n, 32n+32)   (64 MFMA)
+//   dW : wave (jt, kt) -> the 32x32 quadrant dW[32jt.., 32kt..] over all 128 pixels (64 MFMA)
+// so a lane keeps 32 weight registers and 16 persistent dW accumulators.
+template <bool FROM_POOL>
+__global__ __launch_bounds__(256, 2) void k_pw_bwd(const float *__restrict__ g, const float *__restrict__ dpool,
+                                                   const float *__restrict__ y_out, const float *__restrict__ ss_out,
+                                                   const float *__restrict__ coef, const float *__restrict__ y_in,
+                                                   const float *__restrict__ ss_in, const float *__restrict__ mr_in,
+                                                   const float *__restrict__ w, long M, int HW,
+                                                   float *__restrict__ g_in, float *__restrict__ stat_partials,
+                                                   float *__restrict__ dw_partials) {
+    extern __shared__ __align__(16) float lds[];
+    float *dyt = lds, *yit = lds + PW_TILE * PW_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int rh = wv >> 1, n = wv & 1;   // dX role; also (jt, kt) = (rh, n) for the dW role
+    // dX B operand of k-step s: B[j = 32h + s][k = 32n + r] = w[j][k]
+    float wt[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) wt[s] = w[(size_t)(32 * h + s) * 64 + 32 * n + r];
+    const int c4 = tid & 15;
+    const float4 cA = *reinterpret_cast<const float4 *>(coef + 4 * c4);
+    const float4 cB = *reinterpret_cast<const float4 *>(coef + 64 + 4 * c4);
+    const float4 cC = *reinterpret_cast<const float4 *>(coef + 128 + 4 * c4);
+    float4 so = make_float4(0.f, 0.f, 0.f, 0.f), to = so;
+    if (FROM_POOL) {
+        so = *reinterpret_cast<const float4 *>(ss_out + 4 * c4);
+        to = *reinterpret_cast<const float4 *>(ss_out + 64 + 4 * c4);
+    }
+    // input-layer BatchNorm constants of this lane's channel k = 32n + r
+    const float sci = ss_in[32 * n + r], sfi = ss_in[64 + 32 * n + r];
+    const float mui = mr_in[32 * n + r], rsi = mr_in[64 + 32 * n + r];
+    floatx16 dwacc = {0.f};
+    float st1 = 0.f, st2 = 0.f;
+
+    const long ntiles = (M + PW_TILE - 1) / PW_TILE;
+    for (long ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const long p0 = ti * PW_TILE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (tid >> 4) + 16 * i;
+            const long p = p0 + row;
+            float4 dy = make_float4(0.f, 0.f, 0.f, 0.f), yi = dy;
+            if (p < M) {
+                const float4 yo = *reinterpret_cast<const float4 *>(y_out + (size_t)p * 64 + 4 * c4);
+                float4 dz;
+                if (FROM_POOL) {
+                    const float4 dp = *reinterpret_cast<const float4 *>(dpool + (size_t)(p / HW) * 64 + 4 * c4);
+                    dz.x = fmaf(yo.x, so.x, to.x) > 0.f ? dp.x : 0.f;
+                    dz.y = fmaf(yo.y, so.y, to.y) > 0.f ? dp.y : 0.f;
+                    dz.z = fmaf(yo.z, so.z, to.z) > 0.f ? dp.z : 0.f;
+                    dz.w = fmaf(yo.w, so.w, to.w) > 0.f ? dp.w : 0.f;
+                } else {
+                    dz = *reinterpret_cast<const float4 *>(g + (size_t)p * 64 + 4 * c4);
+                }
+                dy.x = fmaf(cA.x, dz.x, fmaf(cB.x, yo.x, cC.x));
+                dy.y = fmaf(cA.y, dz.y, fmaf(cB.y, yo.y, cC.y));
+                dy.z = fmaf(cA.z, dz.z, fmaf(cB.z, yo.z, cC.z));
+                dy.w = fmaf(cA.w, dz.w, fmaf(cB.w, yo.w, cC.w));
+                yi = *reinterpret_cast<const float4 *>(y_in + (size_t)p * 64 + 4 * c4);
+            }
+            *reinterpret_cast<float4 *>(dyt + row * PW_LD + 4 * c4) = dy;   // rows past M: dy = 0, y_in = 0
+            *reinterpret_cast<float4 *>(yit + row * PW_LD + 4 * c4) = yi;
+        }
+        __syncthreads();
+        // ---- dX = dy . W   (rows = pixels, K = output channel j, cols = input channel k)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int rbase = 64 * rh + 32 * t;
+            float a[32];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 v = *reinterpret_cast<const float4 *>(dyt + (rbase + r) * PW_LD + 32 * h + 4 * j);
+                a[4 * j] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+            }
+            floatx16 acc = {0.f};
+#pragma unroll
+            for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wt[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const long p = p0 + prow;
+                const float yv = yit[prow * PW_LD + 32 * n + r];
+                const float d = fmaf(yv, sci, sfi) > 0.f ? acc[reg] : 0.f;
+                if (p < M) g_in[(size_t)p * 64 + 32 * n + r] = d;
+                st1 += d;
+                st2 = fmaf(d, (yv - mui) * rsi, st2);
+            }
+        }
+        // ---- dW[j][k] += sum_p dy[p][j] * a[p][k] ; K = pixels, lane half h <-> pixel 64h + s
+#pragma unroll 16
+        for (int s = 0; s < 64; ++s) {
+            const int prow = 64 * h + s;
+            const float dyv = dyt[prow * PW_LD + 32 * rh + r];
+            const float av = fmaxf(fmaf(yit[prow * PW_LD + 32 * n + r], sci, sfi), 0.f);
+            dwacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dyv, av, dwacc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- block partials: statistics (sum over the two row-halves), dW quadrant straight from registers
+    st1 += __shfl_xor(st1, 32);
+    st2 += __shfl_xor(st2, 32);
+    float *shs = lds;  // [wave][kind][32]
+    if (h == 0) {
+        shs[wv * 64 + r] = st1;
+        shs[wv * 64 + 32 + r] = st2;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int kind = tid >> 6, c = tid & 63, nn = c >> 5, rr = c & 31;
+        stat_partials[(size_t)blockIdx.x * 128 + tid] = shs[nn * 64 + kind * 32 + rr] + shs[(2 + nn) * 64 + kind * 32 + rr];
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int j = 32 * rh + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        dw_partials[(size_t)blockIdx.x * 4096 + j * 64 + 32 * n + r] = dwacc[reg];
+    }
+}
+
+// -------------------------------------------------------------------------------- depthwise
+struct DwGeom {
+    int B, H, W, ncs, nseg, hs_len;
+    long items;
+};
+
+__device__ __forceinline__ void dwb_load_dy(const float *__restrict__ gimg, const float *__restrict__ yimg, int h,
+                                            int w0, int H, int W, float2 cA, float2 cB, float2 cC, int cl,
+                                            float2 (&r)[6]) {
+    const bool hv = (h >= 0) && (h < H);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int wc = w0 - 1 + i;
+        float2 v = make_float2(0.f, 0.f);
+        if (hv && wc >= 0 && wc < W) {
+            const size_t o = ((size_t)h * W + wc) * 64 + 2 * cl;
+            const float2 gz = *reinterpret_cast<const float2 *>(gimg + o);
+            const float2 yo = *reinterpret_cast<const float2 *>(yimg + o);
+            v.x = fmaf(cA.x, gz.x, fmaf(cB.x, yo.x, cC.x));
+            v.y = fmaf(cA.y, gz.y, fmaf(cB.y, yo.y, cC.y));
+        }
+        r[i] = v;
+    }
+}
+
+// centre row h:  rs0 = dy[h+1] (pairs with weight row 0), rs1 = dy[h], rs2 = dy[h-1]
+__device__ __forceinline__ void dwb_row(const float *__restrict__ yin_img, float *__restrict__ gin_img, int h, int w0,
+                                        int W, int cl, const float2 (&rs0)[6], const float2 (&rs1)[6],
+                                        const float2 (&rs2)[6], const float (&wa)[9], const float (&wb)[9], float2 sc,
+                                        float2 sf, float2 mu, float2 rsd, float (&dwa)[9], float (&dwb)[9], float &s1a,
+                                        float &s1b, float &s2a, float &s2b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (w0 + i < W) {
+            const size_t o = ((size_t)h * W + w0 + i) * 64 + 2 * cl;
+            const float2 yv = *reinterpret_cast<const float2 *>(yin_img + o);
+            const float z0 = fmaf(yv.x, sc.x, sf.x), z1 = fmaf(yv.y, sc.y, sf.y);
+            const float a0 = fmaxf(z0, 0.f), a1 = fmaxf(z1, 0.f);
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float2 t0 = rs0[i + 2 - kw], t1 = rs1[i + 2 - kw], t2 = rs2[i + 2 - kw];
+                d0 = fmaf(t0.x, wa[kw], d0);     d1 = fmaf(t0.y, wb[kw], d1);
+                d0 = fmaf(t1.x, wa[3 + kw], d0); d1 = fmaf(t1.y, wb[3 + kw], d1);
+                d0 = fmaf(t2.x, wa[6 + kw], d0); d1 = fmaf(t2.y, wb[6 + kw], d1);
+                dwa[kw] = fmaf(a0, t0.x, dwa[kw]);         dwb[kw] = fmaf(a1, t0.y, dwb[kw]);
+                dwa[3 + kw] = fmaf(a0, t1.x, dwa[3 + kw]); dwb[3 + kw] = fmaf(a1, t1.y, dwb[3 + kw]);
+                dwa[6 + kw] = fmaf(a0, t2.x, dwa[6 + kw]); dwb[6 + kw] = fmaf(a1, t2.y, dwb[6 + kw]);
+            }
+            const float g0 = z0 > 0.f ? d0 : 0.f, g1 = z1 > 0.f ? d1 : 0.f;
+            *reinterpret_cast<float2 *>(gin_img + o) = make_float2(g0, g1);
+            s1a += g0; s1b += g1;
+            s2a = fmaf(g0, (yv.x - mu.x) * rsd.x, s2a);
+            s2b = fmaf(g1, (yv.y - mu.y) * rsd.y, s2b);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dw_bwd(const float *__restrict__ g, const float *__restrict__ y_out,
+                                                const float *__restrict__ coef, const float *__restrict__ y_in,
+                                                const float *__restrict__ ss_in, const float *__restrict__ mr_in,
+                                                const float *__restrict__ w, DwGeom gm, float *__restrict__ g_in,
+                                                float *__restrict__ stat_partials, float *__restrict__ dw_partials) {
+    __shared__ float sh[8 * 576];
+    const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
+    float wa[9], wb[9], dwa[9], dwb[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        wa[t] = w[(2 * cl) * 9 + t];
+        wb[t] = w[(2 * cl + 1) * 9 + t];
+        dwa[t] = 0.f;
+        dwb[t] = 0.f;
+    }
+    const float2 cA = *reinterpret_cast<const float2 *>(coef + 2 * cl);
+    const float2 cB = *reinterpret_cast<const float2 *>(coef + 64 + 2 * cl);
+    const float2 cC = *reinterpret_cast<const float2 *>(coef + 128 + 2 * cl);
+    const float2 sc = *reinterpret_cast<const float2 *>(ss_in + 2 * cl);
+    const float2 sf = *reinterpret_cast<const float2 *>(ss_in + 64 + 2 * cl);
+    const float2 mu = *reinterpret_cast<const float2 *>(mr_in + 2 * cl);
+    const float2 rsd = *reinterpret_cast<const float2 *>(mr_in + 64 + 2 * cl);
+    float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
+    const size_t img_stride = (size_t)gm.H * gm.W * 64;
+    for (long item = (long)blockIdx.x * 8 + slot; item < gm.items; item += (long)gridDim.x * 8) {
+        const int cs = (int)(item % gm.ncs);
+        const long t = item / gm.ncs;
+        const int seg = (int)(t % gm.nseg), b = (int)(t / gm.nseg);
+        const int w0 = cs * 4, hs = seg * gm.hs_len;
+        const int he = min(gm.H, hs + gm.hs_len);
+        const float *gimg = g + (size_t)b * img_stride;
+        const float *yoimg = y_out + (size_t)b * img_stride;
+        const float *yiimg = y_in + (size_t)b * img_stride;
+        float *giimg = g_in + (size_t)b * img_stride;
+        float2 r0[6], r1[6], r2[6];  // r0 = dy[h-1], r1 = dy[h], r2 = dy[h+1] at loop entry
+        dwb_load_dy(gimg, yoimg, hs - 1, w0, gm.H, gm.W, cA, cB, cC, cl, r0);
+        dwb_load_dy(gimg, yoimg, hs, w0, gm.H, gm.W, cA, cB, cC, cl, r1);
+        for (int h = hs; h < he; h += 3) {
+            dwb_load_dy(gimg, yoimg, h + 1, w0, gm.H, gm.W, cA, cB, cC, cl, r2);
+            dwb_row(yiimg, giimg, h, w0, gm.W, cl, r2, r1, r0, wa, wb, sc, sf, mu, rsd, dwa, dwb, s1a, s1b, s2a, s2b);
+            if (h + 1 < he) {
+                dwb_load_dy(gimg, yoimg, h + 2, w0, gm.H, gm.W, cA, cB, cC, cl, r0);
+                dwb_row(yiimg, giimg, h + 1, w0, gm.W, cl, r0, r2, r1, wa, wb, sc, sf, mu, rsd, dwa, dwb, s1a, s1b, s2a,
+                        s2b);
+            }
+            if (h + 2 < he) {
+                dwb_load_dy(gimg, yoimg, h + 3, w0, gm.H, gm.W, cA, cB, cC, cl, r1);
+                dwb_row(yiimg, giimg, h + 2, w0, gm.W, cl, r1, r0, r2, wa, wb, sc, sf, mu, rsd, dwa, dwb, s1a, s1b, s2a,
+                        s2b);
+            }
+        }
+    }
+    // statistics partial
+    sh[slot * 128 + 2 * cl] = s1a;       sh[slot * 128 + 2 * cl + 1] = s1b;
+    sh[slot * 128 + 64 + 2 * cl] = s2a;  sh[slot * 128 + 64 + 2 * cl + 1] = s2b;
+    __syncthreads();
+    if (tid < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) t += sh[s * 128 + tid];
+        stat_partials[(size_t)blockIdx.x * 128 + tid] = t;
+    }
+    __syncthreads();
+    // weight-gradient partial, layout [c][tap] like Conv2d.weight (64,1,3,3)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        sh[slot * 576 + (2 * cl) * 9 + t] = dwa[t];
+        sh[slot * 576 + (2 * cl + 1) * 9 + t] = dwb[t];
+    }
+    __syncthreads();
+    for (int i = tid; i < 576; i += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) t += sh[s * 576 + i];
+        dw_partials[(size_t)blockIdx.x * 576 + i] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------- stem
+__global__ __launch_bounds__(256) void k_stem_bwd(const float *__restrict__ g, const float *__restrict__ y_out,
+                                                  const float *__restrict__ coef, const float *__restrict__ x, int B,
+                                                  int Hin, int Win, int Ho, int Wo, float *__restrict__ dw_partials) {
+    __shared__ float sh[8 * 576];
+    const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
+    const float2 cA = *reinterpret_cast<const float2 *>(coef + 2 * cl);
+    const float2 cB = *reinterpret_cast<const float2 *>(coef + 64 + 2 * cl);
+    const float2 cC = *reinterpret_cast<const float2 *>(coef + 128 + 2 * cl);
+    float dwa[9], dwb[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dwa[t] = dwb[t] = 0.f;
+    const long nrows = (long)B * Ho;
+    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int b = (int)(row / Ho), oh = (int)(row - (long)b * Ho);
+        const float *xb = x + (size_t)b * Hin * Win;
+        for (int ow = slot; ow < Wo; ow += 8) {
+            const size_t o = ((size_t)row * Wo + ow) * 64 + 2 * cl;
+            const float2 gz = *reinterpret_cast<const float2 *>(g + o);
+            const float2 yo = *reinterpret_cast<const float2 *>(y_out + o);
+            const float d0 = fmaf(cA.x, gz.x, fmaf(cB.x, yo.x, cC.x));
+            const float d1 = fmaf(cA.y, gz.y, fmaf(cB.y, yo.y, cC.y));
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = 2 * oh - 1 + kh;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = 2 * ow - 1 + kw;
+                    const float v = (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+                    dwa[kh * 3 + kw] = fmaf(d0, v, dwa[kh * 3 + kw]);
+                    dwb[kh * 3 + kw] = fmaf(d1, v, dwb[kh * 3 + kw]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        sh[slot * 576 + (2 * cl) * 9 + t] = dwa[t];
+        sh[slot * 576 + (2 * cl + 1) * 9 + t] = dwb[t];
+    }
+    __syncthreads();
+    for (int i = tid; i < 576; i += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) t += sh[s * 576 + i];
+        dw_partials[(size_t)blockIdx.x * 576 + i] = t;
+    }
+}
+
+}  // namespace
+
+extern "C" int ww_head_bwd(ww_ctx *ctx, const float *dlogits, const float *pd, const float *pool, int B, int HW,
+                           const float *fc_w, float dropout_p, int training, uint64_t seed, uint64_t step,
+                           uint64_t sample_offset, const float *gamma_last, const float *mr_last, float *dfc_w,
+                           float *dfc_b, float *dpool, float *coef_last, float *dgamma_last, float *dbeta_last,
+                           ww_stream_t stream) {
+    WW_REQUIRE(ctx && dlogits && pd && pool && fc_w && gamma_last && mr_last && dfc_w && dfc_b && dpool && coef_last &&
+                   dgamma_last && dbeta_last,
+               WW_E_INVALID, "ww_head_bwd: null argument");
+    WW_REQUIRE(B >= 1 && HW >= 1, WW_E_INVALID, "ww_head_bwd: bad shape (%d,%d)", B, HW);
+    WW_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, WW_E_INVALID, "ww_head_bwd: dropout_p=%f not in [0,1)", dropout_p);
+    const int use_dropout = training && dropout_p > 0.f;
+    const float scale = (float)(1.0 / (1.0 - (double)dropout_p));
+    hipLaunchKernelGGL(k_head_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream, dlogits, pd, pool, B, HW, fc_w, scale,
+                       ww_prob_threshold((double)dropout_p), use_dropout, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       (uint32_t)step, (uint32_t)(step >> 32), sample_offset, gamma_last, mr_last, dfc_w, dfc_b, dpool,
+                       coef_last, dgamma_last, dbeta_last);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+
+extern "C" int ww_pwconv1x1_bwd(ww_ctx *ctx, const float *g, const float *dpool, const float *y_out,
+                                const float *ss_out, const float *coef, const float *y_in, const float *ss_in,
+                                const float *mr_in, const float *gamma_in, const float *w, int B, int H, int W,
+                                float *g_in, float *dw, float *coef_in, float *dgamma_in, float *dbeta_in,
+                                void *scratch, ww_stream_t stream) {
+    WW_REQUIRE(ctx && y_out && coef && y_in && ss_in && mr_in && gamma_in && w && g_in && dw && coef_in && dgamma_in &&
+                   dbeta_in && scratch,
+               WW_E_INVALID, "ww_pwconv1x1_bwd: null argument");
+    WW_REQUIRE(g || (dpool && ss_out), WW_E_INVALID, "ww_pwconv1x1_bwd: need g, or dpool + ss_out for the last layer");
+    WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_pwconv1x1_bwd: bad shape (%d,%d,%d)", B, H, W);
+    const long M = (long)B * H * W;
+    const long ntiles = (M + PW_TILE - 1) / PW_TILE;
+    const size_t smem = (size_t)2 * PW_TILE * PW_LD * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    float *stat = (float *)scratch, *dwp = stat + WW_STAT_SLAB_FLOATS;
+    int grid;
+    if (g) {
+        WW_HIP(hipFuncSetAttribute((const void *)k_pw_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        grid = ww_occupancy_grid((const void *)k_pw_bwd<false>, 256, smem, ntiles, WW_DW_SLAB_ROWS);
+        hipLaunchKernelGGL(k_pw_bwd<false>, dim3(grid), dim3(256), smem, st, g, dpool, y_out, ss_out, coef, y_in, ss_in,
+                           mr_in, w, M, H * W, g_in, stat, dwp);
+    } else {
+        WW_HIP(hipFuncSetAttribute((const void *)k_pw_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        grid = ww_occupancy_grid((const void *)k_pw_bwd<true>, 256, smem, ntiles, WW_DW_SLAB_ROWS);
+        hipLaunchKernelGGL(k_pw_bwd<true>, dim3(grid), dim3(256), smem, st, g, dpool, y_out, ss_out, coef, y_in, ss_in,
+                           mr_in, w, M, H * W, g_in, stat, dwp);
+    }
+    WW_LAUNCH_CHECK();
+    int rc = ww_launch_bn_bwd_finalize(stat, grid, (double)M, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, st);
+    if (rc) return rc;
+    return ww_launch_colsum(dwp, grid, 4096, dw, st);
+}
+
+extern "C" int ww_dwconv3x3_bwd(ww_ctx *ctx, const float *g, const float *y_out, const float *coef, const float *y_in,
+                                const float *ss_in, const float *mr_in, const float *gamma_in, const float *w, int B,
+                                int H, int W, float *g_in, float *dw, float *coef_in, float *dgamma_in,
+                                float *dbeta_in, void *scratch, ww_stream_t stream) {
+    WW_REQUIRE(ctx && g && y_out && coef && y_in && ss_in && mr_in && gamma_in && w && g_in && dw && coef_in &&
+                   dgamma_in && dbeta_in && scratch,
+               WW_E_INVALID, "ww_dwconv3x3_bwd: null argument");
+    WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_dwconv3x3_bwd: bad shape (%d,%d,%d)", B, H, W);
+    DwGeom gm;
+    gm.B = B; gm.H = H; gm.W = W;
+    gm.ncs = (W + 3) / 4;
+    gm.nseg = H >= 16 ? 2 : 1;
+    gm.hs_len = (H + gm.nseg - 1) / gm.nseg;
+    gm.items = (long)B * gm.nseg * gm.ncs;
+    const long nblk = (gm.items + 7) / 8;
+    hipStream_t st = (hipStream_t)stream;
+    float *stat = (float *)scratch, *dwp = stat + WW_STAT_SLAB_FLOATS;
+    const int grid = ww_occupancy_grid((const void *)k_dw_bwd, 256, 0, nblk, WW_MAX_PARTIALS);
+    hipLaunchKernelGGL(k_dw_bwd, dim3(grid), dim3(256), 0, st, g, y_out, coef, y_in, ss_in, mr_in, w, gm, g_in, stat,
+                       dwp);
+    WW_LAUNCH_CHECK();
+    int rc = ww_launch_bn_bwd_finalize(stat, grid, (double)B * H * W, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, st);
+    if (rc) return rc;
+    return ww_launch_colsum(dwp, grid, 576, dw, st);
+}
+
+extern "C" int ww_conv_stem_bwd(ww_ctx *ctx, const float *g, const float *y_out, const float *coef, const float *x,
+                                int B, int Hin, int Win, float *dw, void *scratch, ww_stream_t stream) {
+    WW_REQUIRE(ctx && g && y_out && coef && x && dw && scratch, WW_E_INVALID, "ww_conv_stem_bwd: null argument");
+    WW_REQUIRE(B >= 1 && Hin >= 1 && Win >= 1, WW_E_INVALID, "ww_conv_stem_bwd: bad shape (%d,%d,%d)", B, Hin, Win);
+    const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
+    const long nrows = (long)B * Ho;
+    hipStream_t st = (hipStream_t)stream;
+    float *dwp = (float *)scratch + WW_STAT_SLAB_FLOATS;
+    const int grid = ww_occupancy_grid((const void *)k_stem_bwd, 256, 0, nrows, WW_MAX_PARTIALS);
+    hipLaunchKernelGGL(k_stem_bwd, dim3(grid), dim3(256), 0, st, g, y_out, coef, x, B, Hin, Win, Ho, Wo, dwp);
+    WW_LAUNCH_CHECK();
+    return ww_launch_colsum(dwp, grid, 576, dw, st);
+}

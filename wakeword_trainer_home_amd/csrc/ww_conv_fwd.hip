@@ -1,0 +1,408 @@
+// Forward kernels of the depthwise-separable conv stack (channels-last, C = 64, fp32).
+//
+// Every conv kernel (a) applies the PRODUCER layer's BatchNorm+ReLU while loading (scale/shift
+// per channel), (b) writes its own PRE-BatchNorm output once, and (c) accumulates the
+// per-channel sum / sum-of-squares of that output in registers; block partials go to a slab
+// that a 1-block finalize kernel sums in double (ww_ctx.hip).  Normalised activations never
+// touch HBM: per layer the traffic is one read + one write of the (B,H,W,64) tensor.
+//
+// Thread maps:
+//   stem / depthwise / GAP : 32 lanes x float2 = one pixel's 64 channels (256 B, coalesced);
+//                            a wavefront holds 2 pixels; channel statistics stay per-lane.
+//   depthwise              : a 32-lane group walks DOWN a 4-column strip keeping a 3x6 pixel
+//                            window in registers, so each input pixel is fetched 1.5x from L1/L2
+//                            and once from HBM; no LDS, no barriers in the main loop.
+//   pointwise              : M=B*H*W rows x K=64 x N=64 GEMM on v_mfma_f32_32x32x2_f32 (exact
+//                            fp32, same rate as the fp32 VALU but no LDS broadcast traffic);
+//                            128-pixel tiles staged coalesced -> BN+ReLU in registers -> LDS
+//                            (272-byte padded rows) -> conflict-free ds_read_b128 fragments; the
+//                            64x64 weight lives in 64 VGPRs per lane for the whole kernel.
+#include "ww_internal.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float bnrelu(float y, float s, float t) { return fmaxf(fmaf(y, s, t), 0.f); }
+
+// block-level reduction of per-lane channel statistics -> partial row [sum(64) | sumsq(64)]
+// lanes: cl = tid & 31 owns channels 2cl, 2cl+1 ; 8 pixel slots per 256-thread block
+__device__ __forceinline__ void reduce_stats_slots(float s0, float s1, float q0, float q1, float *sh /*8*128*/,
+                                                   float *__restrict__ partial_row) {
+    const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
+    __syncthreads();
+    sh[slot * 128 + 2 * cl] = s0;
+    sh[slot * 128 + 2 * cl + 1] = s1;
+    sh[slot * 128 + 64 + 2 * cl] = q0;
+    sh[slot * 128 + 64 + 2 * cl + 1] = q1;
+    __syncthreads();
+    if (tid < 128) {
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) t += sh[s * 128 + tid];
+        partial_row[tid] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------- stem
+// x (B,Hin,Win) -> y (B,Ho,Wo,64) ; 3x3 stride 2 pad 1 ; one (b,oh) output row per iteration
+__global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ x, const float *__restrict__ w, int B,
+                                                  int Hin, int Win, int Ho, int Wo, float *__restrict__ y,
+                                                  float *__restrict__ partials) {
+    __shared__ float sh[8 * 128];
+    const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
+    float w0[9], w1[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        w0[t] = w[(2 * cl) * 9 + t];
+        w1[t] = w[(2 * cl + 1) * 9 + t];
+    }
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    const long nrows = (long)B * Ho;
+    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int b = (int)(row / Ho), oh = (int)(row - (long)b * Ho);
+        const float *xb = x + (size_t)b * Hin * Win;
+        for (int ow = slot; ow < Wo; ow += 8) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = 2 * oh - 1 + kh;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = 2 * ow - 1 + kw;
+                    const float v = (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+                    a0 = fmaf(v, w0[kh * 3 + kw], a0);
+                    a1 = fmaf(v, w1[kh * 3 + kw], a1);
+                }
+            }
+            *reinterpret_cast<float2 *>(y + ((size_t)row * Wo + ow) * 64 + 2 * cl) = make_float2(a0, a1);
+            s0 += a0; s1 += a1;
+            q0 = fmaf(a0, a0, q0); q1 = fmaf(a1, a1, q1);
+        }
+    }
+    if (partials) reduce_stats_slots(s0, s1, q0, q1, sh, partials + (size_t)blockIdx.x * 128);
+}
+
+// -------------------------------------------------------------------------------- depthwise
+struct DwGeom {
+    int B, H, W, ncs, nseg, hs_len;  // column strips per row, row segments per image, rows per segment
+    long items;
+};
+
+__device__ __forceinline__ void dw_load_row(const float *__restrict__ img, int h, int w0, int H, int W, float2 sc,
+                                            float2 sf, int cl, float2 (&r)[6]) {
+    const bool hv = (h >= 0) && (h < H);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int wc = w0 - 1 + i;
+        float2 v = make_float2(0.f, 0.f);
+        if (hv && wc >= 0 && wc < W) {
+            const float2 t = *reinterpret_cast<const float2 *>(img + ((size_t)h * W + wc) * 64 + 2 * cl);
+            v.x = bnrelu(t.x, sc.x, sf.x);
+            v.y = bnrelu(t.y, sc.y, sf.y);
+        }
+        r[i] = v;
+    }
+}
+
+__device__ __forceinline__ void dw_out_row(float *__restrict__ oimg, int h, int w0, int W, int cl,
+                                           const float2 (&top)[6], const float2 (&mid)[6], const float2 (&bot)[6],
+                                           const float (&wa)[9], const float (&wb)[9], float &s0, float &s1, float &q0,
+                                           float &q1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            a0 = fmaf(top[i + kw].x, wa[kw], a0);
+            a1 = fmaf(top[i + kw].y, wb[kw], a1);
+            a0 = fmaf(mid[i + kw].x, wa[3 + kw], a0);
+            a1 = fmaf(mid[i + kw].y, wb[3 + kw], a1);
+            a0 = fmaf(bot[i + kw].x, wa[6 + kw], a0);
+            a1 = fmaf(bot[i + kw].y, wb[6 + kw], a1);
+        }
+        if (w0 + i < W) {
+            *reinterpret_cast<float2 *>(oimg + ((size_t)h * W + w0 + i) * 64 + 2 * cl) = make_float2(a0, a1);
+            s0 += a0; s1 += a1;
+            q0 = fmaf(a0, a0, q0); q1 = fmaf(a1, a1, q1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dw_fwd(const float *__restrict__ yin, const float *__restrict__ ss,
+                                                const float *__restrict__ w, DwGeom g, float *__restrict__ y,
+                                                float *__restrict__ partials) {
+    __shared__ float sh[8 * 128];
+    const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
+    float wa[9], wb[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        wa[t] = w[(2 * cl) * 9 + t];
+        wb[t] = w[(2 * cl + 1) * 9 + t];
+    }
+    const float2 sc = *reinterpret_cast<const float2 *>(ss + 2 * cl);
+    const float2 sf = *reinterpret_cast<const float2 *>(ss + 64 + 2 * cl);
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    const size_t img_stride = (size_t)g.H * g.W * 64;
+    for (long item = (long)blockIdx.x * 8 + slot; item < g.items; item += (long)gridDim.x * 8) {
+        const int cs = (int)(item % g.ncs);
+        const long t = item / g.ncs;
+        const int seg = (int)(t % g.nseg), b = (int)(t / g.nseg);
+        const int w0 = cs * 4, hs = seg * g.hs_len;
+        const int he = min(g.H, hs + g.hs_len);
+        const float *img = yin + (size_t)b * img_stride;
+        float *oimg = y + (size_t)b * img_stride;
+        float2 r0[6], r1[6], r2[6];
+        dw_load_row(img, hs - 1, w0, g.H, g.W, sc, sf, cl, r0);
+        dw_load_row(img, hs, w0, g.H, g.W, sc, sf, cl, r1);
+        for (int h = hs; h < he; h += 3) {
+            dw_load_row(img, h + 1, w0, g.H, g.W, sc, sf, cl, r2);
+            dw_out_row(oimg, h, w0, g.W, cl, r0, r1, r2, wa, wb, s0, s1, q0, q1);
+            if (h + 1 < he) {
+                dw_load_row(img, h + 2, w0, g.H, g.W, sc, sf, cl, r0);
+                dw_out_row(oimg, h + 1, w0, g.W, cl, r1, r2, r0, wa, wb, s0, s1, q0, q1);
+            }
+            if (h + 2 < he) {
+                dw_load_row(img, h + 3, w0, g.H, g.W, sc, sf, cl, r1);
+                dw_out_row(oimg, h + 2, w0, g.W, cl, r2, r0, r1, wa, wb, s0, s1, q0, q1);
+            }
+        }
+    }
+    if (partials) reduce_stats_slots(s0, s1, q0, q1, sh, partials + (size_t)blockIdx.x * 128);
+}
+
+// -------------------------------------------------------------------------------- pointwise
+constexpr int PW_TILE = 128;    // pixels per workgroup tile (32 per wavefront)
+constexpr int PW_LD = 68;       // padded LDS row (floats): 272 B -> conflict-free ds_read_b128 / ds_write_b128
+
+__global__ __launch_bounds__(256) void k_pw_fwd(const float *__restrict__ yin, const float *__restrict__ ss,
+                                                const float *__restrict__ w, long M, float *__restrict__ y,
+                                                float *__restrict__ partials) {
+    __shared__ __align__(16) float tile[PW_TILE * PW_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // wave (rh, n) owns pixels [64rh, 64rh+64) x output channels [32n, 32n+32) of the tile
+    const int rh = wv >> 1, n = wv & 1;
+    // B operand of k-step s: W_kn[k = 32h + s][j = 32n + r] = w[j][k]  (the K order is permuted
+    // identically for A and B: lane half h covers input channels 32h .. 32h+31)
+    float wreg[32];
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+        const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)(32 * n + r) * 64 + 32 * h + 4 * s4);
+        wreg[4 * s4] = v.x; wreg[4 * s4 + 1] = v.y; wreg[4 * s4 + 2] = v.z; wreg[4 * s4 + 3] = v.w;
+    }
+    const int c4 = tid & 15;
+    const float4 sc = *reinterpret_cast<const float4 *>(ss + 4 * c4);
+    const float4 sf = *reinterpret_cast<const float4 *>(ss + 64 + 4 * c4);
+    float s1 = 0.f, s2 = 0.f;
+    const long ntiles = (M + PW_TILE - 1) / PW_TILE;
+    for (long ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const long p0 = ti * PW_TILE;
+        // stage: coalesced 16-B loads, BN+ReLU in registers, padded LDS rows
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (tid >> 4) + 16 * i;
+            const long p = p0 + row;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < M) {
+                const float4 v = *reinterpret_cast<const float4 *>(yin + (size_t)p * 64 + 4 * c4);
+                a.x = bnrelu(v.x, sc.x, sf.x); a.y = bnrelu(v.y, sc.y, sf.y);
+                a.z = bnrelu(v.z, sc.z, sf.z); a.w = bnrelu(v.w, sc.w, sf.w);
+            }
+            *reinterpret_cast<float4 *>(tile + row * PW_LD + 4 * c4) = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int rbase = 64 * rh + 32 * t;
+            float a[32];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 v = *reinterpret_cast<const float4 *>(tile + (rbase + r) * PW_LD + 32 * h + 4 * j);
+                a[4 * j] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+            }
+            floatx16 acc = {0.f};
+#pragma unroll
+            for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wreg[s], acc, 0, 0, 0);
+            // D layout: col = lane&31 (output channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long p = p0 + rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const float v = acc[reg];
+                if (p < M) y[(size_t)p * 64 + 32 * n + r] = v;
+                s1 += v;                      // rows past M are exact zeros
+                s2 = fmaf(v, v, s2);
+            }
+        }
+        __syncthreads();
+    }
+    if (partials) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        float *sh = tile;  // [wave][kind][32]
+        if (h == 0) {
+            sh[wv * 64 + r] = s1;
+            sh[wv * 64 + 32 + r] = s2;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int kind = tid >> 6, c = tid & 63, nn = c >> 5, rr = c & 31;
+            partials[(size_t)blockIdx.x * 128 + tid] = sh[nn * 64 + kind * 32 + rr] + sh[(2 + nn) * 64 + kind * 32 + rr];
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------- GAP
+// pool[b] = [sum relu(z) (64) | sum_{z>0} yhat (64) | count_{z>0} (64)]
+__global__ __launch_bounds__(256) void k_gap_fwd(const float *__restrict__ y, const float *__restrict__ ss,
+                                                 const float *__restrict__ mr, int HW, float *__restrict__ pool) {
+    __shared__ float sh[8 * 192];
+    const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31, b = blockIdx.x;
+    const float2 sc = *reinterpret_cast<const float2 *>(ss + 2 * cl);
+    const float2 sf = *reinterpret_cast<const float2 *>(ss + 64 + 2 * cl);
+    const float2 mu = *reinterpret_cast<const float2 *>(mr + 2 * cl);
+    const float2 rs = *reinterpret_cast<const float2 *>(mr + 64 + 2 * cl);
+    const float *yb = y + (size_t)b * HW * 64;
+    float a0 = 0.f, a1 = 0.f, h0 = 0.f, h1 = 0.f, c0 = 0.f, c1 = 0.f;
+    for (int p = slot; p < HW; p += 8) {
+        const float2 v = *reinterpret_cast<const float2 *>(yb + (size_t)p * 64 + 2 * cl);
+        const float z0 = fmaf(v.x, sc.x, sf.x), z1 = fmaf(v.y, sc.y, sf.y);
+        if (z0 > 0.f) { a0 += z0; h0 += (v.x - mu.x) * rs.x; c0 += 1.f; }
+        if (z1 > 0.f) { a1 += z1; h1 += (v.y - mu.y) * rs.y; c1 += 1.f; }
+    }
+    sh[slot * 192 + 2 * cl] = a0;        sh[slot * 192 + 2 * cl + 1] = a1;
+    sh[slot * 192 + 64 + 2 * cl] = h0;   sh[slot * 192 + 64 + 2 * cl + 1] = h1;
+    sh[slot * 192 + 128 + 2 * cl] = c0;  sh[slot * 192 + 128 + 2 * cl + 1] = c1;
+    __syncthreads();
+    if (tid < 192) {
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) t += sh[s * 192 + tid];
+        pool[(size_t)b * 192 + tid] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------- head
+// one wavefront per sample: lane = channel
+__global__ __launch_bounds__(256) void k_head_fwd(const float *__restrict__ pool, int B, int HW,
+                                                  const float *__restrict__ fc_w, const float *__restrict__ fc_b,
+                                                  float drop_scale, uint64_t drop_thresh, int use_dropout,
+                                                  uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo, uint32_t step_hi,
+                                                  uint64_t sample_offset, float *__restrict__ pd,
+                                                  float *__restrict__ logits) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float v = pool[(size_t)b * 192 + lane] / (float)HW;
+    if (use_dropout) {
+        uint32_t rr[4];
+        ww_philox(step_lo, step_hi, (uint32_t)(sample_offset + (uint64_t)b), (WW_TAG_DROPOUT << 24) | (uint32_t)(lane >> 2),
+                  seed_lo, seed_hi, rr);
+        const uint32_t d = rr[lane & 3];
+        v = ((uint64_t)d >= drop_thresh) ? v * drop_scale : 0.f;
+    }
+    pd[(size_t)b * 64 + lane] = v;
+    float l0 = v * fc_w[lane], l1 = v * fc_w[64 + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        l0 += __shfl_xor(l0, o);
+        l1 += __shfl_xor(l1, o);
+    }
+    if (lane == 0) {
+        logits[(size_t)b * 2] = l0 + fc_b[0];
+        logits[(size_t)b * 2 + 1] = l1 + fc_b[1];
+    }
+}
+
+int finish_bn(const float *partials, int rows, double count, const ww_bn_t *bn, float *ss_out, float *mr_out,
+              hipStream_t st) {
+    if (bn->training) return ww_launch_bn_fwd_finalize(partials, rows, count, bn, ss_out, mr_out, st);
+    return ww_launch_bn_eval_ss(bn, ss_out, mr_out, st);
+}
+
+int check_bn(const char *who, const ww_bn_t *bn, const float *ss_out, const float *mr_out, const void *scratch) {
+    WW_REQUIRE(bn && bn->gamma && bn->beta && ss_out && mr_out, WW_E_INVALID, "%s: null BatchNorm argument", who);
+    WW_REQUIRE(bn->training ? scratch != nullptr : (bn->running_mean && bn->running_var), WW_E_INVALID,
+               "%s: training needs scratch, eval needs running statistics", who);
+    return WW_OK;
+}
+
+}  // namespace
+
+extern "C" int ww_conv_stem_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int Hin, int Win, float *y,
+                                const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch, ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && w && y, WW_E_INVALID, "ww_conv_stem_fwd: null argument");
+    WW_REQUIRE(B >= 1 && Hin >= 1 && Win >= 1, WW_E_INVALID, "ww_conv_stem_fwd: bad shape (%d,%d,%d)", B, Hin, Win);
+    int rc = check_bn("ww_conv_stem_fwd", bn, ss_out, mr_out, scratch);
+    if (rc) return rc;
+    const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
+    const long nrows = (long)B * Ho;
+    const int grid = ww_occupancy_grid((const void *)k_stem_fwd, 256, 0, nrows, WW_MAX_PARTIALS);
+    hipStream_t st = (hipStream_t)stream;
+    float *partials = bn->training ? (float *)scratch : nullptr;
+    hipLaunchKernelGGL(k_stem_fwd, dim3(grid), dim3(256), 0, st, x, w, B, Hin, Win, Ho, Wo, y, partials);
+    WW_LAUNCH_CHECK();
+    return finish_bn(partials, grid, (double)B * Ho * Wo, bn, ss_out, mr_out, st);
+}
+
+extern "C" int ww_dwconv3x3_fwd(ww_ctx *ctx, const float *y_in, const float *ss_in, const float *w, int B, int H,
+                                int W, float *y, const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch,
+                                ww_stream_t stream) {
+    WW_REQUIRE(ctx && y_in && ss_in && w && y, WW_E_INVALID, "ww_dwconv3x3_fwd: null argument");
+    WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_dwconv3x3_fwd: bad shape (%d,%d,%d)", B, H, W);
+    int rc = check_bn("ww_dwconv3x3_fwd", bn, ss_out, mr_out, scratch);
+    if (rc) return rc;
+    DwGeom g;
+    g.B = B; g.H = H; g.W = W;
+    g.ncs = (W + 3) / 4;
+    g.nseg = H >= 16 ? 2 : 1;
+    g.hs_len = (H + g.nseg - 1) / g.nseg;
+    g.items = (long)B * g.nseg * g.ncs;
+    const long nblk = (g.items + 7) / 8;
+    const int grid = ww_occupancy_grid((const void *)k_dw_fwd, 256, 0, nblk, WW_MAX_PARTIALS);
+    hipStream_t st = (hipStream_t)stream;
+    float *partials = bn->training ? (float *)scratch : nullptr;
+    hipLaunchKernelGGL(k_dw_fwd, dim3(grid), dim3(256), 0, st, y_in, ss_in, w, g, y, partials);
+    WW_LAUNCH_CHECK();
+    return finish_bn(partials, grid, (double)B * H * W, bn, ss_out, mr_out, st);
+}
+
+extern "C" int ww_pwconv1x1_fwd(ww_ctx *ctx, const float *y_in, const float *ss_in, const float *w, int B, int H,
+                                int W, float *y, const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch,
+                                ww_stream_t stream) {
+    WW_REQUIRE(ctx && y_in && ss_in && w && y, WW_E_INVALID, "ww_pwconv1x1_fwd: null argument");
+    WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_pwconv1x1_fwd: bad shape (%d,%d,%d)", B, H, W);
+    int rc = check_bn("ww_pwconv1x1_fwd", bn, ss_out, mr_out, scratch);
+    if (rc) return rc;
+    const long M = (long)B * H * W;
+    const long ntiles = (M + PW_TILE - 1) / PW_TILE;
+    const int grid = ww_occupancy_grid((const void *)k_pw_fwd, 256, 0, ntiles, WW_MAX_PARTIALS);
+    hipStream_t st = (hipStream_t)stream;
+    float *partials = bn->training ? (float *)scratch : nullptr;
+    hipLaunchKernelGGL(k_pw_fwd, dim3(grid), dim3(256), 0, st, y_in, ss_in, w, M, y, partials);
+    WW_LAUNCH_CHECK();
+    return finish_bn(partials, grid, (double)M, bn, ss_out, mr_out, st);
+}
+
+extern "C" int ww_gap_fwd(ww_ctx *ctx, const float *y, const float *ss, const float *mr, int B, int H, int W,
+                          float *pool, ww_stream_t stream) {
+    WW_REQUIRE(ctx && y && ss && mr && pool, WW_E_INVALID, "ww_gap_fwd: null argument");
+    WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_gap_fwd: bad shape (%d,%d,%d)", B, H, W);
+    hipLaunchKernelGGL(k_gap_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, y, ss, mr, H * W, pool);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+
+extern "C" int ww_head_fwd(ww_ctx *ctx, const float *pool, int B, int HW, const float *fc_w, const float *fc_b,
+                           float dropout_p, int training, uint64_t seed, uint64_t step, uint64_t sample_offset,
+                           float *pd, float *logits, ww_stream_t stream) {
+    WW_REQUIRE(ctx && pool && fc_w && fc_b && pd && logits, WW_E_INVALID, "ww_head_fwd: null argument");
+    WW_REQUIRE(B >= 1 && HW >= 1, WW_E_INVALID, "ww_head_fwd: bad shape (%d,%d)", B, HW);
+    WW_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, WW_E_INVALID, "ww_head_fwd: dropout_p=%f not in [0,1)", dropout_p);
+    const int use_dropout = training && dropout_p > 0.f;
+    const float scale = (float)(1.0 / (1.0 - (double)dropout_p));
+    hipLaunchKernelGGL(k_head_fwd, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, pool, B, HW, fc_w, fc_b,
+                       scale, ww_prob_threshold((double)dropout_p), use_dropout, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       (uint32_t)step, (uint32_t)(step >> 32), sample_offset, pd, logits);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}

@@ -1,0 +1,369 @@
+// Context, error channel, constant tables and the small reduction / finalize kernels.
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "ww_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void ww_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *ww_last_error(void) { return g_err; }
+extern "C" int ww_abi_version(void) { return WW_ABI_VERSION; }
+
+extern "C" uint64_t ww_prob_threshold(double p) {
+    double t = floor(p * 4294967296.0);
+    if (!(t > 0.0)) return 0;  // also catches NaN
+    if (t > 4294967296.0) t = 4294967296.0;
+    return (uint64_t)t;
+}
+
+extern "C" void ww_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    ww_philox(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+extern "C" int ww_feat_num_frames(int n_samples, int hop) {
+    if (hop <= 0 || n_samples < 0) return WW_E_INVALID;
+    return 1 + n_samples / hop;
+}
+
+extern "C" int ww_ctx_create(int device, ww_ctx **out) {
+    WW_REQUIRE(out != nullptr, WW_E_INVALID, "ww_ctx_create: out is null");
+    int ndev = 0;
+    WW_HIP(hipGetDeviceCount(&ndev));
+    WW_REQUIRE(device >= 0 && device < ndev, WW_E_INVALID, "ww_ctx_create: device %d not in [0,%d)", device, ndev);
+    hipDeviceProp_t prop;
+    WW_HIP(hipGetDeviceProperties(&prop, device));
+    WW_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, WW_E_UNSUPPORTED,
+               "ww_ctx_create: libwwhip is built for gfx950 only, device %d is %s", device, prop.gcnArchName);
+    ww_ctx *c = new ww_ctx();
+    c->device = device;
+    c->tables = nullptr;
+    *out = c;
+    return WW_OK;
+}
+
+static void free_tables(ww_feat_tables *t) {
+    while (t) {
+        ww_feat_tables *n = t->next;
+        (void)hipFree(t->window);
+        (void)hipFree(t->twiddle);
+        (void)hipFree(t->mel_start);
+        (void)hipFree(t->mel_len);
+        (void)hipFree(t->mel_off);
+        (void)hipFree(t->mel_w);
+        if (t->dct) (void)hipFree(t->dct);
+        delete t;
+        t = n;
+    }
+}
+
+extern "C" int ww_ctx_destroy(ww_ctx *ctx) {
+    if (!ctx) return WW_OK;
+    free_tables(ctx->tables);
+    delete ctx;
+    return WW_OK;
+}
+
+static double hz_to_mel(double f) { return 2595.0 * log10(1.0 + f / 700.0); }
+static double mel_to_hz(double m) { return 700.0 * (pow(10.0, m / 2595.0) - 1.0); }
+
+template <typename T>
+static int upload(T **dptr, const std::vector<T> &h) {
+    size_t bytes = (h.empty() ? 1 : h.size()) * sizeof(T);
+    WW_HIP(hipMalloc((void **)dptr, bytes));
+    if (!h.empty()) WW_HIP(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return WW_OK;
+}
+
+// Tables follow DESIGN.md "Feature spec" / oracle/features.py exactly (double on the host).
+int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out) {
+    for (ww_feat_tables *t = ctx->tables; t; t = t->next) {
+        if (memcmp(&t->cfg, cfg, sizeof(ww_feat_cfg)) == 0) {
+            *out = t;
+            return WW_OK;
+        }
+    }
+    const int n_fft = cfg->n_fft, n_bins = n_fft / 2 + 1, M = cfg->n_mels;
+    const double sr = cfg->sample_rate;
+    const double f_min = cfg->f_min, f_max = cfg->f_max > 0.f ? cfg->f_max : sr / 2.0;
+    std::vector<float> win(n_fft);
+    std::vector<float2> tw(n_fft);
+    for (int i = 0; i < n_fft; ++i) {
+        win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / n_fft));
+        tw[i] = make_float2((float)cos(2.0 * M_PI * i / n_fft), (float)(-sin(2.0 * M_PI * i / n_fft)));
+    }
+    std::vector<double> f_pts(M + 2);
+    const double m_lo = hz_to_mel(f_min), m_hi = hz_to_mel(f_max);
+    for (int i = 0; i < M + 2; ++i) {
+        double m = (i == M + 1) ? m_hi : m_lo + i * ((m_hi - m_lo) / (M + 1));
+        f_pts[i] = mel_to_hz(m);
+    }
+    std::vector<int32_t> start(M), len(M), off(M);
+    std::vector<float> w;
+    int max_len = 0;
+    for (int m = 0; m < M; ++m) {
+        int s = -1, e = -1;
+        std::vector<float> band;
+        for (int k = 0; k < n_bins; ++k) {
+            double f = (k == n_bins - 1) ? sr / 2.0 : k * ((sr / 2.0) / (n_bins - 1));
+            double down = -(f_pts[m] - f) / (f_pts[m + 1] - f_pts[m]);
+            double up = (f_pts[m + 2] - f) / (f_pts[m + 2] - f_pts[m + 1]);
+            double v = fmax(0.0, fmin(down, up));
+            if (v > 0.0) {
+                if (s < 0) s = k;
+                e = k;
+            }
+        }
+        if (s < 0) { s = 0; e = -1; }
+        start[m] = s;
+        len[m] = e - s + 1;
+        off[m] = (int32_t)w.size();
+        for (int k = s; k <= e; ++k) {
+            double f = (k == n_bins - 1) ? sr / 2.0 : k * ((sr / 2.0) / (n_bins - 1));
+            double down = -(f_pts[m] - f) / (f_pts[m + 1] - f_pts[m]);
+            double up = (f_pts[m + 2] - f) / (f_pts[m + 2] - f_pts[m + 1]);
+            w.push_back((float)fmax(0.0, fmin(down, up)));
+        }
+        if (len[m] > max_len) max_len = len[m];
+    }
+    std::vector<float> dct;
+    if (cfg->n_mfcc > 0) {
+        dct.resize((size_t)cfg->n_mfcc * M);
+        for (int c = 0; c < cfg->n_mfcc; ++c)
+            for (int m = 0; m < M; ++m) {
+                double v = cos(M_PI / M * (m + 0.5) * c) * sqrt(2.0 / M);
+                if (c == 0) v *= 1.0 / sqrt(2.0);
+                dct[(size_t)c * M + m] = (float)v;
+            }
+    }
+    ww_feat_tables *t = new ww_feat_tables();
+    memset(t, 0, sizeof(*t));
+    t->cfg = *cfg;
+    t->max_len = max_len;
+    int rc;
+    if ((rc = upload(&t->window, win)) || (rc = upload(&t->twiddle, tw)) || (rc = upload(&t->mel_start, start)) ||
+        (rc = upload(&t->mel_len, len)) || (rc = upload(&t->mel_off, off)) || (rc = upload(&t->mel_w, w))) {
+        free_tables(t);
+        return rc;
+    }
+    if (cfg->n_mfcc > 0 && (rc = upload(&t->dct, dct))) {
+        free_tables(t);
+        return rc;
+    }
+    t->next = ctx->tables;
+    ctx->tables = t;
+    *out = t;
+    return WW_OK;
+}
+
+extern "C" size_t ww_layer_scratch_bytes(void) {
+    return (size_t)(WW_STAT_SLAB_FLOATS + WW_DW_SLAB_FLOATS) * sizeof(float);
+}
+
+// ------------------------------------------------------------------------------------------
+// Finalize kernels.  Slab rows are block partials written by the conv kernels; columns are
+// summed in double in a fixed order => bit-reproducible run to run.
+// ------------------------------------------------------------------------------------------
+
+// column sums of partials[rows][128] by one 1024-thread block: thread = (col, part of 8)
+__device__ inline double ww_col128_sum(const float *__restrict__ partials, int rows, double *sh) {
+    const int col = threadIdx.x & 127, part = threadIdx.x >> 7;
+    double acc = 0.0;
+    for (int r = part; r < rows; r += 8) acc += (double)partials[(size_t)r * 128 + col];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < 128) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) tot += sh[p * 128 + col];
+    }
+    return tot;  // valid for threadIdx.x < 128
+}
+
+// BatchNorm2d training forward statistics (torch semantics: biased var for normalisation,
+// unbiased for running_var, running = (1-m)*running + m*batch)
+__global__ __launch_bounds__(1024) void k_bn_fwd_finalize(const float *__restrict__ partials, int rows,
+                                                          double count, ww_bn_t bn, float *__restrict__ ss,
+                                                          float *__restrict__ mr) {
+    __shared__ double sh[1024];
+    __shared__ double tot[128];
+    double t = ww_col128_sum(partials, rows, sh);
+    if (threadIdx.x < 128) tot[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        const double mean = tot[c] / count;
+        double var = tot[64 + c] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)bn.eps);
+        const double scale = (double)bn.gamma[c] * rstd;
+        ss[c] = (float)scale;
+        ss[64 + c] = (float)((double)bn.beta[c] - mean * scale);
+        mr[c] = (float)mean;
+        mr[64 + c] = (float)rstd;
+        if (bn.running_mean) {
+            const double m = bn.momentum;
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            bn.running_mean[c] = (float)((1.0 - m) * (double)bn.running_mean[c] + m * mean);
+            bn.running_var[c] = (float)((1.0 - m) * (double)bn.running_var[c] + m * unb);
+        }
+    }
+}
+
+__global__ void k_bn_eval_ss(ww_bn_t bn, float *__restrict__ ss, float *__restrict__ mr) {
+    const int c = threadIdx.x;
+    if (c < 64) {
+        const double rstd = 1.0 / sqrt((double)bn.running_var[c] + (double)bn.eps);
+        const double scale = (double)bn.gamma[c] * rstd;
+        ss[c] = (float)scale;
+        ss[64 + c] = (float)((double)bn.beta[c] - (double)bn.running_mean[c] * scale);
+        mr[c] = bn.running_mean[c];
+        mr[64 + c] = (float)rstd;
+    }
+}
+
+// BatchNorm2d backward reduction: partial columns = [sum dz (64) | sum dz*yhat (64)].
+//   dgamma = sum dz*yhat, dbeta = sum dz,
+//   dy = gamma*rstd*(dz - mean(dz) - yhat*mean(dz*yhat))  ==  A*dz + Bc*y + Cc
+__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restrict__ partials, int rows,
+                                                          double count, const float *__restrict__ gamma,
+                                                          const float *__restrict__ mr, float *__restrict__ coef,
+                                                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ double sh[1024];
+    __shared__ double tot[128];
+    double t = ww_col128_sum(partials, rows, sh);
+    if (threadIdx.x < 128) tot[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        const double s1 = tot[c], s2 = tot[64 + c];
+        const double mean = mr[c], rstd = mr[64 + c], g = gamma[c];
+        const double c1 = s1 / count, c2 = s2 / count;
+        const double A = g * rstd;
+        coef[c] = (float)A;
+        coef[64 + c] = (float)(-A * rstd * c2);
+        coef[128 + c] = (float)(A * (mean * rstd * c2 - c1));
+        dgamma[c] = (float)s2;
+        dbeta[c] = (float)s1;
+    }
+}
+
+// generic column sum: out[col] = sum_r partials[r][col]; block = 64 cols x 4 row parts
+__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partials, int rows, int cols,
+                                                float *__restrict__ out) {
+    __shared__ double sh[256];
+    const int lc = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lc;
+    double acc = 0.0;
+    if (col < cols)
+        for (int r = part; r < rows; r += 4) acc += (double)partials[(size_t)r * cols + col];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (part == 0 && col < cols) out[col] = (float)(sh[lc] + sh[64 + lc] + sh[128 + lc] + sh[192 + lc]);
+}
+
+int ww_launch_bn_fwd_finalize(const float *partials, int rows, double count, const ww_bn_t *bn, float *ss_out,
+                              float *mr_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3(1), dim3(1024), 0, st, partials, rows, count, *bn, ss_out, mr_out);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+int ww_launch_bn_eval_ss(const ww_bn_t *bn, float *ss_out, float *mr_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_eval_ss, dim3(1), dim3(64), 0, st, *bn, ss_out, mr_out);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+int ww_launch_bn_bwd_finalize(const float *partials, int rows, double count, const float *gamma,
+                              const float *mr, float *coef_out, float *dgamma, float *dbeta, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(1024), 0, st, partials, rows, count, gamma, mr, coef_out,
+                       dgamma, dbeta);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+int ww_launch_colsum(const float *partials, int rows, int cols, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_colsum, dim3((cols + 63) / 64), dim3(256), 0, st, partials, rows, cols, out);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// clip_grad_norm_ on one flat bucket (single block: n is ~2e4 for cnn_small, ~1.5e6 for
+// MobileNetV3-small; deterministic fixed-order reduction)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_grad_norm_clip(float *__restrict__ g, size_t n, float max_norm,
+                                                         float *__restrict__ norm_out) {
+    __shared__ double sh[1024];
+    __shared__ float coef_sh;
+    double acc = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        const double v = g[i];
+        acc += v * v;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(sh[0]);
+        if (norm_out) *norm_out = norm;
+        float c = 1.0f;
+        if (max_norm > 0.f) {
+            c = max_norm / (norm + 1e-6f);   // torch: clamp(max_norm/(total_norm+1e-6), max=1)
+            if (c > 1.0f) c = 1.0f;          // NaN compares false -> NaN propagates like torch
+        }
+        coef_sh = c;
+    }
+    __syncthreads();
+    const float c = coef_sh;
+    if (max_norm > 0.f)
+        for (size_t i = threadIdx.x; i < n; i += 1024) g[i] *= c;
+}
+
+extern "C" int ww_grad_norm_clip(ww_ctx *ctx, float *flat_grads, size_t n, float max_norm, float *norm_out,
+                                 ww_stream_t stream) {
+    WW_REQUIRE(ctx && flat_grads, WW_E_INVALID, "ww_grad_norm_clip: null argument");
+    if (n == 0) return WW_OK;
+    hipLaunchKernelGGL(k_grad_norm_clip, dim3(1), dim3(1024), 0, (hipStream_t)stream, flat_grads, n, max_norm,
+                       norm_out);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+
+// Grid for a persistent (grid-stride) kernel: one full residency wave of blocks, capped by the
+// amount of work and by the reduction slab.  Speed only -- no kernel relies on co-residency.
+int ww_occupancy_grid(const void *fn, int block, size_t smem, long want, int cap) {
+    static int n_cu = 0;
+    struct Entry { const void *fn; size_t smem; int per_cu; };
+    static Entry cache[32];
+    static int n_cache = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+        else
+            n_cu = 256;
+    }
+    int per_cu = 0;
+    for (int i = 0; i < n_cache; ++i)
+        if (cache[i].fn == fn && cache[i].smem == smem) per_cu = cache[i].per_cu;
+    if (!per_cu) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (n_cache < 32) cache[n_cache++] = Entry{fn, smem, per_cu};
+    }
+    long gsz = (long)per_cu * n_cu;
+    if (gsz > cap) gsz = cap;
+    if (gsz > want) gsz = want;
+    return (int)(gsz < 1 ? 1 : gsz);
+}

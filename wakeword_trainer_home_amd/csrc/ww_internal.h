@@ -1,0 +1,124 @@
+// Internal declarations shared by the libwwhip translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "wwhip.h"
+
+#define WW_NFFT 1024
+#define WW_NBINS 513
+#define WW_MAX_MELS 128
+#define WW_MAX_MASKS 16
+#define WW_FRAMES_PER_BLOCK 16
+#define WW_MAX_HOP 512
+
+void ww_set_error(const char *fmt, ...);
+
+#define WW_REQUIRE(cond, code, ...)          \
+    do {                                     \
+        if (!(cond)) {                       \
+            ww_set_error(__VA_ARGS__);       \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+#define WW_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            ww_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                       \
+            return WW_E_HIP;                                                              \
+        }                                                                                 \
+    } while (0)
+
+#define WW_LAUNCH_CHECK()                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) {                                                             \
+            ww_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, \
+                         __LINE__);                                                         \
+            return WW_E_HIP;                                                                \
+        }                                                                                   \
+    } while (0)
+
+// Device-resident feature tables for one (sample_rate, n_fft, n_mels, n_mfcc, f_min, f_max).
+struct ww_feat_tables {
+    ww_feat_cfg cfg;       // key
+    float *window;         // (1024) periodic Hann
+    float2 *twiddle;       // (1024) exp(-2 pi i j / 1024)
+    int32_t *mel_start;    // (n_mels) first bin with non-zero weight
+    int32_t *mel_len;      // (n_mels) band length
+    int32_t *mel_off;      // (n_mels) offset of the band's weights in mel_w
+    float *mel_w;          // compact band weights
+    float *dct;            // (n_mfcc, n_mels) or null
+    int32_t max_len;
+    ww_feat_tables *next;
+};
+
+struct ww_ctx {
+    int device;
+    ww_feat_tables *tables;
+};
+
+int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out);
+
+// ---- reduction slabs (scratch layout of one layer call)
+//   [0, 1024*128)            BN-statistics partials  (rows x [sum(64) | sumsq(64)])
+//   [1024*128, +256*4096)    weight-gradient partials (rows x up to 4096 cols)
+#define WW_STAT_SLAB_FLOATS (WW_MAX_PARTIALS * 128)
+#define WW_DW_SLAB_ROWS 512
+#define WW_DW_SLAB_FLOATS (WW_DW_SLAB_ROWS * 4096)
+
+// finalize launchers (ww_reduce.hip)
+int ww_launch_bn_fwd_finalize(const float *partials, int rows, double count, const ww_bn_t *bn, float *ss_out,
+                              float *mr_out, hipStream_t st);
+int ww_launch_bn_eval_ss(const ww_bn_t *bn, float *ss_out, float *mr_out, hipStream_t st);
+int ww_launch_bn_bwd_finalize(const float *partials, int rows, double count, const float *gamma,
+                              const float *mr, float *coef_out, float *dgamma, float *dbeta, hipStream_t st);
+int ww_launch_colsum(const float *partials, int rows, int cols, float *out, hipStream_t st);
+
+int ww_occupancy_grid(const void *fn, int block, size_t smem, long want, int cap);
+
+// ---- Philox4x32-10 (host + device), must match oracle/philox.py bit for bit
+#define WW_TAG_SPECAUG 0u
+#define WW_TAG_DROPOUT 1u
+
+__host__ __device__ inline void ww_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                          uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct ww_mask_params {  // resolved SpecAugment parameters passed by value to kernels
+    int32_t n_f, n_t, f_param, t_param;
+    uint64_t f_thresh, t_thresh;
+    uint32_t seed_lo, seed_hi, step_lo, step_hi;
+    uint64_t sample_offset;
+};
+
+// (start,width) of mask k for sample b; width==0 when the mask is not applied.
+__device__ inline void ww_specaug_mask(const ww_mask_params &mp, uint32_t sample, int k, int F, int T, int &s,
+                                       int &w) {
+    uint32_t r[4];
+    ww_philox(mp.step_lo, mp.step_hi, sample, (WW_TAG_SPECAUG << 24) | (uint32_t)k, mp.seed_lo, mp.seed_hi, r);
+    const bool is_f = k < mp.n_f;
+    const uint32_t dim = is_f ? (uint32_t)F : (uint32_t)T;
+    const uint32_t param = is_f ? (uint32_t)mp.f_param : (uint32_t)mp.t_param;
+    const uint32_t pmax = param < dim ? param : dim;
+    const uint32_t ww = r[0] % (pmax + 1u);
+    const uint32_t ss = r[1] % (dim - ww + 1u);
+    const uint64_t thr = is_f ? mp.f_thresh : mp.t_thresh;
+    s = (int)ss;
+    w = ((uint64_t)r[2] < thr) ? (int)ww : 0;
+}
