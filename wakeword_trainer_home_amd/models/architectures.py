@@ -1,0 +1,221 @@
+"""Model factory of the hot path: ``create_model`` keeps the reference signature
+(``src/models/architectures.py:437-509``) and adds ``cnn_small`` whose
+forward/backward run entirely in libwwhip (hand-written HIP, gfx950).
+
+The module holds ordinary ``nn.Parameter``s / buffers under the same names as the plain
+``torch.nn`` formulation (``oracle/cnn_small.py``), so ``state_dict()``, ``load_state_dict()``,
+``.to()``, ``.parameters()``, optimizers and checkpoints behave as for any reference model
+(needed by ``src/training/trainer.py:69-71,489,551``).  There is no PyTorch fallback: off an
+MI355X, or without the built library, ``forward`` raises.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import _native as nat
+
+_SUPPORTED = "cnn_small"
+_REFERENCE_ONLY = ("resnet18", "mobilenetv3", "lstm", "gru", "tcn")
+
+
+class _DSBlock(nn.Module):
+    """Parameter container of one depthwise-separable block (never called)."""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.dw = nn.Conv2d(ch, ch, 3, padding=1, groups=ch, bias=False)
+        self.dw_bn = nn.BatchNorm2d(ch)
+        self.pw = nn.Conv2d(ch, ch, 1, bias=False)
+        self.pw_bn = nn.BatchNorm2d(ch)
+
+
+class _CNNSmallFn(torch.autograd.Function):
+    """logits = cnn_small(x).  Parameter gradients are written by the HIP backward straight into the
+    module's flat gradient bucket (``p.grad`` are views of it), so nothing is returned for them."""
+
+    @staticmethod
+    def forward(ctx, x, mod, *params):
+        logits, ws, step = mod._launch_forward(x, training=True)
+        ctx.mod, ctx.ws, ctx.step = mod, ws, step
+        ctx.save_for_backward(x)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        (x,) = ctx.saved_tensors
+        ctx.mod._launch_backward(x, dlogits, ctx.ws, ctx.step)
+        return (None, None) + (None,) * len(ctx.mod._plist)
+
+
+class CNNSmallWakeword(nn.Module):
+    """stem Conv2d(1,64,3,s2,p1)+BN+ReLU -> 4 x [DW3x3+BN+ReLU, PW1x1+BN+ReLU] -> GAP -> dropout -> Linear(64,2).
+
+    ``forward(x)``: x (B,1,F,T) float32 on an MI355X -> (B,2) logits.
+    """
+
+    CH = 64
+    N_BLOCKS = 4
+
+    def __init__(self, num_classes: int = 2, pretrained: bool = False, dropout: float = 0.3,
+                 input_channels: int = 1, dropout_seed: int = 0):
+        super().__init__()
+        if num_classes != 2:
+            raise ValueError(f"cnn_small: the HIP classifier/loss kernels implement num_classes == 2, got {num_classes}")
+        if input_channels != 1:
+            raise ValueError(f"cnn_small: input_channels must be 1 (mono spectrogram), got {input_channels}")
+        if pretrained:
+            raise ValueError("cnn_small has no pretrained weights (pass pretrained=False)")
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError(f"dropout must be in [0, 1), got {dropout}")
+        self.stem = nn.Sequential(OrderedDict(conv=nn.Conv2d(1, self.CH, 3, stride=2, padding=1, bias=False),
+                                              bn=nn.BatchNorm2d(self.CH)))
+        self.blocks = nn.ModuleList([_DSBlock(self.CH) for _ in range(self.N_BLOCKS)])
+        self.classifier = nn.Linear(self.CH, num_classes)
+        self.p = float(dropout)
+        self.dropout_seed = int(dropout_seed)
+        self.dropout_step = 0        # advanced once per training-mode forward (counter of the Philox stream)
+        self.sample_offset = 0       # first global sample index of this rank's shard (data parallel)
+        self._pending_tracked = 0
+        self._reset_caches()
+        self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_tracked())
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _bns(self):
+        return [self.stem.bn] + [b for blk in self.blocks for b in (blk.dw_bn, blk.pw_bn)]
+
+    def _ordered(self):
+        """Tensors in the C-ABI order of ww_cnn_small_fwd (include/wwhip.h)."""
+        out = [self.stem.conv.weight, self.stem.bn.weight, self.stem.bn.bias, self.stem.bn.running_mean,
+               self.stem.bn.running_var]
+        for blk in self.blocks:
+            out += [blk.dw.weight, blk.dw_bn.weight, blk.dw_bn.bias, blk.dw_bn.running_mean, blk.dw_bn.running_var,
+                    blk.pw.weight, blk.pw_bn.weight, blk.pw_bn.bias, blk.pw_bn.running_mean, blk.pw_bn.running_var]
+        return out + [self.classifier.weight, self.classifier.bias]
+
+    def _reset_caches(self):
+        self._plist = None
+        self._pkey = None
+        self._pptr = None
+        self._gptr = None
+        self._flat_grad = None
+        self._grad_views = None
+        self._ws = {}
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._reset_caches()
+        return r
+
+    def _flush_tracked(self):
+        if self._pending_tracked:
+            for bn in self._bns():
+                bn.num_batches_tracked += self._pending_tracked
+            self._pending_tracked = 0
+
+    def _prepare(self, dev):
+        tensors = self._ordered()
+        key = tuple(t.data_ptr() for t in tensors)
+        if self._pptr is not None and self._pkey == key:
+            return
+        for t in tensors:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
+                raise nat.NativeError("cnn_small parameters must be contiguous float32 on the input's device")
+        self._pkey = key
+        self._pptr = nat.ptr_array(tensors)
+        self._plist = [t for t in tensors if isinstance(t, nn.Parameter)]
+        sizes = [(t.numel() + 3) // 4 * 4 for t in self._plist]
+        self._flat_grad = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        views, off = {}, 0
+        for t, n in zip(self._plist, sizes):
+            views[id(t)] = self._flat_grad[off:off + t.numel()].view_as(t)
+            off += n
+        self._grad_views = views
+        self._gptr = nat.ptr_array([views.get(id(t)) for t in tensors])
+
+    @property
+    def flat_grad(self):
+        """The one flat fp32 gradient bucket (all-reduce / clip operate on it)."""
+        return self._flat_grad
+
+    def _workspace(self, B, F, T, dev, hold):
+        key = (B, F, T)
+        slot = self._ws.get(key)
+        if slot is None or slot["busy"]:
+            n = nat.cnn_small_workspace_bytes(B, F, T)
+            slot = {"buf": torch.empty(n // 4, dtype=torch.float32, device=dev), "busy": False}
+            self._ws[key] = slot
+        slot["busy"] = hold
+        return slot
+
+    # ------------------------------------------------------------------ launches
+    def _check_input(self, x):
+        if x.dim() == 3:
+            x = x.unsqueeze(1)
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"cnn_small expects (B,1,F,T) features, got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise nat.NativeError("cnn_small runs on hand-written HIP kernels only: the input is on "
+                                  f"'{x.device}', need an MI355X ('cuda') device -- there is no CPU fallback")
+        if x.dtype != torch.float32:
+            raise ValueError(f"cnn_small expects float32 features, got {x.dtype}")
+        return x.contiguous()
+
+    def _launch_forward(self, x, training):
+        dev = x.device
+        self._prepare(dev)
+        B, _, F, T = x.shape
+        slot = self._workspace(B, F, T, dev, hold=training and torch.is_grad_enabled())
+        logits = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        bn0 = self.stem.bn
+        step = self.dropout_step
+        nat.cnn_small_fwd(self._pptr, x, slot["buf"], logits, training=training,
+                          bn_momentum=bn0.momentum if bn0.momentum is not None else 0.1, bn_eps=bn0.eps,
+                          dropout_p=self.p, seed=self.dropout_seed, step=step, sample_offset=self.sample_offset)
+        if training:
+            self.dropout_step += 1
+            self._pending_tracked += 1
+        return logits, slot, step
+
+    def _launch_backward(self, x, dlogits, slot, step):
+        fresh = all(p.grad is None for p in self._plist)
+        if fresh:
+            gptr = self._gptr
+        else:                                   # accumulate into existing .grad tensors
+            tmp = torch.zeros_like(self._flat_grad)
+            views, off, tens = {}, 0, self._ordered()
+            for t in self._plist:
+                views[id(t)] = tmp[off:off + t.numel()].view_as(t)
+                off += (t.numel() + 3) // 4 * 4
+            gptr = nat.ptr_array([views.get(id(t)) for t in tens])
+        nat.cnn_small_bwd(self._pptr, gptr, x, dlogits.contiguous(), slot["buf"], dropout_p=self.p,
+                          seed=self.dropout_seed, step=step, sample_offset=self.sample_offset)
+        slot["busy"] = False
+        for p in self._plist:
+            if fresh:
+                p.grad = self._grad_views[id(p)]
+            elif p.grad is None:
+                p.grad = views[id(p)].clone()
+            else:
+                p.grad.add_(views[id(p)])
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self._check_input(x)
+        if self.training and torch.is_grad_enabled():
+            self._prepare(x.device)
+            return _CNNSmallFn.apply(x, self, *self._plist)
+        logits, _, _ = self._launch_forward(x, training=self.training)
+        return logits
+
+
+def create_model(architecture: str, num_classes: int = 2, pretrained: bool = False, **kwargs) -> nn.Module:
+    """Factory (same signature and error behaviour as the reference's, case-insensitive name)."""
+    name = architecture.lower()
+    if name == "cnn_small":
+        return CNNSmallWakeword(num_classes=num_classes, pretrained=pretrained, dropout=kwargs.get("dropout", 0.3),
+                                input_channels=kwargs.get("input_channels", 1),
+                                dropout_seed=kwargs.get("dropout_seed", 0))
+    if name in _REFERENCE_ONLY:
+        raise ValueError(f"Architecture '{architecture}' exists in the reference but is outside this build's "
+                         f"HIP hot path (DESIGN.md 'Out of scope'). Supported: {_SUPPORTED}")
+    raise ValueError(f"Unknown architecture: {architecture}. Supported: {_SUPPORTED}")

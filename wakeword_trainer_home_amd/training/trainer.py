@@ -1,0 +1,482 @@
+"""Training loop with the reference ``Trainer`` API (``src/training/trainer.py:44-585``) and an
+MI355X-native inner step.
+
+Kept from the reference (pinned by tests/golden/g2_*.{npz,json} captured from the real class):
+constructor signature and attributes (:50-126), ``train()`` result dict and history keys (:328-337,
+:409-418), per-epoch order train -> validate -> scheduler(val_loss) -> history -> improvement ->
+checkpoint -> early stop -> ``on_epoch_end`` (:350-379), the "any of loss/F1/FPR improved" rule
+(:431-457), checkpoint schema, file names and atomic tmp+rename (:463-525), resume (:527-575),
+callback protocol ``on_epoch_start / on_batch_end(batch_idx, loss, acc) / on_epoch_end`` (:577-585),
+batch contract (2- or 3-tuples, empty tensors skipped, :150-162), error policy (OOM -> skip, other
+RuntimeError -> re-raise, other Exception -> log + skip, :214-226), non-finite loss -> batch skipped
+but still counted in the epoch-loss denominator (:177-179, :229).
+
+Replaced (the hot path, :165-203): when the model is HIP-backed the step is
+``frontend (optional) -> ww_cnn_small_fwd -> ww_ce2_loss_fwd_bwd -> ww_cnn_small_bwd ->
+[all-reduce of the flat gradient bucket] -> ww_grad_norm_clip -> optimizer.step`` with ONE 40-byte
+device->host read per step (loss, accuracy counters, finite flag, grad norm) instead of the
+reference's >= 6 synchronisations.  Extension: 2-D inputs ``(B, N)`` are raw waveforms and go
+through the fused log-mel + SpecAugment kernel first.  Any other ``nn.Module`` takes the
+reference's autograd step unchanged, so the class stays a drop-in.
+"""
+import logging
+import sys
+import time
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Any, Callable, Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch.utils.data import DataLoader
+
+from .. import _native as nat
+from ..config.cuda_utils import enforce_cuda
+from ..models.architectures import CNNSmallWakeword
+from ..models.losses import create_loss_function, _NativeLoss
+from .metrics import MetricMonitor, MetricResults, MetricsTracker
+from .optimizer_factory import (clip_gradients, create_grad_scaler, create_optimizer_and_scheduler,
+                                get_learning_rate)
+
+logger = logging.getLogger(__name__)
+
+try:
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+    tqdm = None
+
+
+@dataclass
+class TrainingState:
+    epoch: int = 0
+    global_step: int = 0
+    best_val_loss: float = float("inf")
+    best_val_f1: float = 0.0
+    best_val_fpr: float = 1.0
+    epochs_without_improvement: int = 0
+    training_time: float = 0.0
+
+
+_HISTORY_KEYS = ("train_loss", "train_acc", "val_loss", "val_acc", "val_f1", "val_fpr", "val_fnr", "learning_rates")
+_SAVE_EVERY = {"every_epoch": 1, "every_5_epochs": 5, "every_10_epochs": 10}
+
+
+class Trainer:
+    def __init__(self, model: nn.Module, train_loader: DataLoader, val_loader: DataLoader, config: Any,
+                 checkpoint_dir: Optional[Path] = None, device: str = "cuda", criterion: Optional[nn.Module] = None):
+        enforce_cuda()
+        self.device, self.config = device, config
+        self.model = model.to(device).to(memory_format=torch.channels_last)
+        self.native = isinstance(self.model, CNNSmallWakeword)
+        self.train_loader, self.val_loader = train_loader, val_loader
+
+        if criterion is None:
+            criterion = create_loss_function(loss_name=config.loss.loss_function, num_classes=config.model.num_classes,
+                                             label_smoothing=config.loss.label_smoothing,
+                                             focal_alpha=config.loss.focal_alpha, focal_gamma=config.loss.focal_gamma,
+                                             class_weights=None, device=device)
+        self.criterion = criterion.to(device)
+        self._native_loss = isinstance(self.criterion, _NativeLoss)
+        if self._native_loss:
+            self.criterion.validate_targets = False      # checked from the per-step stats read instead
+
+        self.optimizer, self.scheduler = create_optimizer_and_scheduler(self.model, config)
+        self.use_mixed_precision = config.optimizer.mixed_precision
+        if self.native and self.use_mixed_precision:
+            logger.warning("mixed_precision=True: the HIP path computes and stores in fp32 in this build "
+                           "(fp16 autocast/GradScaler apply to generic modules only)")
+        self.scaler = create_grad_scaler(enabled=self.use_mixed_precision and not self.native)
+        self.gradient_clip = config.optimizer.gradient_clip
+
+        self.train_metrics_tracker = MetricsTracker(device=device)
+        self.val_metrics_tracker = MetricsTracker(device=device)
+        self.metric_monitor = MetricMonitor(window_size=100)
+        self.state = TrainingState()
+        self.early_stopping_patience = config.training.early_stopping_patience
+        self.checkpoint_dir = Path(checkpoint_dir) if checkpoint_dir is not None else Path("checkpoints")
+        self.checkpoint_dir.mkdir(parents=True, exist_ok=True)
+        self.checkpoint_frequency = config.training.checkpoint_frequency
+        self.callbacks = []
+        self.show_progress = sys.stderr.isatty()
+
+        # data parallel: one process per GPU, gradients averaged over the flat bucket (RCCL via torch.distributed)
+        import torch.distributed as dist
+        self._dist = dist if (dist.is_available() and dist.is_initialized()
+                              and getattr(config.training, "data_parallel", True)) else None
+        self.world_size = self._dist.get_world_size() if self._dist else 1
+        self.rank = self._dist.get_rank() if self._dist else 0
+        if self._dist:
+            with torch.no_grad():
+                for t in list(self.model.parameters()) + list(self.model.buffers()):
+                    self._dist.broadcast(t, src=0)
+        self._stats_host = None
+        logger.info("Trainer initialized (device=%s, model=%s, native=%s, optimizer=%s, scheduler=%s, loss=%s, "
+                    "world=%d)", device, config.model.architecture, self.native, config.optimizer.optimizer,
+                    config.optimizer.scheduler, config.loss.loss_function, self.world_size)
+
+    # ------------------------------------------------------------------------------- helpers
+    def _bar(self, loader, desc):
+        if tqdm is None or not self.show_progress:
+            return loader
+        return tqdm(loader, desc=desc, leave=False)
+
+    @staticmethod
+    def _unpack(batch, idx, what):
+        if not isinstance(batch, (tuple, list)) or len(batch) < 2:
+            logger.error("Invalid batch structure at %s %d, skipping", what, idx)
+            return None
+        inputs, targets = batch[0], batch[1]
+        if inputs.numel() == 0 or targets.numel() == 0:
+            logger.warning("Empty tensor in %s %d, skipping", what, idx)
+            return None
+        return inputs, targets
+
+    def _features(self, inputs: torch.Tensor, training: bool) -> torch.Tensor:
+        """Native front end for raw waveform batches (B,N): fused log-mel/MFCC (+SpecAugment when training)."""
+        d, a = self.config.data, self.config.augmentation
+        mfcc = d.feature_type == "mfcc"
+        if d.feature_type not in ("mel", "mfcc", "mel_spectrogram"):
+            raise ValueError(f"Unknown feature_type: {d.feature_type}")
+        cfg = nat.make_feat_cfg(sample_rate=d.sample_rate, n_fft=d.n_fft, hop=d.hop_length, n_mels=d.n_mels,
+                                n_mfcc=d.n_mfcc if mfcc else 0)
+        sa = None
+        if training and (a.n_freq_masks + a.n_time_masks) > 0 and (a.freq_mask_prob > 0 or a.time_mask_prob > 0):
+            sa = nat.make_specaug_cfg(a.freq_mask_param, a.time_mask_param, a.n_freq_masks, a.n_time_masks,
+                                      a.freq_mask_prob, a.time_mask_prob)
+        wave = inputs.to(self.device, non_blocking=True)
+        if wave.dtype not in (torch.float32, torch.int16):
+            wave = wave.float()
+        return nat.logmel_fwd(wave.contiguous(), cfg, sa, seed=a.seed, step=self.state.global_step,
+                              sample_offset=self.rank * wave.shape[0])
+
+    def _read_stats(self, stats: torch.Tensor) -> dict:
+        """The step's single device->host transfer (40 bytes, pinned)."""
+        if self._stats_host is None:
+            self._stats_host = torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory()
+        self._stats_host.copy_(stats, non_blocking=True)
+        torch.cuda.current_stream(stats.device).synchronize()
+        return nat.decode_stats(self._stats_host)
+
+    def _allreduce_grads(self):
+        if not self._dist:
+            return
+        if self.native:
+            flat = self.model.flat_grad
+            self._dist.all_reduce(flat)
+            flat.div_(self.world_size)
+        else:
+            for p in self.model.parameters():
+                if p.grad is not None:
+                    self._dist.all_reduce(p.grad)
+                    p.grad.div_(self.world_size)
+
+    # ------------------------------------------------------------------------------- inner steps
+    def _step_native(self, inputs, targets, batch_idx) -> Optional[Tuple[float, float]]:
+        if inputs.dim() == 2:
+            inputs = self._features(inputs, training=True)
+        else:
+            inputs = inputs.to(self.device, non_blocking=True)
+        targets = targets.to(self.device, non_blocking=True)
+        self.model.sample_offset = self.rank * inputs.shape[0]
+        self.optimizer.zero_grad(set_to_none=True)
+        outputs = self.model(inputs)
+        loss = self.criterion(outputs, targets)
+        loss.backward()
+        self._allreduce_grads()
+        stats = self.criterion.last_stats
+        nat.grad_norm_clip_(self.model.flat_grad, max(float(self.gradient_clip), 0.0),
+                            norm_out=stats.view(torch.float32)[1:2])
+        s = self._read_stats(stats)
+        if s["bad_target"]:
+            raise ValueError("Target values must be in [0, 1]")
+        if s["nonfinite"] or (self._dist and s["grad_norm"] != s["grad_norm"]):
+            logger.error("Non-finite loss detected at batch %d: %s", batch_idx, s["loss"])
+            self.optimizer.zero_grad(set_to_none=True)
+            return None
+        self.optimizer.step()
+        self.train_metrics_tracker.update_counts(s["tp"], s["tn"], s["fp"], s["fn"])
+        self.last_grad_norm = s["grad_norm"]
+        return s["loss"], s["correct"] / max(s["count"], 1)
+
+    def _step_generic(self, inputs, targets, batch_idx) -> Optional[Tuple[float, float]]:
+        inputs = inputs.to(self.device, non_blocking=True, memory_format=torch.channels_last)
+        targets = targets.to(self.device, non_blocking=True)
+        self.optimizer.zero_grad(set_to_none=True)
+        dev_type = torch.device(self.device).type
+        with torch.autocast(dev_type, enabled=self.use_mixed_precision and dev_type == "cuda"):
+            outputs = self.model(inputs)
+            loss = self.criterion(outputs, targets)
+        if not torch.isfinite(loss):
+            logger.error("Non-finite loss detected at batch %d: %s", batch_idx, loss.item())
+            return None
+        self.scaler.scale(loss).backward()
+        self._allreduce_grads()
+        if self.gradient_clip > 0:
+            self.scaler.unscale_(self.optimizer)
+            self.last_grad_norm = clip_gradients(self.model, self.gradient_clip)
+        else:
+            self.last_grad_norm = 0.0
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        with torch.no_grad():
+            acc = (outputs.argmax(dim=1) == targets).float().mean().item()
+        self.train_metrics_tracker.update(outputs.detach(), targets.detach())
+        return loss.item(), acc
+
+    def _eval_batch(self, inputs, targets) -> Optional[float]:
+        if self.native and self._native_loss:
+            inputs = self._features(inputs, training=False) if inputs.dim() == 2 else inputs.to(self.device,
+                                                                                              non_blocking=True)
+            targets = targets.to(self.device, non_blocking=True)
+            self.model.sample_offset = self.rank * inputs.shape[0]
+            self.criterion(self.model(inputs), targets)
+            s = self._read_stats(self.criterion.last_stats)
+            if s["bad_target"]:
+                raise ValueError("Target values must be in [0, 1]")
+            if s["nonfinite"]:
+                return None
+            self.val_metrics_tracker.update_counts(s["tp"], s["tn"], s["fp"], s["fn"])
+            return s["loss"]
+        inputs = inputs.to(self.device, non_blocking=True, memory_format=torch.channels_last)
+        targets = targets.to(self.device, non_blocking=True)
+        dev_type = torch.device(self.device).type
+        with torch.autocast(dev_type, enabled=self.use_mixed_precision and dev_type == "cuda"):
+            outputs = self.model(inputs)
+            loss = self.criterion(outputs, targets)
+        if not torch.isfinite(loss):
+            return None
+        self.val_metrics_tracker.update(outputs.detach(), targets.detach())
+        return loss.item()
+
+    def _epoch_reduce(self, tracker: MetricsTracker, loss_sum: float, n_batches: int):
+        """Data parallel: every rank sees the epoch's global counters / mean loss."""
+        if not self._dist:
+            return loss_sum, n_batches
+        dev = self.device if torch.device(self.device).type == "cuda" else "cpu"
+        t = torch.tensor(tracker._c + [n_batches], dtype=torch.float64, device=dev)
+        ls = torch.tensor([loss_sum], dtype=torch.float64, device=dev)
+        self._dist.all_reduce(t)
+        self._dist.all_reduce(ls)
+        tracker._c = [int(v) for v in t[:4].tolist()]
+        tracker._seen = tracker._seen or sum(tracker._c) > 0
+        return float(ls.item()), int(t[4].item())
+
+    # ------------------------------------------------------------------------------- epochs
+    def train_epoch(self, epoch: int) -> Tuple[float, float]:
+        self.model.train()
+        self.train_metrics_tracker.reset()
+        num_batches = len(self.train_loader)
+        if num_batches == 0:
+            logger.warning("Training loader is empty, skipping epoch")
+            return 0.0, 0.0
+        epoch_loss = 0.0
+        step = self._step_native if (self.native and self._native_loss) else self._step_generic
+        bar = self._bar(self.train_loader, f"Epoch {epoch + 1}/{self.config.training.epochs} [Train]")
+        for batch_idx, batch in enumerate(bar):
+            try:
+                parsed = self._unpack(batch, batch_idx, "batch")
+                if parsed is None:
+                    continue
+                result = step(parsed[0], parsed[1], batch_idx)
+                if result is None:
+                    continue
+                loss_value, batch_acc = result
+                self.metric_monitor.update_batch(loss_value, batch_acc)
+                epoch_loss += loss_value
+                if bar is not self.train_loader:
+                    avg = self.metric_monitor.get_running_averages()
+                    bar.set_postfix({"loss": f"{avg['loss']:.4f}", "acc": f"{avg['accuracy']:.4f}",
+                                     "lr": f"{get_learning_rate(self.optimizer):.6f}"})
+                self.state.global_step += 1
+                self._call_callbacks("on_batch_end", batch_idx, loss_value, batch_acc)
+            except RuntimeError as e:
+                if "out of memory" in str(e).lower():
+                    logger.error("GPU OOM at batch %d. Clearing cache and skipping batch.", batch_idx)
+                    torch.cuda.empty_cache()
+                    continue
+                logger.exception("Runtime error at batch %d: %s", batch_idx, e)
+                raise
+            except Exception as e:
+                logger.exception("Unexpected error at batch %d: %s", batch_idx, e)
+                continue
+        epoch_loss, num_batches = self._epoch_reduce(self.train_metrics_tracker, epoch_loss, num_batches)
+        avg_loss = epoch_loss / max(num_batches, 1)
+        train_metrics = self.train_metrics_tracker.compute()
+        logger.info("Epoch %d [Train]: Loss=%.4f, %s", epoch + 1, avg_loss, train_metrics)
+        return avg_loss, train_metrics.accuracy
+
+    def validate_epoch(self, epoch: int) -> Tuple[float, MetricResults]:
+        self.model.eval()
+        self.val_metrics_tracker.reset()
+        num_batches = len(self.val_loader)
+        if num_batches == 0:
+            logger.warning("Validation loader is empty")
+            return 0.0, MetricResults.empty()
+        epoch_loss = 0.0
+        bar = self._bar(self.val_loader, f"Epoch {epoch + 1}/{self.config.training.epochs} [Val]")
+        with torch.no_grad():
+            for batch_idx, batch in enumerate(bar):
+                try:
+                    parsed = self._unpack(batch, batch_idx, "validation batch")
+                    if parsed is None:
+                        continue
+                    loss_value = self._eval_batch(parsed[0], parsed[1])
+                    if loss_value is None:
+                        logger.warning("Non-finite validation loss at batch %d", batch_idx)
+                        continue
+                    epoch_loss += loss_value
+                except RuntimeError as e:
+                    if "out of memory" in str(e).lower():
+                        logger.error("GPU OOM during validation at batch %d", batch_idx)
+                        torch.cuda.empty_cache()
+                        continue
+                    logger.exception("Runtime error during validation at batch %d: %s", batch_idx, e)
+                    raise
+                except Exception as e:
+                    logger.exception("Unexpected error during validation at batch %d: %s", batch_idx, e)
+                    continue
+        epoch_loss, num_batches = self._epoch_reduce(self.val_metrics_tracker, epoch_loss, num_batches)
+        avg_loss = epoch_loss / max(num_batches, 1)
+        val_metrics = self.val_metrics_tracker.compute()
+        logger.info("Epoch %d [Val]: Loss=%.4f, %s", epoch + 1, avg_loss, val_metrics)
+        return avg_loss, val_metrics
+
+    # ------------------------------------------------------------------------------- full loop
+    def train(self, start_epoch: int = 0, resume_from: Optional[Path] = None) -> Dict[str, Any]:
+        if resume_from is not None:
+            self.load_checkpoint(Path(resume_from))
+            start_epoch = self.state.epoch + 1
+            logger.info("Resumed from checkpoint at epoch %d", start_epoch)
+        history = {k: [] for k in _HISTORY_KEYS}
+        epochs = self.config.training.epochs
+        logger.info("Starting training: epochs=%d, train batches=%d, val batches=%d, batch size=%d", epochs,
+                    len(self.train_loader), len(self.val_loader), self.config.training.batch_size)
+        t0 = time.time()
+        try:
+            for epoch in range(start_epoch, epochs):
+                self.state.epoch = epoch
+                self._call_callbacks("on_epoch_start", epoch)
+                train_loss, train_acc = self.train_epoch(epoch)
+                val_loss, vm = self.validate_epoch(epoch)
+                self._update_scheduler(val_loss)
+                lr = get_learning_rate(self.optimizer)
+                for key, value in zip(_HISTORY_KEYS, (train_loss, train_acc, val_loss, vm.accuracy, vm.f1_score,
+                                                      vm.fpr, vm.fnr, lr)):
+                    history[key].append(value)
+                self.val_metrics_tracker.save_epoch_metrics(vm)
+                improved = self._check_improvement(val_loss, vm.f1_score, vm.fpr)
+                self._save_checkpoint(epoch, val_loss, vm, improved)
+                if self._should_stop_early():
+                    logger.info("Early stopping triggered after %d epochs", epoch + 1)
+                    break
+                self._call_callbacks("on_epoch_end", epoch, train_loss, val_loss, vm)
+                if self.rank == 0:
+                    print(f"\nEpoch {epoch + 1}/{epochs}\n  Train: Loss={train_loss:.4f}, Acc={train_acc:.4f}\n"
+                          f"  Val:   Loss={val_loss:.4f}, Acc={vm.accuracy:.4f}, F1={vm.f1_score:.4f}, "
+                          f"FPR={vm.fpr:.4f}, FNR={vm.fnr:.4f}\n  LR: {lr:.6f}"
+                          + ("\n  New best model (improvement detected)\n" if improved else ""))
+        except KeyboardInterrupt:
+            logger.info("Training interrupted by user")
+        self.state.training_time = time.time() - t0
+        best_f1_epoch, _ = self.val_metrics_tracker.get_best_epoch("f1_score")
+        best_fpr_epoch, _ = self.val_metrics_tracker.get_best_epoch("fpr")
+        logger.info("Training complete: %.2f h, best val loss %.4f, best F1 %.4f, best FPR %.4f",
+                    self.state.training_time / 3600, self.state.best_val_loss, self.state.best_val_f1,
+                    self.state.best_val_fpr)
+        return {"history": history, "final_epoch": self.state.epoch, "best_val_loss": self.state.best_val_loss,
+                "best_val_f1": self.state.best_val_f1, "best_val_fpr": self.state.best_val_fpr,
+                "training_time": self.state.training_time, "best_f1_epoch": best_f1_epoch,
+                "best_fpr_epoch": best_fpr_epoch}
+
+    def _update_scheduler(self, val_loss: float):
+        if self.scheduler is not None and hasattr(self.scheduler, "step"):
+            try:
+                self.scheduler.step(val_loss)      # positional, as the reference does (quirk Q2)
+            except TypeError:
+                self.scheduler.step()
+
+    def _check_improvement(self, val_loss: float, val_f1: float, val_fpr: float) -> bool:
+        s, improved = self.state, False
+        if val_loss < s.best_val_loss:
+            s.best_val_loss, improved = val_loss, True
+        if val_f1 > s.best_val_f1:
+            s.best_val_f1, improved = val_f1, True
+        if val_fpr < s.best_val_fpr:
+            s.best_val_fpr, improved = val_fpr, True
+        s.epochs_without_improvement = 0 if improved else s.epochs_without_improvement + 1
+        return improved
+
+    def _should_stop_early(self) -> bool:
+        return self.state.epochs_without_improvement >= self.early_stopping_patience
+
+    # ------------------------------------------------------------------------------- checkpoints
+    def _atomic_save(self, obj, path: Path, what: str):
+        tmp = path.with_suffix(".pt.tmp")
+        try:
+            torch.save(obj, tmp)
+            tmp.replace(path)
+            logger.info("Saved %s: %s", what, path)
+        except Exception as e:
+            logger.error("Failed to save %s: %s", what, e)
+            if tmp.exists():
+                tmp.unlink()
+
+    def _save_checkpoint(self, epoch: int, val_loss: float, val_metrics: MetricResults, is_best: bool):
+        every = _SAVE_EVERY.get(self.checkpoint_frequency)
+        periodic = (every is not None and (epoch + 1) % every == 0) or \
+                   (self.checkpoint_frequency == "best_only" and is_best)
+        if not (periodic or is_best) or self.rank != 0:
+            return
+        try:
+            ckpt = {"epoch": epoch, "model_state_dict": self.model.state_dict(),
+                    "optimizer_state_dict": self.optimizer.state_dict(),
+                    "scheduler_state_dict": self.scheduler.state_dict() if self.scheduler else None,
+                    "scaler_state_dict": self.scaler.state_dict(), "state": self.state, "config": self.config,
+                    "val_loss": val_loss, "val_metrics": val_metrics.to_dict()}
+        except Exception as e:
+            logger.error("Failed to create checkpoint dict: %s", e)
+            return
+        if periodic:
+            self._atomic_save(ckpt, self.checkpoint_dir / f"checkpoint_epoch_{epoch + 1:03d}.pt", "checkpoint")
+        if is_best:
+            self._atomic_save(ckpt, self.checkpoint_dir / "best_model.pt", "best model")
+
+    def load_checkpoint(self, checkpoint_path: Path):
+        checkpoint_path = Path(checkpoint_path)
+        if not checkpoint_path.exists():
+            raise FileNotFoundError(f"Checkpoint file not found: {checkpoint_path}")
+        if not checkpoint_path.is_file():
+            raise ValueError(f"Checkpoint path is not a file: {checkpoint_path}")
+        try:
+            # the dict pickles TrainingState / config instances, as the reference's does (:493-494)
+            ckpt = torch.load(checkpoint_path, map_location=self.device, weights_only=False)
+        except Exception as e:
+            raise RuntimeError(f"Corrupted or invalid checkpoint file: {checkpoint_path}") from e
+        missing = [k for k in ("model_state_dict", "optimizer_state_dict", "state") if k not in ckpt]
+        if missing:
+            raise ValueError(f"Checkpoint missing required keys: {missing}")
+        try:
+            self.model.load_state_dict(ckpt["model_state_dict"])
+        except Exception as e:
+            raise RuntimeError("Model state dict incompatible with current model") from e
+        for name, obj, key in (("optimizer", self.optimizer, "optimizer_state_dict"),
+                               ("scheduler", self.scheduler, "scheduler_state_dict"),
+                               ("scaler", self.scaler, "scaler_state_dict")):
+            if obj is None or not ckpt.get(key):
+                continue
+            try:
+                obj.load_state_dict(ckpt[key])
+            except Exception as e:
+                logger.warning("Failed to load %s state dict: %s. Continuing with fresh %s.", name, e, name)
+        self.state = ckpt["state"]
+        logger.info("Checkpoint loaded: Epoch %d", self.state.epoch + 1)
+
+    # ------------------------------------------------------------------------------- callbacks
+    def add_callback(self, callback: Callable):
+        self.callbacks.append(callback)
+
+    def _call_callbacks(self, event: str, *args, **kwargs):
+        for cb in self.callbacks:
+            fn = getattr(cb, event, None)
+            if fn is not None:
+                fn(*args, **kwargs)
