@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the wakeword training inner loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+One "step" = the whole hot path on one batch of synthetic 16 kHz x 1.5 s clips already resident in HBM:
+fused log-mel(40)+SpecAugment -> cnn_small forward -> 2-class loss -> backward -> [RCCL all-reduce of the flat
+gradient bucket] -> grad-norm clip -> AdamW step, i.e. wakeword_trainer_home_amd.training.Trainer._step_native
+(BASELINE.json config 2: cnn_small + log-mel 40, batch 512 per GPU).  Rank 0 prints ONE JSON line with the
+metric, the roofline of the dominant kernel (HIP-event timed inside the timed region) and the CPU baseline
+(the oracle's PyTorch CPU step on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+N_SAMPLES = 24000            # 16 kHz x 1.5 s
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the achievable copy rate
+A_ELEMS = 64 * 20 * 76       # one conv activation tensor per sample
+# ALGORITHMIC fp32 bytes per sample and launch, by kernel class (DESIGN.md "Measurement"): the per-layer
+# accounting of SURVEY.md §8d (write y, read y fwd, read y bwd, write dy, read dy) split over the kernels.
+ALGO_BYTES = {
+    "logmel_specaug": 96000 + 24160,
+    "conv_stem_fwd": 24160 + A_ELEMS * 4,
+    "dwconv3x3_fwd": 2 * A_ELEMS * 4,
+    "pwconv1x1_fwd": 2 * A_ELEMS * 4,
+    "gap_fwd": A_ELEMS * 4,
+    "pwconv1x1_bwd": 3 * A_ELEMS * 4,
+    "dwconv3x3_bwd": 3 * A_ELEMS * 4,
+    "conv_stem_bwd": 2 * A_ELEMS * 4,
+}
+STEP_ALGO_BYTES = 120160 + 45 * A_ELEMS * 4      # 17.63 MB / sample
+
+
+def cpu_baseline(batch, seconds_budget=20.0):
+    """Reference-style PyTorch CPU path (oracle/train_step.py: torch.stft log-mel -> SpecAugment -> cnn_small in
+    torch.nn -> label-smoothing CE -> backward -> clip -> AdamW), timed on this host's cores."""
+    import torch
+    from oracle.cnn_small import CNNSmallOracle
+    from oracle.train_step import TorchLoss, frontend, train_step
+    from wakeword_trainer_home_amd.data import make_synthetic_batch
+    # the 1-GPU box's CPU share is 16 cores; asking torch for all 256 hardware threads oversubscribes them
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(avail, 16)))
+    cores = torch.get_num_threads()
+    torch.manual_seed(0)
+    model = CNNSmallOracle(dropout=0.3).to(memory_format=torch.channels_last)
+    model.train()
+    crit = TorchLoss("cross_entropy", eps=0.05)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    wave, y = make_synthetic_batch(batch, N_SAMPLES, seed=1234)
+    spec = dict(freq_mask_param=15, time_mask_param=35, n_freq_masks=2, n_time_masks=2, freq_mask_prob=0.5,
+                time_mask_prob=0.5)
+
+    def one(i):
+        x, _ = frontend(wave.numpy(), spec, seed=2024, step=i)
+        train_step(model, crit, opt, x.to(memory_format=torch.channels_last), y, 1.0)
+    one(0)
+    t0 = time.perf_counter()
+    one(1)
+    per = time.perf_counter() - t0
+    steps = max(2, min(20, int(seconds_budget / max(per, 1e-3))))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(2 + i)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps x batch {batch} of the same workload (oracle PyTorch CPU step, fp32), "
+                      f"{dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=512, help="clips per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=128)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} "
+                         f"(WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from wakeword_trainer_home_amd import _native as nat
+    from wakeword_trainer_home_amd.config import get_preset
+    from wakeword_trainer_home_amd.data import make_synthetic_batch
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+
+    cfg = get_preset("cnn_small_logmel40")
+    cfg.training.batch_size = args.batch
+    torch.manual_seed(1234)                                   # same initial weights on every rank
+    model = create_model("cnn_small", num_classes=2, pretrained=False, dropout=cfg.model.dropout)
+    import tempfile
+    trainer = Trainer(model, [], [], cfg, checkpoint_dir=Path(tempfile.mkdtemp(prefix="wwbench_")), device=dev)
+    # a few distinct synthetic batches, generated on the device, rank-specific seeds (weak scaling)
+    pool = [make_synthetic_batch(args.batch, N_SAMPLES, seed=1234 + 97 * rank + i, device=dev) for i in range(4)]
+    trainer.model.train()
+
+    def step(i):
+        wave, y = pool[i % len(pool)]
+        r = trainer._step_native(wave, y, i)
+        trainer.state.global_step += 1
+        return r
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up; the first steps also tell which kernel class dominates
+    nat.prof_enable(dev, None)
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    warm = nat.prof_collect(dev)
+    dominant = max(warm, key=lambda k: warm[k][0]) if warm else "pwconv1x1_bwd"
+    nat.prof_enable(dev, [dominant])
+
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = nat.prof_collect(dev)
+    nat.prof_enable(dev, [])
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total = args.batch * world * args.steps
+        value = total / dt
+        ms, launches = prof.get(dominant, (0.0, 0))
+        per_launch_s = (ms / launches) * 1e-3 if launches else float("nan")
+        algo = ALGO_BYTES.get(dominant, 0) * args.batch
+        achieved = algo / per_launch_s / 1e9 if launches else float("nan")
+        out = {
+            "metric": "training samples/sec (16kHz x 1.5s clips)", "value": round(value, 1), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: cnn_small + log-mel(40) + SpecAugment, fwd/bwd + clip + AdamW, "
+                                   "16 kHz x 1.5 s clips resident in HBM", "batch_per_gpu": args.batch,
+                       "global_batch": args.batch * world, "n_samples": N_SAMPLES,
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "last_loss": None if last is None else round(last[0], 6)},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": launches,
+                         "algorithmic_bytes_per_launch": algo,
+                         "step_frac_of_hbm_roofline": round(value / world * STEP_ALGO_BYTES / (HBM_PEAK_GBS * 1e9), 4)},
+            "kernel_ms_per_step_warmup": {k: round(v[0] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -196,6 +196,16 @@ int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64_t *targets
  * only the norm is computed.  norm_out (nullable) receives the pre-clip L2 norm.          */
 int ww_grad_norm_clip(ww_ctx *ctx, float *flat_grads, size_t n, float max_norm, float *norm_out,
                       ww_stream_t stream);
+/* ------------------------------------------------------------------ measurement
+ * Opt-in timing of kernel classes with hipEvents recorded on the launch stream around the
+ * class's main kernel (bench.py's roofline leg; no reference counterpart -- the reference never
+ * measures, src/ui/panel_training.py:69,484).  ww_prof_collect synchronises on the recorded events
+ * and returns, per class, the summed milliseconds and the number of launches since the last call. */
+int ww_prof_num_classes(void);
+const char *ww_prof_class_name(int cls);
+int ww_prof_enable(ww_ctx *ctx, uint32_t class_mask);
+int ww_prof_collect(ww_ctx *ctx, float *ms_sum, int32_t *count);
+
 /* floor(p * 2^32) clamped to [0, 2^32] -- the integer probability threshold of the specs  */
 uint64_t ww_prob_threshold(double p);
 /* Philox4x32-10, exported so host tests can pin the device RNG's law (oracle/philox.py)   */

@@ -1,0 +1,90 @@
+"""CPU: numpy emulation of k_logmel's FFT index algebra (wakeword_trainer_home_amd/csrc/ww_frontend.hip):
+1024 = 16 x 16 x 4 decomposition with 16 points per lane, the padded LDS slot map, the in-place passes 2/3,
+the fft16 output-slot permutation, and the separation of two real frames packed into one complex FFT.
+The HIP kernel transcribes exactly these index formulas; the GPU tests then check the arithmetic."""
+import numpy as np
+
+N, STRIDE = 1024, 68
+
+
+def W(n, k, n_pts):
+    return np.exp(-2j * np.pi * ((n * k) % n_pts) / n_pts)
+
+
+def fft4(v0, v1, v2, v3):
+    a, b, c, d = v0 + v2, v0 - v2, v1 + v3, v1 - v3
+    return a + c, b - 1j * d, a - c, b + 1j * d
+
+
+def fft16_slots(v):
+    """v: list of 16 arrays in natural order -> list where X[k] sits at slot (k>>2) + 4*(k&3) (as in the kernel)."""
+    v = list(v)
+    for j1 in range(4):
+        v[j1], v[j1 + 4], v[j1 + 8], v[j1 + 12] = fft4(v[j1], v[j1 + 4], v[j1 + 8], v[j1 + 12])
+    for j1 in range(1, 4):
+        for ka in range(1, 4):
+            v[j1 + 4 * ka] = v[j1 + 4 * ka] * W(j1, ka, 16)
+    for ka in range(4):
+        v[4 * ka], v[4 * ka + 1], v[4 * ka + 2], v[4 * ka + 3] = fft4(v[4 * ka], v[4 * ka + 1], v[4 * ka + 2], v[4 * ka + 3])
+    return v
+
+
+def slot(k):
+    return (k >> 2) + 4 * (k & 3)
+
+
+def test_fft16_slot_permutation():
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=16) + 1j * rng.normal(size=16)
+    out = fft16_slots([np.array(t) for t in x])
+    ref = np.fft.fft(x)
+    for k in range(16):
+        assert abs(out[slot(k)] - ref[k]) < 1e-12
+
+
+def test_packed_1024_point_fft_index_algebra():
+    rng = np.random.default_rng(1)
+    xa, xb = rng.normal(size=N), rng.normal(size=N)
+    lane = np.arange(64)
+    buf = np.zeros(16 * STRIDE, complex)
+    # pass 1: lane holds n = lane + 64 j ; radix-16 over j ; twiddle W1024^(lane*kb) ; store [kb][lane]
+    regs = fft16_slots([xa[lane + 64 * j] + 1j * xb[lane + 64 * j] for j in range(16)])
+    for kb in range(16):
+        buf[kb * STRIDE + lane] = regs[slot(kb)] * W(lane, kb, 1024)
+    # pass 2 (in place): lane = kb*4 + q reads [kb][4m+q], radix-16 over m, twiddle W64^(q*kc), writes [kb][4kc+q]
+    kb2, q = lane >> 2, lane & 3
+    regs = fft16_slots([buf[kb2 * STRIDE + 4 * m + q] for m in range(16)])
+    touched_r = {(int(a), int(b)) for m in range(16) for a, b in zip(kb2, 4 * m + q)}
+    touched_w = {(int(a), int(b)) for kc in range(16) for a, b in zip(kb2, 4 * kc + q)}
+    assert touched_r == touched_w and len(touched_r) == 1024          # in place: each lane rewrites its own slots
+    for kc in range(16):
+        buf[kb2 * STRIDE + 4 * kc + q] = regs[slot(kc)] * W(16 * q * kc, 1, 1024)
+    # pass 3 (in place): radix-4 over the 4 consecutive slots of (kb, kc = (lane&3) + 4u)
+    for u in range(4):
+        base = kb2 * STRIDE + ((lane & 3) + 4 * u) * 4
+        o = fft4(buf[base], buf[base + 1], buf[base + 2], buf[base + 3])
+        for kd in range(4):
+            buf[base + kd] = o[kd]
+    # X[k] lives at [k&15][4*((k>>4)&15) + (k>>8)]
+    k = np.arange(N)
+    X = buf[(k & 15) * STRIDE + 4 * ((k >> 4) & 15) + (k >> 8)]
+    assert np.abs(X - np.fft.fft(xa + 1j * xb)).max() < 1e-10
+    # separation of the two real spectra + power, as in the kernel
+    kk = np.arange(513)
+    A, Bv = X[kk], X[(N - kk) & 1023]
+    pa = 0.25 * ((A.real + Bv.real) ** 2 + (A.imag - Bv.imag) ** 2)
+    pb = 0.25 * ((A.imag + Bv.imag) ** 2 + (A.real - Bv.real) ** 2)
+    assert np.abs(pa - np.abs(np.fft.rfft(xa)) ** 2).max() < 1e-8
+    assert np.abs(pb - np.abs(np.fft.rfft(xb)) ** 2).max() < 1e-8
+
+
+def test_mel_band_halves_cover_each_band_once():
+    from oracle.features import mel_filterbank
+    fb = mel_filterbank(513, 40, 16000)
+    for m in range(40):
+        nz = np.nonzero(fb[:, m] > 0)[0]
+        s, L = int(nz[0]), len(nz)
+        assert np.array_equal(nz, np.arange(s, s + L))              # bands are contiguous
+        h0 = (L + 1) >> 1
+        halves = list(range(0, h0)) + list(range(h0, L))
+        assert halves == list(range(L))

@@ -138,6 +138,7 @@ def test_module_api_autograd_and_accumulation():
     crit(model(x.to(DEV)), y.to(DEV)).backward()  # second backward without zero_grad accumulates
     for n, p in model.named_parameters():
         assert torch.allclose(p.grad, 1.5 * g1[n], rtol=2e-3, atol=1e-7), n
+    oracle(x)                                     # mirror the second training forward (running statistics)
     model.eval()
     with torch.no_grad():
         e_out = model(x.to(DEV))

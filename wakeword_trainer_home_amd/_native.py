@@ -74,6 +74,10 @@ _SIGS = {
                                    _sz, _vp]),
     "ww_ce2_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ww_grad_norm_clip": (C.c_int, [_vp, _vp, _sz, _f, _vp, _vp]),
+    "ww_prof_num_classes": (C.c_int, []),
+    "ww_prof_class_name": (C.c_char_p, [_i]),
+    "ww_prof_enable": (C.c_int, [_vp, C.c_uint32]),
+    "ww_prof_collect": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "ww_prob_threshold": (_u64, [C.c_double]),
     "ww_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
@@ -387,6 +391,30 @@ def grad_norm_clip_(flat, max_norm, norm_out=None):
         _check(load().ww_grad_norm_clip(ctx(dev), _p(flat), flat.numel(), float(max_norm), _p(norm_out), _stream(dev)),
                "ww_grad_norm_clip")
     return norm_out
+
+
+def prof_classes():
+    lib = load()
+    return [lib.ww_prof_class_name(i).decode() for i in range(lib.ww_prof_num_classes())]
+
+
+def prof_enable(dev, names=None):
+    """Time the given kernel classes (None = all, [] = off) with HIP events on the launch stream."""
+    classes = prof_classes()
+    mask = 0
+    for i, n in enumerate(classes):
+        if names is None or n in names:
+            mask |= 1 << i
+    _check(load().ww_prof_enable(ctx(dev), mask), "ww_prof_enable")
+
+
+def prof_collect(dev):
+    """-> {class: (total_ms, launches)} since the last collect (waits for the recorded events)."""
+    classes = prof_classes()
+    ms = (C.c_float * len(classes))()
+    cnt = (C.c_int32 * len(classes))()
+    _check(load().ww_prof_collect(ctx(dev), ms, cnt), "ww_prof_collect")
+    return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(classes) if cnt[i]}
 
 
 def decode_stats(stats_cpu: torch.Tensor) -> dict:

@@ -17,7 +17,6 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int PW_TILE = 128;
 constexpr int PW_LD = 68;
 
 // ------------------------------------------------------------------------------------- head
@@ -81,11 +80,14 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ dlog
 }
 
 // -------------------------------------------------------------------------------- pointwise
-// LDS: dyt[128][68] | yit[128][68]  (dynamic, 69632 B).
-// Wave roles inside a 128-pixel tile (4 waves):
-//   dX : wave (rh, n)  -> pixels [64rh, 64rh+64) x input channels [32n, 32n+32)   (64 MFMA)
-//   dW : wave (jt, kt) -> the 32x32 quadrant dW[32jt.., 32kt..] over all 128 pixels (64 MFMA)
-// so a lane keeps 32 weight registers and 16 persistent dW accumulators.
+// LDS: dyt[64][68] | yit[64][68]  (34816 B).
+// Wave roles inside a 64-pixel tile (4 waves):
+//   dX : wave (rh, n)  -> pixels [32rh, 32rh+32) x input channels [32n, 32n+32)    (32 MFMA)
+//   dW : wave (jt, kt) -> the 32x32 quadrant dW[32jt.., 32kt..] over all 64 pixels  (32 MFMA)
+// so a lane keeps 32 weight registers and 16 persistent dW accumulators; the next tile's three input
+// tensors are prefetched into 48 registers while the 64 MFMAs of this tile run.
+constexpr int PWB_TILE = 64;
+
 template <bool FROM_POOL>
 __global__ __launch_bounds__(256, 2) void k_pw_bwd(const float *__restrict__ g, const float *__restrict__ dpool,
                                                    const float *__restrict__ y_out, const float *__restrict__ ss_out,
@@ -94,8 +96,8 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const float *__restrict__ g, 
                                                    const float *__restrict__ w, long M, int HW,
                                                    float *__restrict__ g_in, float *__restrict__ stat_partials,
                                                    float *__restrict__ dw_partials) {
-    extern __shared__ __align__(16) float lds[];
-    float *dyt = lds, *yit = lds + PW_TILE * PW_LD;
+    __shared__ __align__(16) float lds[2 * PWB_TILE * PW_LD];
+    float *dyt = lds, *yit = lds + PWB_TILE * PW_LD;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int rh = wv >> 1, n = wv & 1;   // dX role; also (jt, kt) = (rh, n) for the dW role
@@ -118,49 +120,61 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const float *__restrict__ g, 
     floatx16 dwacc = {0.f};
     float st1 = 0.f, st2 = 0.f;
 
-    const long ntiles = (M + PW_TILE - 1) / PW_TILE;
-    for (long ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
-        const long p0 = ti * PW_TILE;
+    const long ntiles = (M + PWB_TILE - 1) / PWB_TILE;
+    // software pipeline (see k_pw_fwd): next tile's g / y_out / y_in loads fly during this tile's MFMAs
+    float4 rg[4], ro[4], ri[4];
+    auto issue = [&](long ti) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
+            long p = ti * PWB_TILE + (tid >> 4) + 16 * i;
+            p = p < M ? p : M - 1;                       // clamped, branch-free; masked when consumed
+            ro[i] = *reinterpret_cast<const float4 *>(y_out + (size_t)p * 64 + 4 * c4);
+            ri[i] = *reinterpret_cast<const float4 *>(y_in + (size_t)p * 64 + 4 * c4);
+            if (!FROM_POOL) rg[i] = *reinterpret_cast<const float4 *>(g + (size_t)p * 64 + 4 * c4);
+        }
+    };
+    if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
+    for (long ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const long p0 = ti * PWB_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             const int row = (tid >> 4) + 16 * i;
             const long p = p0 + row;
-            float4 dy = make_float4(0.f, 0.f, 0.f, 0.f), yi = dy;
-            if (p < M) {
-                const float4 yo = *reinterpret_cast<const float4 *>(y_out + (size_t)p * 64 + 4 * c4);
-                float4 dz;
-                if (FROM_POOL) {
-                    const float4 dp = *reinterpret_cast<const float4 *>(dpool + (size_t)(p / HW) * 64 + 4 * c4);
-                    dz.x = fmaf(yo.x, so.x, to.x) > 0.f ? dp.x : 0.f;
-                    dz.y = fmaf(yo.y, so.y, to.y) > 0.f ? dp.y : 0.f;
-                    dz.z = fmaf(yo.z, so.z, to.z) > 0.f ? dp.z : 0.f;
-                    dz.w = fmaf(yo.w, so.w, to.w) > 0.f ? dp.w : 0.f;
-                } else {
-                    dz = *reinterpret_cast<const float4 *>(g + (size_t)p * 64 + 4 * c4);
-                }
-                dy.x = fmaf(cA.x, dz.x, fmaf(cB.x, yo.x, cC.x));
-                dy.y = fmaf(cA.y, dz.y, fmaf(cB.y, yo.y, cC.y));
-                dy.z = fmaf(cA.z, dz.z, fmaf(cB.z, yo.z, cC.z));
-                dy.w = fmaf(cA.w, dz.w, fmaf(cB.w, yo.w, cC.w));
-                yi = *reinterpret_cast<const float4 *>(y_in + (size_t)p * 64 + 4 * c4);
+            const bool ok = p < M;
+            const float4 yo = ro[i];
+            float4 dz;
+            if (FROM_POOL) {
+                const float4 dp = *reinterpret_cast<const float4 *>(dpool + (size_t)((ok ? p : M - 1) / HW) * 64 + 4 * c4);
+                dz.x = fmaf(yo.x, so.x, to.x) > 0.f ? dp.x : 0.f;
+                dz.y = fmaf(yo.y, so.y, to.y) > 0.f ? dp.y : 0.f;
+                dz.z = fmaf(yo.z, so.z, to.z) > 0.f ? dp.z : 0.f;
+                dz.w = fmaf(yo.w, so.w, to.w) > 0.f ? dp.w : 0.f;
+            } else {
+                dz = rg[i];
             }
+            float4 dy, yi;
+            dy.x = ok ? fmaf(cA.x, dz.x, fmaf(cB.x, yo.x, cC.x)) : 0.f;
+            dy.y = ok ? fmaf(cA.y, dz.y, fmaf(cB.y, yo.y, cC.y)) : 0.f;
+            dy.z = ok ? fmaf(cA.z, dz.z, fmaf(cB.z, yo.z, cC.z)) : 0.f;
+            dy.w = ok ? fmaf(cA.w, dz.w, fmaf(cB.w, yo.w, cC.w)) : 0.f;
+            yi.x = ok ? ri[i].x : 0.f; yi.y = ok ? ri[i].y : 0.f; yi.z = ok ? ri[i].z : 0.f; yi.w = ok ? ri[i].w : 0.f;
             *reinterpret_cast<float4 *>(dyt + row * PW_LD + 4 * c4) = dy;   // rows past M: dy = 0, y_in = 0
             *reinterpret_cast<float4 *>(yit + row * PW_LD + 4 * c4) = yi;
         }
         __syncthreads();
+        if (ti + gridDim.x < ntiles) issue(ti + gridDim.x);
         // ---- dX = dy . W   (rows = pixels, K = output channel j, cols = input channel k)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int rbase = 64 * rh + 32 * t;
-            float a[32];
+        {
+            const int rbase = 32 * rh;
+            floatx16 acc = {0.f};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float4 v = *reinterpret_cast<const float4 *>(dyt + (rbase + r) * PW_LD + 32 * h + 4 * j);
-                a[4 * j] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, wt[4 * j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, wt[4 * j + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, wt[4 * j + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, wt[4 * j + 3], acc, 0, 0, 0);
             }
-            floatx16 acc = {0.f};
-#pragma unroll
-            for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wt[s], acc, 0, 0, 0);
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -172,10 +186,10 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const float *__restrict__ g, 
                 st2 = fmaf(d, (yv - mui) * rsi, st2);
             }
         }
-        // ---- dW[j][k] += sum_p dy[p][j] * a[p][k] ; K = pixels, lane half h <-> pixel 64h + s
-#pragma unroll 16
-        for (int s = 0; s < 64; ++s) {
-            const int prow = 64 * h + s;
+        // ---- dW[j][k] += sum_p dy[p][j] * a[p][k] ; K = pixels, lane half h <-> pixel 32h + s
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const int prow = 32 * h + s;
             const float dyv = dyt[prow * PW_LD + 32 * rh + r];
             const float av = fmaxf(fmaf(yit[prow * PW_LD + 32 * n + r], sci, sfi), 0.f);
             dwacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dyv, av, dwacc, 0, 0, 0);
@@ -208,36 +222,51 @@ struct DwGeom {
     long items;
 };
 
-__device__ __forceinline__ void dwb_load_dy(const float *__restrict__ gimg, const float *__restrict__ yimg, int h,
-                                            int w0, int H, int W, float2 cA, float2 cB, float2 cC, int cl,
-                                            float2 (&r)[6]) {
+constexpr int DW_HS = 10;   // max rows per strip segment (matches ww_conv_fwd.hip)
+
+__device__ __forceinline__ void dwb_issue(const float *__restrict__ gimg, const float *__restrict__ yimg, int h, int w0,
+                                          int H, int W, int cl, float2 (&rg)[6], float2 (&ry)[6]) {
+    const int hh = min(max(h, 0), H - 1);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int wc = min(max(w0 - 1 + i, 0), W - 1);
+        const size_t o = ((size_t)hh * W + wc) * 64 + 2 * cl;
+        rg[i] = *reinterpret_cast<const float2 *>(gimg + o);
+        ry[i] = *reinterpret_cast<const float2 *>(yimg + o);
+    }
+}
+// dy = A*g + Bc*y + Cc inside the image, 0 outside (zero padding of the transposed conv)
+__device__ __forceinline__ void dwb_finish(const float2 (&rg)[6], const float2 (&ry)[6], int h, int w0, int H, int W,
+                                           float2 cA, float2 cB, float2 cC, float2 (&r)[6]) {
     const bool hv = (h >= 0) && (h < H);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int wc = w0 - 1 + i;
-        float2 v = make_float2(0.f, 0.f);
-        if (hv && wc >= 0 && wc < W) {
-            const size_t o = ((size_t)h * W + wc) * 64 + 2 * cl;
-            const float2 gz = *reinterpret_cast<const float2 *>(gimg + o);
-            const float2 yo = *reinterpret_cast<const float2 *>(yimg + o);
-            v.x = fmaf(cA.x, gz.x, fmaf(cB.x, yo.x, cC.x));
-            v.y = fmaf(cA.y, gz.y, fmaf(cB.y, yo.y, cC.y));
-        }
-        r[i] = v;
+        const bool ok = hv && wc >= 0 && wc < W;
+        r[i].x = ok ? fmaf(cA.x, rg[i].x, fmaf(cB.x, ry[i].x, cC.x)) : 0.f;
+        r[i].y = ok ? fmaf(cA.y, rg[i].y, fmaf(cB.y, ry[i].y, cC.y)) : 0.f;
+    }
+}
+__device__ __forceinline__ void dwb_issue_centre(const float *__restrict__ yin_img, int h, int w0, int H, int W, int cl,
+                                                 float2 (&rc)[4]) {
+    const int hh = min(max(h, 0), H - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int wc = min(w0 + i, W - 1);
+        rc[i] = *reinterpret_cast<const float2 *>(yin_img + ((size_t)hh * W + wc) * 64 + 2 * cl);
     }
 }
 
-// centre row h:  rs0 = dy[h+1] (pairs with weight row 0), rs1 = dy[h], rs2 = dy[h-1]
-__device__ __forceinline__ void dwb_row(const float *__restrict__ yin_img, float *__restrict__ gin_img, int h, int w0,
-                                        int W, int cl, const float2 (&rs0)[6], const float2 (&rs1)[6],
-                                        const float2 (&rs2)[6], const float (&wa)[9], const float (&wb)[9], float2 sc,
-                                        float2 sf, float2 mu, float2 rsd, float (&dwa)[9], float (&dwb)[9], float &s1a,
-                                        float &s1b, float &s2a, float &s2b) {
+// centre row h:  rs0 = dy[h+1] (pairs with weight row 0), rs1 = dy[h], rs2 = dy[h-1]; yc = y_in[h][w0..w0+3]
+__device__ __forceinline__ void dwb_row(const float2 (&yc)[4], float *__restrict__ gin_img, int h, int w0, int W, int cl,
+                                        const float2 (&rs0)[6], const float2 (&rs1)[6], const float2 (&rs2)[6],
+                                        const float (&wa)[9], const float (&wb)[9], float2 sc, float2 sf, float2 mu,
+                                        float2 rsd, float (&dwa)[9], float (&dwb)[9], float &s1a, float &s1b, float &s2a,
+                                        float &s2b) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (w0 + i < W) {
-            const size_t o = ((size_t)h * W + w0 + i) * 64 + 2 * cl;
-            const float2 yv = *reinterpret_cast<const float2 *>(yin_img + o);
+            const float2 yv = yc[i];
             const float z0 = fmaf(yv.x, sc.x, sf.x), z1 = fmaf(yv.y, sc.y, sf.y);
             const float a0 = fmaxf(z0, 0.f), a1 = fmaxf(z1, 0.f);
             float d0 = 0.f, d1 = 0.f;
@@ -252,7 +281,7 @@ __device__ __forceinline__ void dwb_row(const float *__restrict__ yin_img, float
                 dwa[6 + kw] = fmaf(a0, t2.x, dwa[6 + kw]); dwb[6 + kw] = fmaf(a1, t2.y, dwb[6 + kw]);
             }
             const float g0 = z0 > 0.f ? d0 : 0.f, g1 = z1 > 0.f ? d1 : 0.f;
-            *reinterpret_cast<float2 *>(gin_img + o) = make_float2(g0, g1);
+            *reinterpret_cast<float2 *>(gin_img + ((size_t)h * W + w0 + i) * 64 + 2 * cl) = make_float2(g0, g1);
             s1a += g0; s1b += g1;
             s2a = fmaf(g0, (yv.x - mu.x) * rsd.x, s2a);
             s2b = fmaf(g1, (yv.y - mu.y) * rsd.y, s2b);
@@ -294,21 +323,30 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const float *__restrict__ g, con
         const float *yoimg = y_out + (size_t)b * img_stride;
         const float *yiimg = y_in + (size_t)b * img_stride;
         float *giimg = g_in + (size_t)b * img_stride;
-        float2 r0[6], r1[6], r2[6];  // r0 = dy[h-1], r1 = dy[h], r2 = dy[h+1] at loop entry
-        dwb_load_dy(gimg, yoimg, hs - 1, w0, gm.H, gm.W, cA, cB, cC, cl, r0);
-        dwb_load_dy(gimg, yoimg, hs, w0, gm.H, gm.W, cA, cB, cC, cl, r1);
-        for (int h = hs; h < he; h += 3) {
-            dwb_load_dy(gimg, yoimg, h + 1, w0, gm.H, gm.W, cA, cB, cC, cl, r2);
-            dwb_row(yiimg, giimg, h, w0, gm.W, cl, r2, r1, r0, wa, wb, sc, sf, mu, rsd, dwa, dwb, s1a, s1b, s2a, s2b);
-            if (h + 1 < he) {
-                dwb_load_dy(gimg, yoimg, h + 2, w0, gm.H, gm.W, cA, cB, cC, cl, r0);
-                dwb_row(yiimg, giimg, h + 1, w0, gm.W, cl, r0, r2, r1, wa, wb, sc, sf, mu, rsd, dwa, dwb, s1a, s1b, s2a,
-                        s2b);
-            }
-            if (h + 2 < he) {
-                dwb_load_dy(gimg, yoimg, h + 3, w0, gm.H, gm.W, cA, cB, cC, cl, r1);
-                dwb_row(yiimg, giimg, h + 2, w0, gm.W, cl, r1, r0, r2, wa, wb, sc, sf, mu, rsd, dwa, dwb, s1a, s1b, s2a,
-                        s2b);
+        // rows[i%3] = dy[h-1], rows[(i+1)%3] = dy[h], rows[(i+2)%3] = dy[h+1]; raw dy row h+2 and the raw centre row
+        // h+1 are in flight while row h is processed
+        float2 rows[3][6], rg[6], ry[6], ag[6], ay[6], yc[4], ayc[4];
+        dwb_issue(gimg, yoimg, hs - 1, w0, gm.H, gm.W, cl, rg, ry);
+        dwb_finish(rg, ry, hs - 1, w0, gm.H, gm.W, cA, cB, cC, rows[0]);
+        dwb_issue(gimg, yoimg, hs, w0, gm.H, gm.W, cl, rg, ry);
+        dwb_finish(rg, ry, hs, w0, gm.H, gm.W, cA, cB, cC, rows[1]);
+        dwb_issue(gimg, yoimg, hs + 1, w0, gm.H, gm.W, cl, ag, ay);
+        dwb_issue_centre(yiimg, hs, w0, gm.H, gm.W, cl, ayc);
+#pragma unroll
+        for (int i = 0; i < DW_HS; ++i) {
+            const int h = hs + i;
+            if (h < he) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) { rg[c] = ag[c]; ry[c] = ay[c]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) yc[c] = ayc[c];
+                if (i + 1 < DW_HS) {
+                    dwb_issue(gimg, yoimg, h + 2, w0, gm.H, gm.W, cl, ag, ay);
+                    dwb_issue_centre(yiimg, h + 1, w0, gm.H, gm.W, cl, ayc);
+                }
+                dwb_finish(rg, ry, h + 1, w0, gm.H, gm.W, cA, cB, cC, rows[(i + 2) % 3]);
+                dwb_row(yc, giimg, h, w0, gm.W, cl, rows[(i + 2) % 3], rows[(i + 1) % 3], rows[i % 3], wa, wb, sc, sf, mu,
+                        rsd, dwa, dwb, s1a, s1b, s2a, s2b);
             }
         }
     }
@@ -401,6 +439,7 @@ extern "C" int ww_head_bwd(ww_ctx *ctx, const float *dlogits, const float *pd, c
     WW_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, WW_E_INVALID, "ww_head_bwd: dropout_p=%f not in [0,1)", dropout_p);
     const int use_dropout = training && dropout_p > 0.f;
     const float scale = (float)(1.0 / (1.0 - (double)dropout_p));
+    ww_prof_scope ps_(ctx, WW_K_HEAD_LOSS, (hipStream_t)stream);
     hipLaunchKernelGGL(k_head_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream, dlogits, pd, pool, B, HW, fc_w, scale,
                        ww_prob_threshold((double)dropout_p), use_dropout, (uint32_t)seed, (uint32_t)(seed >> 32),
                        (uint32_t)step, (uint32_t)(step >> 32), sample_offset, gamma_last, mr_last, dfc_w, dfc_b, dpool,
@@ -420,23 +459,25 @@ extern "C" int ww_pwconv1x1_bwd(ww_ctx *ctx, const float *g, const float *dpool,
     WW_REQUIRE(g || (dpool && ss_out), WW_E_INVALID, "ww_pwconv1x1_bwd: need g, or dpool + ss_out for the last layer");
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_pwconv1x1_bwd: bad shape (%d,%d,%d)", B, H, W);
     const long M = (long)B * H * W;
-    const long ntiles = (M + PW_TILE - 1) / PW_TILE;
-    const size_t smem = (size_t)2 * PW_TILE * PW_LD * sizeof(float);
+    const long ntiles = (M + PWB_TILE - 1) / PWB_TILE;
+    const size_t smem = 0;   // static LDS
     hipStream_t st = (hipStream_t)stream;
     float *stat = (float *)scratch, *dwp = stat + WW_STAT_SLAB_FLOATS;
     int grid;
+    {
+    ww_prof_scope ps_(ctx, WW_K_PW_BWD, st);
     if (g) {
-        WW_HIP(hipFuncSetAttribute((const void *)k_pw_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         grid = ww_occupancy_grid((const void *)k_pw_bwd<false>, 256, smem, ntiles, WW_DW_SLAB_ROWS);
         hipLaunchKernelGGL(k_pw_bwd<false>, dim3(grid), dim3(256), smem, st, g, dpool, y_out, ss_out, coef, y_in, ss_in,
                            mr_in, w, M, H * W, g_in, stat, dwp);
     } else {
-        WW_HIP(hipFuncSetAttribute((const void *)k_pw_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         grid = ww_occupancy_grid((const void *)k_pw_bwd<true>, 256, smem, ntiles, WW_DW_SLAB_ROWS);
         hipLaunchKernelGGL(k_pw_bwd<true>, dim3(grid), dim3(256), smem, st, g, dpool, y_out, ss_out, coef, y_in, ss_in,
                            mr_in, w, M, H * W, g_in, stat, dwp);
     }
+    }
     WW_LAUNCH_CHECK();
+    ww_prof_scope pf_(ctx, WW_K_FINALIZE, st);
     int rc = ww_launch_bn_bwd_finalize(stat, grid, (double)M, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, st);
     if (rc) return rc;
     return ww_launch_colsum(dwp, grid, 4096, dw, st);
@@ -453,16 +494,18 @@ extern "C" int ww_dwconv3x3_bwd(ww_ctx *ctx, const float *g, const float *y_out,
     DwGeom gm;
     gm.B = B; gm.H = H; gm.W = W;
     gm.ncs = (W + 3) / 4;
-    gm.nseg = H >= 16 ? 2 : 1;
-    gm.hs_len = (H + gm.nseg - 1) / gm.nseg;
+    gm.nseg = (H + DW_HS - 1) / DW_HS;
+    gm.hs_len = (H + gm.nseg - 1) / gm.nseg;   // <= DW_HS
     gm.items = (long)B * gm.nseg * gm.ncs;
     const long nblk = (gm.items + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
     float *stat = (float *)scratch, *dwp = stat + WW_STAT_SLAB_FLOATS;
     const int grid = ww_occupancy_grid((const void *)k_dw_bwd, 256, 0, nblk, WW_MAX_PARTIALS);
-    hipLaunchKernelGGL(k_dw_bwd, dim3(grid), dim3(256), 0, st, g, y_out, coef, y_in, ss_in, mr_in, w, gm, g_in, stat,
-                       dwp);
+    { ww_prof_scope ps_(ctx, WW_K_DW_BWD, st);
+      hipLaunchKernelGGL(k_dw_bwd, dim3(grid), dim3(256), 0, st, g, y_out, coef, y_in, ss_in, mr_in, w, gm, g_in, stat,
+                         dwp); }
     WW_LAUNCH_CHECK();
+    ww_prof_scope pf_(ctx, WW_K_FINALIZE, st);
     int rc = ww_launch_bn_bwd_finalize(stat, grid, (double)B * H * W, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, st);
     if (rc) return rc;
     return ww_launch_colsum(dwp, grid, 576, dw, st);
@@ -477,7 +520,9 @@ extern "C" int ww_conv_stem_bwd(ww_ctx *ctx, const float *g, const float *y_out,
     hipStream_t st = (hipStream_t)stream;
     float *dwp = (float *)scratch + WW_STAT_SLAB_FLOATS;
     const int grid = ww_occupancy_grid((const void *)k_stem_bwd, 256, 0, nrows, WW_MAX_PARTIALS);
-    hipLaunchKernelGGL(k_stem_bwd, dim3(grid), dim3(256), 0, st, g, y_out, coef, x, B, Hin, Win, Ho, Wo, dwp);
+    { ww_prof_scope ps_(ctx, WW_K_STEM_BWD, st);
+      hipLaunchKernelGGL(k_stem_bwd, dim3(grid), dim3(256), 0, st, g, y_out, coef, x, B, Hin, Win, Ho, Wo, dwp); }
     WW_LAUNCH_CHECK();
+    ww_prof_scope pf_(ctx, WW_K_FINALIZE, st);
     return ww_launch_colsum(dwp, grid, 576, dw, st);
 }

@@ -89,19 +89,28 @@ struct DwGeom {
     long items;
 };
 
-__device__ __forceinline__ void dw_load_row(const float *__restrict__ img, int h, int w0, int H, int W, float2 sc,
-                                            float2 sf, int cl, float2 (&r)[6]) {
+constexpr int DW_HS = 10;   // max rows per strip segment (compile-time so the row loop fully unrolls)
+
+// raw (pre-BatchNorm) row of 6 pixels around the strip; addresses are clamped so the loads are branch-free
+__device__ __forceinline__ void dw_issue_row(const float *__restrict__ img, int h, int w0, int H, int W, int cl,
+                                             float2 (&raw)[6]) {
+    const int hh = min(max(h, 0), H - 1);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int wc = min(max(w0 - 1 + i, 0), W - 1);
+        raw[i] = *reinterpret_cast<const float2 *>(img + ((size_t)hh * W + wc) * 64 + 2 * cl);
+    }
+}
+// BatchNorm+ReLU of a raw row; positions outside the image are the conv's zero padding (in activation space)
+__device__ __forceinline__ void dw_finish_row(const float2 (&raw)[6], int h, int w0, int H, int W, float2 sc, float2 sf,
+                                              float2 (&r)[6]) {
     const bool hv = (h >= 0) && (h < H);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int wc = w0 - 1 + i;
-        float2 v = make_float2(0.f, 0.f);
-        if (hv && wc >= 0 && wc < W) {
-            const float2 t = *reinterpret_cast<const float2 *>(img + ((size_t)h * W + wc) * 64 + 2 * cl);
-            v.x = bnrelu(t.x, sc.x, sf.x);
-            v.y = bnrelu(t.y, sc.y, sf.y);
-        }
-        r[i] = v;
+        const bool ok = hv && wc >= 0 && wc < W;
+        r[i].x = ok ? bnrelu(raw[i].x, sc.x, sf.x) : 0.f;
+        r[i].y = ok ? bnrelu(raw[i].y, sc.y, sf.y) : 0.f;
     }
 }
 
@@ -152,19 +161,23 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const float *__restrict__ yin, c
         const int he = min(g.H, hs + g.hs_len);
         const float *img = yin + (size_t)b * img_stride;
         float *oimg = y + (size_t)b * img_stride;
-        float2 r0[6], r1[6], r2[6];
-        dw_load_row(img, hs - 1, w0, g.H, g.W, sc, sf, cl, r0);
-        dw_load_row(img, hs, w0, g.H, g.W, sc, sf, cl, r1);
-        for (int h = hs; h < he; h += 3) {
-            dw_load_row(img, h + 1, w0, g.H, g.W, sc, sf, cl, r2);
-            dw_out_row(oimg, h, w0, g.W, cl, r0, r1, r2, wa, wb, s0, s1, q0, q1);
-            if (h + 1 < he) {
-                dw_load_row(img, h + 2, w0, g.H, g.W, sc, sf, cl, r0);
-                dw_out_row(oimg, h + 1, w0, g.W, cl, r1, r2, r0, wa, wb, s0, s1, q0, q1);
-            }
-            if (h + 2 < he) {
-                dw_load_row(img, h + 3, w0, g.H, g.W, sc, sf, cl, r1);
-                dw_out_row(oimg, h + 2, w0, g.W, cl, r2, r0, r1, wa, wb, s0, s1, q0, q1);
+        // rows[(i)%3] = row h-1, rows[(i+1)%3] = row h, rows[(i+2)%3] = row h+1 ; `ahead` = raw row h+2 in flight
+        float2 rows[3][6], raw[6], ahead[6];
+        dw_issue_row(img, hs - 1, w0, g.H, g.W, cl, raw);
+        dw_finish_row(raw, hs - 1, w0, g.H, g.W, sc, sf, rows[0]);
+        dw_issue_row(img, hs, w0, g.H, g.W, cl, raw);
+        dw_finish_row(raw, hs, w0, g.H, g.W, sc, sf, rows[1]);
+        dw_issue_row(img, hs + 1, w0, g.H, g.W, cl, ahead);
+#pragma unroll
+        for (int i = 0; i < DW_HS; ++i) {
+            const int h = hs + i;
+            if (h < he) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) raw[c] = ahead[c];
+                if (i + 1 < DW_HS) dw_issue_row(img, h + 2, w0, g.H, g.W, cl, ahead);   // one row ahead of its use
+                dw_finish_row(raw, h + 1, w0, g.H, g.W, sc, sf, rows[(i + 2) % 3]);
+                dw_out_row(oimg, h, w0, g.W, cl, rows[i % 3], rows[(i + 1) % 3], rows[(i + 2) % 3], wa, wb, s0, s1, q0,
+                           q1);
             }
         }
     }
@@ -196,22 +209,33 @@ __global__ __launch_bounds__(256) void k_pw_fwd(const float *__restrict__ yin, c
     const float4 sf = *reinterpret_cast<const float4 *>(ss + 64 + 4 * c4);
     float s1 = 0.f, s2 = 0.f;
     const long ntiles = (M + PW_TILE - 1) / PW_TILE;
+    // software pipeline: the NEXT tile's global loads are issued right after the LDS barrier, so they are in
+    // flight while this tile's MFMAs run (co-resident workgroups otherwise fall into lockstep: all load, then
+    // all compute, and time = HBM + MFMA instead of max(HBM, MFMA))
+    float4 raw[8];
+    auto issue = [&](long ti) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            long p = ti * PW_TILE + (tid >> 4) + 16 * i;
+            p = p < M ? p : M - 1;                       // clamped, branch-free; masked when consumed
+            raw[i] = *reinterpret_cast<const float4 *>(yin + (size_t)p * 64 + 4 * c4);
+        }
+    };
+    if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
     for (long ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
         const long p0 = ti * PW_TILE;
-        // stage: coalesced 16-B loads, BN+ReLU in registers, padded LDS rows
+        // BN+ReLU in registers, padded LDS rows
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = (tid >> 4) + 16 * i;
-            const long p = p0 + row;
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < M) {
-                const float4 v = *reinterpret_cast<const float4 *>(yin + (size_t)p * 64 + 4 * c4);
-                a.x = bnrelu(v.x, sc.x, sf.x); a.y = bnrelu(v.y, sc.y, sf.y);
-                a.z = bnrelu(v.z, sc.z, sf.z); a.w = bnrelu(v.w, sc.w, sf.w);
-            }
+            const bool ok = p0 + row < M;
+            float4 a;
+            a.x = ok ? bnrelu(raw[i].x, sc.x, sf.x) : 0.f; a.y = ok ? bnrelu(raw[i].y, sc.y, sf.y) : 0.f;
+            a.z = ok ? bnrelu(raw[i].z, sc.z, sf.z) : 0.f; a.w = ok ? bnrelu(raw[i].w, sc.w, sf.w) : 0.f;
             *reinterpret_cast<float4 *>(tile + row * PW_LD + 4 * c4) = a;
         }
         __syncthreads();
+        if (ti + gridDim.x < ntiles) issue(ti + gridDim.x);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int rbase = 64 * rh + 32 * t;
@@ -313,8 +337,9 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float *__restrict__ pool
     }
 }
 
-int finish_bn(const float *partials, int rows, double count, const ww_bn_t *bn, float *ss_out, float *mr_out,
-              hipStream_t st) {
+int finish_bn(ww_ctx *ctx, const float *partials, int rows, double count, const ww_bn_t *bn, float *ss_out,
+              float *mr_out, hipStream_t st) {
+    ww_prof_scope ps_(ctx, WW_K_FINALIZE, st);
     if (bn->training) return ww_launch_bn_fwd_finalize(partials, rows, count, bn, ss_out, mr_out, st);
     return ww_launch_bn_eval_ss(bn, ss_out, mr_out, st);
 }
@@ -339,9 +364,10 @@ extern "C" int ww_conv_stem_fwd(ww_ctx *ctx, const float *x, const float *w, int
     const int grid = ww_occupancy_grid((const void *)k_stem_fwd, 256, 0, nrows, WW_MAX_PARTIALS);
     hipStream_t st = (hipStream_t)stream;
     float *partials = bn->training ? (float *)scratch : nullptr;
-    hipLaunchKernelGGL(k_stem_fwd, dim3(grid), dim3(256), 0, st, x, w, B, Hin, Win, Ho, Wo, y, partials);
+    { ww_prof_scope ps_(ctx, WW_K_STEM_FWD, st);
+      hipLaunchKernelGGL(k_stem_fwd, dim3(grid), dim3(256), 0, st, x, w, B, Hin, Win, Ho, Wo, y, partials); }
     WW_LAUNCH_CHECK();
-    return finish_bn(partials, grid, (double)B * Ho * Wo, bn, ss_out, mr_out, st);
+    return finish_bn(ctx, partials, grid, (double)B * Ho * Wo, bn, ss_out, mr_out, st);
 }
 
 extern "C" int ww_dwconv3x3_fwd(ww_ctx *ctx, const float *y_in, const float *ss_in, const float *w, int B, int H,
@@ -354,16 +380,17 @@ extern "C" int ww_dwconv3x3_fwd(ww_ctx *ctx, const float *y_in, const float *ss_
     DwGeom g;
     g.B = B; g.H = H; g.W = W;
     g.ncs = (W + 3) / 4;
-    g.nseg = H >= 16 ? 2 : 1;
-    g.hs_len = (H + g.nseg - 1) / g.nseg;
+    g.nseg = (H + DW_HS - 1) / DW_HS;
+    g.hs_len = (H + g.nseg - 1) / g.nseg;      // <= DW_HS
     g.items = (long)B * g.nseg * g.ncs;
     const long nblk = (g.items + 7) / 8;
     const int grid = ww_occupancy_grid((const void *)k_dw_fwd, 256, 0, nblk, WW_MAX_PARTIALS);
     hipStream_t st = (hipStream_t)stream;
     float *partials = bn->training ? (float *)scratch : nullptr;
-    hipLaunchKernelGGL(k_dw_fwd, dim3(grid), dim3(256), 0, st, y_in, ss_in, w, g, y, partials);
+    { ww_prof_scope ps_(ctx, WW_K_DW_FWD, st);
+      hipLaunchKernelGGL(k_dw_fwd, dim3(grid), dim3(256), 0, st, y_in, ss_in, w, g, y, partials); }
     WW_LAUNCH_CHECK();
-    return finish_bn(partials, grid, (double)B * H * W, bn, ss_out, mr_out, st);
+    return finish_bn(ctx, partials, grid, (double)B * H * W, bn, ss_out, mr_out, st);
 }
 
 extern "C" int ww_pwconv1x1_fwd(ww_ctx *ctx, const float *y_in, const float *ss_in, const float *w, int B, int H,
@@ -378,16 +405,18 @@ extern "C" int ww_pwconv1x1_fwd(ww_ctx *ctx, const float *y_in, const float *ss_
     const int grid = ww_occupancy_grid((const void *)k_pw_fwd, 256, 0, ntiles, WW_MAX_PARTIALS);
     hipStream_t st = (hipStream_t)stream;
     float *partials = bn->training ? (float *)scratch : nullptr;
-    hipLaunchKernelGGL(k_pw_fwd, dim3(grid), dim3(256), 0, st, y_in, ss_in, w, M, y, partials);
+    { ww_prof_scope ps_(ctx, WW_K_PW_FWD, st);
+      hipLaunchKernelGGL(k_pw_fwd, dim3(grid), dim3(256), 0, st, y_in, ss_in, w, M, y, partials); }
     WW_LAUNCH_CHECK();
-    return finish_bn(partials, grid, (double)M, bn, ss_out, mr_out, st);
+    return finish_bn(ctx, partials, grid, (double)M, bn, ss_out, mr_out, st);
 }
 
 extern "C" int ww_gap_fwd(ww_ctx *ctx, const float *y, const float *ss, const float *mr, int B, int H, int W,
                           float *pool, ww_stream_t stream) {
     WW_REQUIRE(ctx && y && ss && mr && pool, WW_E_INVALID, "ww_gap_fwd: null argument");
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_gap_fwd: bad shape (%d,%d,%d)", B, H, W);
-    hipLaunchKernelGGL(k_gap_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, y, ss, mr, H * W, pool);
+    { ww_prof_scope ps_(ctx, WW_K_GAP_FWD, (hipStream_t)stream);
+      hipLaunchKernelGGL(k_gap_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, y, ss, mr, H * W, pool); }
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -400,6 +429,7 @@ extern "C" int ww_head_fwd(ww_ctx *ctx, const float *pool, int B, int HW, const 
     WW_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, WW_E_INVALID, "ww_head_fwd: dropout_p=%f not in [0,1)", dropout_p);
     const int use_dropout = training && dropout_p > 0.f;
     const float scale = (float)(1.0 / (1.0 - (double)dropout_p));
+    ww_prof_scope ps_(ctx, WW_K_HEAD_LOSS, (hipStream_t)stream);
     hipLaunchKernelGGL(k_head_fwd, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, pool, B, HW, fc_w, fc_b,
                        scale, ww_prob_threshold((double)dropout_p), use_dropout, (uint32_t)seed, (uint32_t)(seed >> 32),
                        (uint32_t)step, (uint32_t)(step >> 32), sample_offset, pd, logits);

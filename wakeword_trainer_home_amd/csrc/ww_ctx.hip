@@ -47,6 +47,9 @@ extern "C" int ww_ctx_create(int device, ww_ctx **out) {
     ww_ctx *c = new ww_ctx();
     c->device = device;
     c->tables = nullptr;
+    c->prof_mask = 0;
+    c->prof_recs = new std::vector<ww_prof_rec>();
+    c->prof_free = new std::vector<ww_prof_rec>();
     *out = c;
     return WW_OK;
 }
@@ -69,6 +72,10 @@ static void free_tables(ww_feat_tables *t) {
 extern "C" int ww_ctx_destroy(ww_ctx *ctx) {
     if (!ctx) return WW_OK;
     free_tables(ctx->tables);
+    for (auto *v : {ctx->prof_recs, ctx->prof_free}) {
+        for (auto &r : *v) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        delete v;
+    }
     delete ctx;
     return WW_OK;
 }
@@ -149,6 +156,7 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
     memset(t, 0, sizeof(*t));
     t->cfg = *cfg;
     t->max_len = max_len;
+    t->n_mel_w = (int32_t)w.size();
     int rc;
     if ((rc = upload(&t->window, win)) || (rc = upload(&t->twiddle, tw)) || (rc = upload(&t->mel_start, start)) ||
         (rc = upload(&t->mel_len, len)) || (rc = upload(&t->mel_off, off)) || (rc = upload(&t->mel_w, w))) {
@@ -174,17 +182,23 @@ extern "C" size_t ww_layer_scratch_bytes(void) {
 // summed in double in a fixed order => bit-reproducible run to run.
 // ------------------------------------------------------------------------------------------
 
-// column sums of partials[rows][128] by one 1024-thread block: thread = (col, part of 8)
-__device__ inline double ww_col128_sum(const float *__restrict__ partials, int rows, double *sh) {
-    const int col = threadIdx.x & 127, part = threadIdx.x >> 7;
-    double acc = 0.0;
-    for (int r = part; r < rows; r += 8) acc += (double)partials[(size_t)r * 128 + col];
-    sh[threadIdx.x] = acc;
+// column sums of partials[rows][128] by one 1024-thread block: thread = (4 columns as float4, 1 of 32 row
+// parts); the <= 32 loads of a thread are independent, so the sweep is bandwidth- not latency-bound
+__device__ inline double ww_col128_sum(const float *__restrict__ partials, int rows, double *sh /*32*128*/) {
+    const int c4 = threadIdx.x & 31, part = threadIdx.x >> 5;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+    for (int r = part; r < rows; r += 32) {
+        const float4 v = *reinterpret_cast<const float4 *>(partials + (size_t)r * 128 + 4 * c4);
+        a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+    }
+    sh[part * 128 + 4 * c4] = a0; sh[part * 128 + 4 * c4 + 1] = a1;
+    sh[part * 128 + 4 * c4 + 2] = a2; sh[part * 128 + 4 * c4 + 3] = a3;
     __syncthreads();
     double tot = 0.0;
     if (threadIdx.x < 128) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) tot += sh[p * 128 + col];
+        for (int p = 0; p < 32; ++p) tot += sh[p * 128 + threadIdx.x];
     }
     return tot;  // valid for threadIdx.x < 128
 }
@@ -194,7 +208,7 @@ __device__ inline double ww_col128_sum(const float *__restrict__ partials, int r
 __global__ __launch_bounds__(1024) void k_bn_fwd_finalize(const float *__restrict__ partials, int rows,
                                                           double count, ww_bn_t bn, float *__restrict__ ss,
                                                           float *__restrict__ mr) {
-    __shared__ double sh[1024];
+    __shared__ double sh[32 * 128];
     __shared__ double tot[128];
     double t = ww_col128_sum(partials, rows, sh);
     if (threadIdx.x < 128) tot[threadIdx.x] = t;
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restric
                                                           double count, const float *__restrict__ gamma,
                                                           const float *__restrict__ mr, float *__restrict__ coef,
                                                           float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    __shared__ double sh[1024];
+    __shared__ double sh[32 * 128];
     __shared__ double tot[128];
     double t = ww_col128_sum(partials, rows, sh);
     if (threadIdx.x < 128) tot[threadIdx.x] = t;
@@ -257,18 +271,30 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restric
     }
 }
 
-// generic column sum: out[col] = sum_r partials[r][col]; block = 64 cols x 4 row parts
-__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partials, int rows, int cols,
-                                                float *__restrict__ out) {
-    __shared__ double sh[256];
-    const int lc = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lc;
-    double acc = 0.0;
-    if (col < cols)
-        for (int r = part; r < rows; r += 4) acc += (double)partials[(size_t)r * cols + col];
-    sh[threadIdx.x] = acc;
+// generic column sum: out[col] = sum_r partials[r][col]; block = 64 columns (16 float4 groups) x 64 row parts.
+// cols must be a multiple of 4 (576 and 4096 here).
+__global__ __launch_bounds__(1024) void k_colsum(const float *__restrict__ partials, int rows, int cols,
+                                                 float *__restrict__ out) {
+    __shared__ double sh[64 * 64];
+    const int c4 = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int col = blockIdx.x * 64 + 4 * c4;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (col < cols) {
+#pragma unroll 4
+        for (int r = part; r < rows; r += 64) {
+            const float4 v = *reinterpret_cast<const float4 *>(partials + (size_t)r * cols + col);
+            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+        }
+    }
+    sh[part * 64 + 4 * c4] = a0; sh[part * 64 + 4 * c4 + 1] = a1;
+    sh[part * 64 + 4 * c4 + 2] = a2; sh[part * 64 + 4 * c4 + 3] = a3;
     __syncthreads();
-    if (part == 0 && col < cols) out[col] = (float)(sh[lc] + sh[64 + lc] + sh[128 + lc] + sh[192 + lc]);
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < cols) {
+        double t = 0.0;
+#pragma unroll 8
+        for (int p = 0; p < 64; ++p) t += sh[p * 64 + threadIdx.x];
+        out[blockIdx.x * 64 + threadIdx.x] = (float)t;
+    }
 }
 
 int ww_launch_bn_fwd_finalize(const float *partials, int rows, double count, const ww_bn_t *bn, float *ss_out,
@@ -290,7 +316,7 @@ int ww_launch_bn_bwd_finalize(const float *partials, int rows, double count, con
     return WW_OK;
 }
 int ww_launch_colsum(const float *partials, int rows, int cols, float *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_colsum, dim3((cols + 63) / 64), dim3(256), 0, st, partials, rows, cols, out);
+    hipLaunchKernelGGL(k_colsum, dim3((cols + 63) / 64), dim3(1024), 0, st, partials, rows, cols, out);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -334,6 +360,7 @@ extern "C" int ww_grad_norm_clip(ww_ctx *ctx, float *flat_grads, size_t n, float
                                  ww_stream_t stream) {
     WW_REQUIRE(ctx && flat_grads, WW_E_INVALID, "ww_grad_norm_clip: null argument");
     if (n == 0) return WW_OK;
+    ww_prof_scope ps_(ctx, WW_K_CLIP, (hipStream_t)stream);
     hipLaunchKernelGGL(k_grad_norm_clip, dim3(1), dim3(1024), 0, (hipStream_t)stream, flat_grads, n, max_norm,
                        norm_out);
     WW_LAUNCH_CHECK();
@@ -366,4 +393,30 @@ int ww_occupancy_grid(const void *fn, int block, size_t smem, long want, int cap
     if (gsz > cap) gsz = cap;
     if (gsz > want) gsz = want;
     return (int)(gsz < 1 ? 1 : gsz);
+}
+
+// ------------------------------------------------------------------------------------------
+static const char *k_class_names[WW_K_NCLASS] = {"logmel_specaug", "conv_stem_fwd", "dwconv3x3_fwd", "pwconv1x1_fwd",
+                                                 "gap_fwd", "head_loss", "pwconv1x1_bwd", "dwconv3x3_bwd",
+                                                 "conv_stem_bwd", "finalize", "grad_norm_clip"};
+extern "C" int ww_prof_num_classes(void) { return WW_K_NCLASS; }
+extern "C" const char *ww_prof_class_name(int cls) { return (cls >= 0 && cls < WW_K_NCLASS) ? k_class_names[cls] : ""; }
+extern "C" int ww_prof_enable(ww_ctx *ctx, uint32_t class_mask) {
+    WW_REQUIRE(ctx != nullptr, WW_E_INVALID, "ww_prof_enable: ctx is null");
+    ctx->prof_mask = class_mask;
+    return WW_OK;
+}
+extern "C" int ww_prof_collect(ww_ctx *ctx, float *ms_sum, int32_t *count) {
+    WW_REQUIRE(ctx && ms_sum && count, WW_E_INVALID, "ww_prof_collect: null argument");
+    for (int i = 0; i < WW_K_NCLASS; ++i) { ms_sum[i] = 0.f; count[i] = 0; }
+    for (auto &r : *ctx->prof_recs) {
+        WW_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        WW_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        ms_sum[r.cls] += ms;
+        count[r.cls] += 1;
+        ctx->prof_free->push_back(r);
+    }
+    ctx->prof_recs->clear();
+    return WW_OK;
 }

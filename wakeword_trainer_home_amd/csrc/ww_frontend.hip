@@ -8,9 +8,11 @@
 //   pass 1  radix-16 in registers over n2 (n = lane + 64*n2), twiddle W1024^(lane*kb) -> LDS
 //   pass 2  radix-16 in registers over m  (lane = kb*4+q, n1 = 4m+q), twiddle W64^(q*kc) -> LDS
 //   pass 3  four radix-4 butterflies per lane -> X[16kc + 256kd + kb] -> LDS (natural order)
-// then the two real spectra are separated (X[k], conj X[N-k]), |.|^2 goes to LDS, each lane
-// owns one (frame, mel) band sum, and the 16 x F tile is transposed through LDS so the
-// (B,1,F,T) output is written in 64-byte runs along T.
+// (passes 2 and 3 run IN PLACE: each lane rewrites exactly the 16 LDS slots it read, so one 8.7 KB buffer per
+// wavefront suffices and two workgroups fit a CU).  Then the two real spectra are separated (X[k], conj X[N-k]),
+// |.|^2 goes to LDS, every mel band is summed by two adjacent lanes (half a band each, weights staged in LDS,
+// combined with one shuffle), and the 16 x F tile is transposed through LDS so the (B,1,F,T) output is
+// written in 64-byte runs along T.
 // Index algebra verified against numpy (tests/test_frontend_index_algebra.py).
 #include "ww_internal.h"
 
@@ -76,6 +78,7 @@ struct FeatArgs {
     const float *mel_w;
     const float *dct;
     int span_len;
+    int n_mel_w;
 };
 
 template <typename WaveT>
@@ -83,11 +86,14 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
                                                 int use_mask, ww_mask_params mp, int32_t *__restrict__ mask_idx) {
     extern __shared__ __align__(16) unsigned char smem[];
     float2 *tw = reinterpret_cast<float2 *>(smem);                    // 1024
-    float2 *fbuf = tw + 1024;                                         // 4 waves x 2 x BUF_ELEMS
-    float *lm = reinterpret_cast<float *>(fbuf + 4 * 2 * BUF_ELEMS);  // FR x M
+    float2 *fbuf = tw + 1024;                                         // 4 waves x BUF_ELEMS
+    float *pb = reinterpret_cast<float *>(fbuf + 4 * BUF_ELEMS);      // 4 waves x 2 x 516 power spectra
+    float *lm = pb + 4 * 2 * 516;                                     // FR x M
     float *feat = lm + FR * a.M;                                      // FR x F (== lm when !use_dct)
     int *msk = reinterpret_cast<int *>(feat + (a.use_dct ? FR * a.F : 0));  // 2*WW_MAX_MASKS
-    float *span = reinterpret_cast<float *>(msk + 2 * WW_MAX_MASKS);  // span_len
+    int *mtab = msk + 2 * WW_MAX_MASKS;                               // 3*M : start, len, offset
+    float *mw = reinterpret_cast<float *>(mtab + 3 * a.M);            // n_mel_w band weights
+    float *span = mw + a.n_mel_w;                                     // span_len
     if (!a.use_dct) feat = lm;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -96,6 +102,12 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
 
     // ---- stage twiddles, SpecAugment masks and the sample span
     for (int i = tid; i < 1024; i += 256) tw[i] = a.twiddle[i];
+    for (int i = tid; i < a.M; i += 256) {
+        mtab[3 * i] = a.mel_start[i];
+        mtab[3 * i + 1] = a.mel_len[i];
+        mtab[3 * i + 2] = a.mel_off[i];
+    }
+    for (int i = tid; i < a.n_mel_w; i += 256) mw[i] = a.mel_w[i];
     const int K = use_mask ? (mp.n_f + mp.n_t) : 0;
     if (tid < K) {
         int s, w;
@@ -119,9 +131,8 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
     }
     __syncthreads();
 
-    float2 *buf1 = fbuf + (wv * 2) * BUF_ELEMS;
-    float2 *buf2 = buf1 + BUF_ELEMS;
-    float *pbuf = reinterpret_cast<float *>(buf2);  // 2 x 516 floats, aliases buf2 after pass 3
+    float2 *buf = fbuf + wv * BUF_ELEMS;
+    float *pbuf = pb + wv * 2 * 516;
 
     for (int round = 0; round < 2; ++round) {
         const int fa = round * 8 + 2 * wv, fb = fa + 1;  // local frame indices of this wave's pair
@@ -140,14 +151,14 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
             float r = re[F16_SLOT(kb)], i = im[F16_SLOT(kb)];
             const float2 t = tw[(lane * kb) & 1023];
             cmul_c(r, i, t.x, t.y);
-            buf1[kb * BUF_STRIDE + lane] = make_float2(r, i);
+            buf[kb * BUF_STRIDE + lane] = make_float2(r, i);
         }
         __syncthreads();
         // ---- pass 2: lane = kb*4 + q ; radix-16 over m (n1 = 4m + q), twiddle W64^(q*kc)
         const int kb2 = lane >> 2, q = lane & 3;
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
-            const float2 v = buf1[kb2 * BUF_STRIDE + 4 * m + q];
+            const float2 v = buf[kb2 * BUF_STRIDE + 4 * m + q];
             re[m] = v.x;
             im[m] = v.y;
         }
@@ -157,33 +168,30 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
             float r = re[F16_SLOT(kc)], i = im[F16_SLOT(kc)];
             const float2 t = tw[(16 * q * kc) & 1023];
             cmul_c(r, i, t.x, t.y);
-            buf2[kb2 * BUF_STRIDE + kc * 4 + q] = make_float2(r, i);
+            buf[kb2 * BUF_STRIDE + kc * 4 + q] = make_float2(r, i);
         }
         __syncthreads();
-        // ---- pass 3: radix-4 over q for (kb, kc = (lane&3) + 4u) -> X[16kc + 256kd + kb] (natural, in buf1)
+        // ---- pass 3 (in place): radix-4 over q for (kb, kc = (lane&3) + 4u); slot [kb][4kc + kd] <- X[16kc + 256kd + kb]
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int kc = (lane & 3) + 4 * u;
-            const float2 v0 = buf2[kb2 * BUF_STRIDE + kc * 4 + 0];
-            const float2 v1 = buf2[kb2 * BUF_STRIDE + kc * 4 + 1];
-            const float2 v2 = buf2[kb2 * BUF_STRIDE + kc * 4 + 2];
-            const float2 v3 = buf2[kb2 * BUF_STRIDE + kc * 4 + 3];
+            float2 *s4 = buf + kb2 * BUF_STRIDE + ((lane & 3) + 4 * u) * 4;
+            const float2 v0 = s4[0], v1 = s4[1], v2 = s4[2], v3 = s4[3];
             float r0 = v0.x, i0 = v0.y, r1 = v1.x, i1 = v1.y, r2 = v2.x, i2 = v2.y, r3 = v3.x, i3 = v3.y;
             fft4(r0, i0, r1, i1, r2, i2, r3, i3);
-            const int kbase = 16 * kc + kb2;
-            buf1[kbase] = make_float2(r0, i0);
-            buf1[kbase + 256] = make_float2(r1, i1);
-            buf1[kbase + 512] = make_float2(r2, i2);
-            buf1[kbase + 768] = make_float2(r3, i3);
+            s4[0] = make_float2(r0, i0);
+            s4[1] = make_float2(r1, i1);
+            s4[2] = make_float2(r2, i2);
+            s4[3] = make_float2(r3, i3);
         }
         __syncthreads();
-        // ---- separate the two real spectra, power -> pbuf[frame][k]
+        // ---- separate the two real spectra, power -> pbuf[frame][k];  X[k] lives at [k&15][4*((k>>4)&15) + (k>>8)]
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
             const int k = lane + 64 * u;
             if (k <= 512) {
-                const float2 A = buf1[k];
-                const float2 Bv = buf1[(1024 - k) & 1023];
+                const int kn = (1024 - k) & 1023;
+                const float2 A = buf[(k & 15) * BUF_STRIDE + 4 * ((k >> 4) & 15) + (k >> 8)];
+                const float2 Bv = buf[(kn & 15) * BUF_STRIDE + 4 * ((kn >> 4) & 15) + (kn >> 8)];
                 const float xr = A.x + Bv.x, xi = A.y - Bv.y;   // 2*Xa
                 const float yr = A.y + Bv.y, yi = A.x - Bv.x;   // 2*Xb (up to sign of imag)
                 pbuf[k] = 0.25f * (xr * xr + xi * xi);
@@ -191,16 +199,25 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
             }
         }
         __syncthreads();
-        // ---- mel band sums: one lane per (frame, mel)
-        for (int it = lane; it < 2 * a.M; it += 64) {
-            const int fr = it >= a.M ? 1 : 0;
-            const int m = it - fr * a.M;
-            const int s = a.mel_start[m], L = a.mel_len[m];
-            const float *wp = a.mel_w + a.mel_off[m];
+        // ---- mel band sums: item = ((frame, mel), half); the two halves of a band sit in adjacent lanes
+        for (int it0 = 0; it0 < 4 * a.M; it0 += 64) {
+            const int it = it0 + lane;
+            const bool act = it < 4 * a.M;
+            const int pair = act ? it >> 1 : 0, half = it & 1;
+            const int fr = pair >= a.M ? 1 : 0;
+            const int m = pair - fr * a.M;
+            const int s = mtab[3 * m], L = mtab[3 * m + 1];
+            const int h0 = (L + 1) >> 1;
+            const int j0 = half ? h0 : 0, j1 = half ? L : h0;
+            const float *wp = mw + mtab[3 * m + 2];
             const float *pp = pbuf + fr * 516 + s;
             float acc = 0.f;
-            for (int j = 0; j < L; ++j) acc = fmaf(wp[j], pp[j], acc);
-            lm[(fa + fr) * a.M + m] = logf(acc + a.log_eps);
+            if (act) {
+#pragma unroll 4
+                for (int j = j0; j < j1; ++j) acc = fmaf(wp[j], pp[j], acc);
+            }
+            acc += __shfl_xor(acc, 1);
+            if (act && half == 0) lm[(fa + fr) * a.M + m] = logf(acc + a.log_eps);
         }
         __syncthreads();
     }
@@ -318,17 +335,20 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
     a.mel_start = tb->mel_start; a.mel_len = tb->mel_len; a.mel_off = tb->mel_off; a.mel_w = tb->mel_w;
     a.dct = tb->dct;
     a.span_len = (FR - 1) * cfg->hop + WW_NFFT;
+    a.n_mel_w = tb->n_mel_w;
     ww_mask_params mp = {};
     int use_mask = 0;
     if (sa) {
         if ((rc = resolve_mask(sa, seed, step, sample_offset, &mp))) return rc;
         use_mask = (mp.n_f + mp.n_t) > 0;
     }
-    const size_t smem = 1024 * sizeof(float2) + (size_t)4 * 2 * BUF_ELEMS * sizeof(float2) +
+    const size_t smem = 1024 * sizeof(float2) + (size_t)4 * BUF_ELEMS * sizeof(float2) + (size_t)4 * 2 * 516 * sizeof(float) +
                         (size_t)FR * a.M * sizeof(float) + (a.use_dct ? (size_t)FR * a.F * sizeof(float) : 0) +
-                        2 * WW_MAX_MASKS * sizeof(int) + (size_t)a.span_len * sizeof(float);
+                        2 * WW_MAX_MASKS * sizeof(int) + (size_t)3 * a.M * sizeof(int) + (size_t)a.n_mel_w * sizeof(float) +
+                        (size_t)a.span_len * sizeof(float);
     dim3 grid((a.T + FR - 1) / FR, B);
     hipStream_t st = (hipStream_t)stream;
+    ww_prof_scope ps_(ctx, WW_K_LOGMEL, st);
     if (wave_dtype == WW_WAVE_F32) {
         WW_HIP(hipFuncSetAttribute((const void *)k_logmel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)smem));

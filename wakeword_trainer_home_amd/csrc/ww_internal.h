@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <vector>
 #include "wwhip.h"
 
 #define WW_NFFT 1024
@@ -53,12 +54,37 @@ struct ww_feat_tables {
     float *mel_w;          // compact band weights
     float *dct;            // (n_mfcc, n_mels) or null
     int32_t max_len;
+    int32_t n_mel_w;       // number of floats in mel_w
     ww_feat_tables *next;
 };
 
+// ---- opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+enum {
+    WW_K_LOGMEL = 0, WW_K_STEM_FWD, WW_K_DW_FWD, WW_K_PW_FWD, WW_K_GAP_FWD, WW_K_HEAD_LOSS, WW_K_PW_BWD, WW_K_DW_BWD,
+    WW_K_STEM_BWD, WW_K_FINALIZE, WW_K_CLIP, WW_K_NCLASS
+};
+struct ww_prof_rec { int cls; hipEvent_t a, b; };
 struct ww_ctx {
     int device;
     ww_feat_tables *tables;
+    uint32_t prof_mask;
+    std::vector<ww_prof_rec> *prof_recs;   // recorded, not yet collected
+    std::vector<ww_prof_rec> *prof_free;   // event pairs ready for reuse
+};
+struct ww_prof_scope {   // RAII: records an event pair around the launches issued in its lifetime
+    ww_ctx *ctx; hipStream_t st; ww_prof_rec r; bool on;
+    ww_prof_scope(ww_ctx *c, int cls, hipStream_t s) : ctx(c), st(s), on(false) {
+        if (!c || !(c->prof_mask & (1u << cls))) return;
+        if (!c->prof_free->empty()) { r = c->prof_free->back(); c->prof_free->pop_back(); }
+        else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        r.cls = cls;
+        on = hipEventRecord(r.a, s) == hipSuccess;
+    }
+    ~ww_prof_scope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, st);
+        ctx->prof_recs->push_back(r);
+    }
 };
 
 int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out);

@@ -105,6 +105,7 @@ extern "C" int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64
                "Label smoothing must be in [0, 1], got %g", label_smoothing);
     WW_REQUIRE(focal_alpha >= 0.f && focal_alpha <= 1.f, WW_E_INVALID, "Alpha must be in [0, 1], got %g", focal_alpha);
     WW_REQUIRE(focal_gamma >= 0.f, WW_E_INVALID, "Gamma must be non-negative, got %g", focal_gamma);
+    ww_prof_scope ps_(ctx, WW_K_HEAD_LOSS, (hipStream_t)stream);
     hipLaunchKernelGGL(k_ce2_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, targets, B, loss_kind,
                        label_smoothing, focal_alpha, focal_gamma, loss_out, dlogits, stats);
     WW_LAUNCH_CHECK();
