@@ -35,7 +35,20 @@ ALGO_BYTES = {
     "dwconv3x3_bwd": 3 * A_ELEMS * 4,
     "conv_stem_bwd": 2 * A_ELEMS * 4,
 }
-STEP_ALGO_BYTES = 120160 + 45 * A_ELEMS * 4      # 17.63 MB / sample
+
+
+def algo_bytes(kernel, esz):
+    """fp32 figures above scale with the activation element size (features stay fp32)."""
+    b = ALGO_BYTES.get(kernel, 0)
+    if kernel == "logmel_specaug":
+        return b
+    if kernel == "conv_stem_fwd":
+        return 24160 + A_ELEMS * esz
+    return b * esz // 4
+
+
+def step_algo_bytes(esz):
+    return 120160 + 45 * A_ELEMS * esz               # BASELINE.md §3: 17.63 MB (fp32) / 8.88 MB (bf16) per sample
 
 
 def cpu_baseline(batch, seconds_budget=20.0):
@@ -81,6 +94,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=512, help="clips per GPU per step")
+    ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16",
+                    help="storage of the conv-stack activations/gradients (arithmetic is fp32 either way); "
+                         "BASELINE config 2 names bf16, f32 is the 1e-3 parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=128)
     args = ap.parse_args()
@@ -110,7 +126,9 @@ def main():
     cfg = get_preset("cnn_small_logmel40")
     cfg.training.batch_size = args.batch
     torch.manual_seed(1234)                                   # same initial weights on every rank
-    model = create_model("cnn_small", num_classes=2, pretrained=False, dropout=cfg.model.dropout)
+    model = create_model("cnn_small", num_classes=2, pretrained=False, dropout=cfg.model.dropout,
+                         act_dtype="bf16" if args.dtype == "bf16" else "fp32")
+    esz = 2 if args.dtype == "bf16" else 4
     import tempfile
     trainer = Trainer(model, [], [], cfg, checkpoint_dir=Path(tempfile.mkdtemp(prefix="wwbench_")), device=dev)
     # a few distinct synthetic batches, generated on the device, rank-specific seeds (weak scaling)
@@ -156,14 +174,15 @@ def main():
         value = total / dt
         ms, launches = prof.get(dominant, (0.0, 0))
         per_launch_s = (ms / launches) * 1e-3 if launches else float("nan")
-        algo = ALGO_BYTES.get(dominant, 0) * args.batch
+        algo = algo_bytes(dominant, esz) * args.batch
         achieved = algo / per_launch_s / 1e9 if launches else float("nan")
         out = {
             "metric": "training samples/sec (16kHz x 1.5s clips)", "value": round(value, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE config 2: cnn_small + log-mel(40) + SpecAugment, fwd/bwd + clip + AdamW, "
                                    "16 kHz x 1.5 s clips resident in HBM", "batch_per_gpu": args.batch,
+                       "activation_storage": args.dtype, "arithmetic": "f32",
                        "global_batch": args.batch * world, "n_samples": N_SAMPLES,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "last_loss": None if last is None else round(last[0], 6)},
@@ -171,7 +190,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": launches,
                          "algorithmic_bytes_per_launch": algo,
-                         "step_frac_of_hbm_roofline": round(value / world * STEP_ALGO_BYTES / (HBM_PEAK_GBS * 1e9), 4)},
+                         "step_frac_of_hbm_roofline": round(value / world * step_algo_bytes(esz) / (HBM_PEAK_GBS * 1e9), 4)},
             "kernel_ms_per_step_warmup": {k: round(v[0] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
         if not args.no_cpu_baseline:

@@ -15,8 +15,10 @@
  *   - Every launch goes to the hipStream_t passed as `stream` (void*; NULL = default
  *     stream).  No entry point synchronises the device or allocates device memory,
  *     except ww_ctx_create (uploads constant tables once).
- *   - Activations inside the conv stack are channels-last  [B][H][W][64] fp32 -- the
- *     memory format the reference trains in (src/training/trainer.py:71,165).
+ *   - Activations inside the conv stack are channels-last  [B][H][W][64] -- the memory format the
+ *     reference trains in (src/training/trainer.py:71,165) -- stored as fp32 (WW_ACT_F32, the parity
+ *     mode) or bf16 (WW_ACT_BF16; the counterpart of the reference's optimizer.mixed_precision switch,
+ *     src/training/trainer.py:92,172).  Arithmetic, statistics and parameters are always fp32.
  *   - A ww_ctx is used by one host thread at a time (the training thread).
  */
 #ifndef WWHIP_H
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 1
+#define WW_ABI_VERSION 2
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -110,24 +112,26 @@ typedef struct {
 } ww_bn_t;
 
 #define WW_C 64              /* channel width of the conv stack */
+#define WW_ACT_F32 0         /* storage type of the activation tensors y_l / g_l (void* arguments) */
+#define WW_ACT_BF16 1
 #define WW_MAX_PARTIALS 1024 /* rows of a reduction slab */
 /* scratch for one layer call: partial-sum slabs */
 size_t ww_layer_scratch_bytes(void);
 
 /* x (B,Hin,Win) f32 (C=1)  ->  y (B,Ho,Wo,64), Ho=(Hin+1)/2, Wo=(Win+1)/2 ; 3x3 s2 p1 */
-int ww_conv_stem_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int Hin, int Win, float *y,
+int ww_conv_stem_fwd(ww_ctx *ctx, int act_dtype, const float *x, const float *w, int B, int Hin, int Win, void *y,
                      const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch, ww_stream_t stream);
 /* depthwise 3x3 p1 on relu(bn(y_in)) */
-int ww_dwconv3x3_fwd(ww_ctx *ctx, const float *y_in, const float *ss_in, const float *w, int B, int H, int W,
-                     float *y, const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch,
+int ww_dwconv3x3_fwd(ww_ctx *ctx, int act_dtype, const void *y_in, const float *ss_in, const float *w, int B, int H,
+                     int W, void *y, const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch,
                      ww_stream_t stream);
 /* pointwise 1x1 (64->64) on relu(bn(y_in)); f32 MFMA */
-int ww_pwconv1x1_fwd(ww_ctx *ctx, const float *y_in, const float *ss_in, const float *w, int B, int H, int W,
-                     float *y, const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch,
+int ww_pwconv1x1_fwd(ww_ctx *ctx, int act_dtype, const void *y_in, const float *ss_in, const float *w, int B, int H,
+                     int W, void *y, const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch,
                      ww_stream_t stream);
 /* AdaptiveAvgPool2d(1) of relu(bn(y)):  pool (B,3,64) = [sum relu(z) | sum_{z>0} yhat | count_{z>0}] */
-int ww_gap_fwd(ww_ctx *ctx, const float *y, const float *ss, const float *mr, int B, int H, int W, float *pool,
-               ww_stream_t stream);
+int ww_gap_fwd(ww_ctx *ctx, int act_dtype, const void *y, const float *ss, const float *mr, int B, int H, int W,
+               float *pool, ww_stream_t stream);
 /* dropout(Philox) + nn.Linear(64,2) (classifier of cnn_small; reference head form
  * src/models/architectures.py:105-111).  pd (B,64) = dropped pooled vector (kept for bwd) */
 int ww_head_fwd(ww_ctx *ctx, const float *pool, int B, int HW, const float *fc_w, const float *fc_b,
@@ -143,16 +147,16 @@ int ww_head_bwd(ww_ctx *ctx, const float *dlogits, const float *pd, const float 
                 float *dfc_b, float *dpool, float *coef_last, float *dgamma_last, float *dbeta_last,
                 ww_stream_t stream);
 /* g == NULL -> this is the last conv layer: dz = dpool[b][c] * [z>0] (dpool carries 1/HW) */
-int ww_pwconv1x1_bwd(ww_ctx *ctx, const float *g, const float *dpool, const float *y_out, const float *ss_out,
-                     const float *coef, const float *y_in, const float *ss_in, const float *mr_in,
-                     const float *gamma_in, const float *w, int B, int H, int W, float *g_in, float *dw,
+int ww_pwconv1x1_bwd(ww_ctx *ctx, int act_dtype, const void *g, const float *dpool, const void *y_out,
+                     const float *ss_out, const float *coef, const void *y_in, const float *ss_in, const float *mr_in,
+                     const float *gamma_in, const float *w, int B, int H, int W, void *g_in, float *dw,
                      float *coef_in, float *dgamma_in, float *dbeta_in, void *scratch, ww_stream_t stream);
-int ww_dwconv3x3_bwd(ww_ctx *ctx, const float *g, const float *y_out, const float *coef, const float *y_in,
+int ww_dwconv3x3_bwd(ww_ctx *ctx, int act_dtype, const void *g, const void *y_out, const float *coef, const void *y_in,
                      const float *ss_in, const float *mr_in, const float *gamma_in, const float *w, int B,
-                     int H, int W, float *g_in, float *dw, float *coef_in, float *dgamma_in,
+                     int H, int W, void *g_in, float *dw, float *coef_in, float *dgamma_in,
                      float *dbeta_in, void *scratch, ww_stream_t stream);
-int ww_conv_stem_bwd(ww_ctx *ctx, const float *g, const float *y_out, const float *coef, const float *x, int B,
-                     int Hin, int Win, float *dw, void *scratch, ww_stream_t stream);
+int ww_conv_stem_bwd(ww_ctx *ctx, int act_dtype, const void *g, const void *y_out, const float *coef, const float *x,
+                     int B, int Hin, int Win, float *dw, void *scratch, ww_stream_t stream);
 
 /* ------------------------------------------------------------------ whole model
  * cnn_small (added to create_model, src/models/architectures.py:437):
@@ -164,12 +168,12 @@ int ww_conv_stem_bwd(ww_ctx *ctx, const float *g, const float *y_out, const floa
  *   45 classifier.weight   46 classifier.bias
  * (grads: running_* slots are ignored).                                                  */
 #define WW_CNN_SMALL_NPTR 47
-size_t ww_cnn_small_workspace_bytes(int B, int F, int T);
-int ww_cnn_small_fwd(ww_ctx *ctx, void *const *params, const float *x, int B, int F, int T, int training,
+size_t ww_cnn_small_workspace_bytes(int B, int F, int T, int act_dtype);
+int ww_cnn_small_fwd(ww_ctx *ctx, int act_dtype, void *const *params, const float *x, int B, int F, int T, int training,
                      float bn_momentum, float bn_eps, float dropout_p, uint64_t seed, uint64_t step,
                      uint64_t sample_offset, void *ws, size_t ws_bytes, float *logits, ww_stream_t stream);
 /* must follow a training-mode ww_cnn_small_fwd on the same ws/x */
-int ww_cnn_small_bwd(ww_ctx *ctx, void *const *params, void *const *grads, const float *x, const float *dlogits,
+int ww_cnn_small_bwd(ww_ctx *ctx, int act_dtype, void *const *params, void *const *grads, const float *x, const float *dlogits,
                      int B, int F, int T, float dropout_p, uint64_t seed, uint64_t step, uint64_t sample_offset,
                      void *ws, size_t ws_bytes, ww_stream_t stream);
 

@@ -13,7 +13,8 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+ACT_F32, ACT_BF16 = 0, 1
 LOSS_CE, LOSS_FOCAL = 0, 1
 WAVE_F32, WAVE_I16 = 0, 1
 CNN_SMALL_NPTR = 47
@@ -57,21 +58,21 @@ _SIGS = {
                                 _vp, _vp]),
     "ww_specaug_apply": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(SpecAugCfg), _u64, _u64, _u64, _vp, _vp]),
     "ww_layer_scratch_bytes": (_sz, []),
-    "ww_conv_stem_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
-    "ww_dwconv3x3_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
-    "ww_pwconv1x1_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
-    "ww_gap_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ww_conv_stem_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
+    "ww_dwconv3x3_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
+    "ww_pwconv1x1_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
+    "ww_gap_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ww_head_fwd": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _f, _i, _u64, _u64, _u64, _vp, _vp, _vp]),
     "ww_head_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _f, _i, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _vp]),
-    "ww_pwconv1x1_bwd": (C.c_int, [_vp] + [_vp] * 10 + [_i, _i, _i] + [_vp] * 7),
-    "ww_dwconv3x3_bwd": (C.c_int, [_vp] + [_vp] * 8 + [_i, _i, _i] + [_vp] * 7),
-    "ww_conv_stem_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "ww_cnn_small_workspace_bytes": (_sz, [_i, _i, _i]),
-    "ww_cnn_small_fwd": (C.c_int, [_vp, C.POINTER(_vp), _vp, _i, _i, _i, _i, _f, _f, _f, _u64, _u64, _u64, _vp, _sz,
+    "ww_pwconv1x1_bwd": (C.c_int, [_vp, _i] + [_vp] * 10 + [_i, _i, _i] + [_vp] * 7),
+    "ww_dwconv3x3_bwd": (C.c_int, [_vp, _i] + [_vp] * 8 + [_i, _i, _i] + [_vp] * 7),
+    "ww_conv_stem_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ww_cnn_small_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ww_cnn_small_fwd": (C.c_int, [_vp, _i, C.POINTER(_vp), _vp, _i, _i, _i, _i, _f, _f, _f, _u64, _u64, _u64, _vp, _sz,
                                    _vp, _vp]),
-    "ww_cnn_small_bwd": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i, _i, _i, _f, _u64, _u64, _u64, _vp,
-                                   _sz, _vp]),
+    "ww_cnn_small_bwd": (C.c_int, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i, _i, _i, _f, _u64, _u64, _u64,
+                                   _vp, _sz, _vp]),
     "ww_ce2_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ww_grad_norm_clip": (C.c_int, [_vp, _vp, _sz, _f, _vp, _vp]),
     "ww_prof_num_classes": (C.c_int, []),
@@ -146,6 +147,23 @@ def _dev(*tensors):
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+_ACT = {torch.float32: ACT_F32, torch.bfloat16: ACT_BF16}
+
+
+def act_code(dtype) -> int:
+    """storage type of the conv-stack activation tensors: 'fp32'/torch.float32 or 'bf16'/torch.bfloat16."""
+    if isinstance(dtype, str):
+        dtype = {"fp32": torch.float32, "f32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+                 "bfloat16": torch.bfloat16}.get(dtype.lower())
+    if dtype not in _ACT:
+        raise ValueError("activation storage must be float32 or bfloat16")
+    return _ACT[dtype]
+
+
+def act_torch_dtype(code):
+    return torch.bfloat16 if code == ACT_BF16 else torch.float32
 
 
 def _stream(dev):
@@ -227,15 +245,15 @@ def make_bn(gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, trai
     return BN(_p(gamma), _p(beta), _p(running_mean), _p(running_var), momentum, eps, 1 if training else 0)
 
 
-def conv_stem_fwd(x, w, bn: BN, scratch):
+def conv_stem_fwd(x, w, bn: BN, scratch, act=torch.float32):
     dev = _dev(x, w, scratch)
     B, Hin, Win = x.shape[0], x.shape[-2], x.shape[-1]
     Ho, Wo = (Hin + 1) // 2, (Win + 1) // 2
-    y = torch.empty((B, Ho, Wo, 64), dtype=torch.float32, device=dev)
+    y = torch.empty((B, Ho, Wo, 64), dtype=act, device=dev)
     ss = torch.empty(128, dtype=torch.float32, device=dev)
     mr = torch.empty(128, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _check(load().ww_conv_stem_fwd(ctx(dev), _p(x), _p(w), B, Hin, Win, _p(y), C.byref(bn), _p(ss), _p(mr),
+        _check(load().ww_conv_stem_fwd(ctx(dev), act_code(act), _p(x), _p(w), B, Hin, Win, _p(y), C.byref(bn), _p(ss), _p(mr),
                                        _p(scratch), _stream(dev)), "ww_conv_stem_fwd")
     return y, ss, mr
 
@@ -249,7 +267,7 @@ def _conv_fwd(name, y_in, ss_in, w, bn, scratch):
     ss = torch.empty(128, dtype=torch.float32, device=dev)
     mr = torch.empty(128, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _check(getattr(load(), name)(ctx(dev), _p(y_in), _p(ss_in), _p(w), B, H, W, _p(y), C.byref(bn), _p(ss), _p(mr),
+        _check(getattr(load(), name)(ctx(dev), act_code(y_in.dtype), _p(y_in), _p(ss_in), _p(w), B, H, W, _p(y), C.byref(bn), _p(ss), _p(mr),
                                      _p(scratch), _stream(dev)), name)
     return y, ss, mr
 
@@ -267,7 +285,8 @@ def gap_fwd(y, ss, mr):
     B, H, W, _ = y.shape
     pool = torch.empty((B, 3, 64), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _check(load().ww_gap_fwd(ctx(dev), _p(y), _p(ss), _p(mr), B, H, W, _p(pool), _stream(dev)), "ww_gap_fwd")
+        _check(load().ww_gap_fwd(ctx(dev), act_code(y.dtype), _p(y), _p(ss), _p(mr), B, H, W, _p(pool), _stream(dev)),
+               "ww_gap_fwd")
     return pool
 
 
@@ -304,7 +323,7 @@ def pwconv1x1_bwd(g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, gamma_in, w
     g_in, dw = torch.empty_like(y_in), torch.empty((64, 64), **f32)
     coef_in, dgamma, dbeta = torch.empty(192, **f32), torch.empty(64, **f32), torch.empty(64, **f32)
     with torch.cuda.device(dev):
-        _check(load().ww_pwconv1x1_bwd(ctx(dev), _p(g), _p(dpool), _p(y_out), _p(ss_out), _p(coef), _p(y_in), _p(ss_in),
+        _check(load().ww_pwconv1x1_bwd(ctx(dev), act_code(y_out.dtype), _p(g), _p(dpool), _p(y_out), _p(ss_out), _p(coef), _p(y_in), _p(ss_in),
                                        _p(mr_in), _p(gamma_in), _p(w), B, H, W, _p(g_in), _p(dw), _p(coef_in),
                                        _p(dgamma), _p(dbeta), _p(scratch), _stream(dev)), "ww_pwconv1x1_bwd")
     return g_in, dw, coef_in, dgamma, dbeta
@@ -317,7 +336,7 @@ def dwconv3x3_bwd(g, y_out, coef, y_in, ss_in, mr_in, gamma_in, w, scratch):
     g_in, dw = torch.empty_like(y_in), torch.empty((64, 1, 3, 3), **f32)
     coef_in, dgamma, dbeta = torch.empty(192, **f32), torch.empty(64, **f32), torch.empty(64, **f32)
     with torch.cuda.device(dev):
-        _check(load().ww_dwconv3x3_bwd(ctx(dev), _p(g), _p(y_out), _p(coef), _p(y_in), _p(ss_in), _p(mr_in),
+        _check(load().ww_dwconv3x3_bwd(ctx(dev), act_code(y_out.dtype), _p(g), _p(y_out), _p(coef), _p(y_in), _p(ss_in), _p(mr_in),
                                        _p(gamma_in), _p(w), B, H, W, _p(g_in), _p(dw), _p(coef_in), _p(dgamma),
                                        _p(dbeta), _p(scratch), _stream(dev)), "ww_dwconv3x3_bwd")
     return g_in, dw, coef_in, dgamma, dbeta
@@ -328,13 +347,13 @@ def conv_stem_bwd(g, y_out, coef, x, scratch):
     B, Hin, Win = x.shape[0], x.shape[-2], x.shape[-1]
     dw = torch.empty((64, 1, 3, 3), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _check(load().ww_conv_stem_bwd(ctx(dev), _p(g), _p(y_out), _p(coef), _p(x), B, Hin, Win, _p(dw), _p(scratch),
+        _check(load().ww_conv_stem_bwd(ctx(dev), act_code(y_out.dtype), _p(g), _p(y_out), _p(coef), _p(x), B, Hin, Win, _p(dw), _p(scratch),
                                        _stream(dev)), "ww_conv_stem_bwd")
     return dw
 
 
-def cnn_small_workspace_bytes(B, F, T):
-    return load().ww_cnn_small_workspace_bytes(B, F, T)
+def cnn_small_workspace_bytes(B, F, T, act=ACT_F32):
+    return load().ww_cnn_small_workspace_bytes(B, F, T, act)
 
 
 def ptr_array(tensors):
@@ -345,20 +364,20 @@ def ptr_array(tensors):
 
 
 def cnn_small_fwd(params, x, ws, logits, training, bn_momentum=0.1, bn_eps=1e-5, dropout_p=0.0, seed=0, step=0,
-                  sample_offset=0):
+                  sample_offset=0, act=ACT_F32):
     dev = _dev(x, ws, logits)
     B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
     with torch.cuda.device(dev):
-        _check(load().ww_cnn_small_fwd(ctx(dev), params, _p(x), B, F, T, int(training), bn_momentum, bn_eps, dropout_p,
+        _check(load().ww_cnn_small_fwd(ctx(dev), act, params, _p(x), B, F, T, int(training), bn_momentum, bn_eps, dropout_p,
                                        seed, step, sample_offset, _p(ws), ws.numel() * ws.element_size(), _p(logits),
                                        _stream(dev)), "ww_cnn_small_fwd")
 
 
-def cnn_small_bwd(params, grads, x, dlogits, ws, dropout_p=0.0, seed=0, step=0, sample_offset=0):
+def cnn_small_bwd(params, grads, x, dlogits, ws, dropout_p=0.0, seed=0, step=0, sample_offset=0, act=ACT_F32):
     dev = _dev(x, ws, dlogits)
     B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
     with torch.cuda.device(dev):
-        _check(load().ww_cnn_small_bwd(ctx(dev), params, grads, _p(x), _p(dlogits), B, F, T, dropout_p, seed, step,
+        _check(load().ww_cnn_small_bwd(ctx(dev), act, params, grads, _p(x), _p(dlogits), B, F, T, dropout_p, seed, step,
                                        sample_offset, _p(ws), ws.numel() * ws.element_size(), _stream(dev)),
                "ww_cnn_small_bwd")
 

@@ -1,4 +1,5 @@
-// Backward kernels of the depthwise-separable conv stack (channels-last, C = 64, fp32).
+// Backward kernels of the depthwise-separable conv stack (channels-last, C = 64).
+// y_l / g_l are stored as fp32 or bf16 (ww_act.h); arithmetic, sums and weight gradients are fp32.
 //
 // Stored tensors per layer l: y_l (PRE-BatchNorm conv output, written by forward) and
 // g_l = dL/dz_l (gradient w.r.t. the BatchNorm output, ReLU mask already applied).
@@ -12,6 +13,7 @@
 // Weight-gradient and statistic partials are per-block slabs summed in double by the
 // finalize kernels (bit-reproducible; no float atomics).
 #include "ww_internal.h"
+#include "ww_act.h"
 
 namespace {
 
@@ -20,8 +22,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int PW_LD = 68;
 
 // ------------------------------------------------------------------------------------- head
-// single block: thread = (channel c, part of 4 over the batch)
-__global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ dlogits, const float *__restrict__ pd,
+// single block: thread = (channel c, part of 16 over the batch)
+__global__ __launch_bounds__(1024) void k_head_bwd(const float *__restrict__ dlogits, const float *__restrict__ pd,
                                                   const float *__restrict__ pool, int B, int HW,
                                                   const float *__restrict__ fc_w, float drop_scale,
                                                   uint64_t drop_thresh, int use_dropout, uint32_t seed_lo,
@@ -31,12 +33,12 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ dlog
                                                   float *__restrict__ dfc_b, float *__restrict__ dpool,
                                                   float *__restrict__ coef, float *__restrict__ dgamma,
                                                   float *__restrict__ dbeta) {
-    __shared__ double sh[6][256];
+    __shared__ double sh[6][1024];
     const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
     const float w0 = fc_w[c], w1 = fc_w[64 + c];
     const float inv_hw = 1.0f / (float)HW;
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int b = part; b < B; b += 4) {
+    for (int b = part; b < B; b += 16) {
         const float dl0 = dlogits[(size_t)b * 2], dl1 = dlogits[(size_t)b * 2 + 1];
         const float pv = pd[(size_t)b * 64 + c];
         a0 += (double)dl0 * pv;
@@ -61,7 +63,12 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ dlog
     if (part == 0) {
         double t[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) t[k] = sh[k][c] + sh[k][64 + c] + sh[k][128 + c] + sh[k][192 + c];
+        for (int k = 0; k < 6; ++k) {
+            double a = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a += sh[k][64 * q + c];
+            t[k] = a;
+        }
         dfc_w[c] = (float)t[0];
         dfc_w[64 + c] = (float)t[1];
         if (c == 0) {
@@ -88,16 +95,18 @@ __global__ __launch_bounds__(256) void k_head_bwd(const float *__restrict__ dlog
 // tensors are prefetched into 48 registers while the 64 MFMAs of this tile run.
 constexpr int PWB_TILE = 64;
 
-template <bool FROM_POOL>
-__global__ __launch_bounds__(256, 2) void k_pw_bwd(const float *__restrict__ g, const float *__restrict__ dpool,
-                                                   const float *__restrict__ y_out, const float *__restrict__ ss_out,
-                                                   const float *__restrict__ coef, const float *__restrict__ y_in,
+template <typename T, bool FROM_POOL>
+__global__ __launch_bounds__(256, 2) void k_pw_bwd(const T *__restrict__ g, const float *__restrict__ dpool,
+                                                   const T *__restrict__ y_out, const float *__restrict__ ss_out,
+                                                   const float *__restrict__ coef, const T *__restrict__ y_in,
                                                    const float *__restrict__ ss_in, const float *__restrict__ mr_in,
                                                    const float *__restrict__ w, long M, int HW,
-                                                   float *__restrict__ g_in, float *__restrict__ stat_partials,
+                                                   T *__restrict__ g_in, float *__restrict__ stat_partials,
                                                    float *__restrict__ dw_partials) {
-    __shared__ __align__(16) float lds[2 * PWB_TILE * PW_LD];
+    __shared__ __align__(16) float lds[(Act<T>::is_f32 ? 2 : 3) * PWB_TILE * PW_LD];
     float *dyt = lds, *yit = lds + PWB_TILE * PW_LD;
+    float *otile = lds + 2 * PWB_TILE * PW_LD;     // bf16 only: g_in staged for packed stores
+    typedef typename Act<T>::raw4 raw4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int rh = wv >> 1, n = wv & 1;   // dX role; also (jt, kt) = (rh, n) for the dW role
@@ -122,15 +131,15 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const float *__restrict__ g, 
 
     const long ntiles = (M + PWB_TILE - 1) / PWB_TILE;
     // software pipeline (see k_pw_fwd): next tile's g / y_out / y_in loads fly during this tile's MFMAs
-    float4 rg[4], ro[4], ri[4];
+    raw4 rg[4], ro[4], ri[4];
     auto issue = [&](long ti) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             long p = ti * PWB_TILE + (tid >> 4) + 16 * i;
             p = p < M ? p : M - 1;                       // clamped, branch-free; masked when consumed
-            ro[i] = *reinterpret_cast<const float4 *>(y_out + (size_t)p * 64 + 4 * c4);
-            ri[i] = *reinterpret_cast<const float4 *>(y_in + (size_t)p * 64 + 4 * c4);
-            if (!FROM_POOL) rg[i] = *reinterpret_cast<const float4 *>(g + (size_t)p * 64 + 4 * c4);
+            ro[i] = Act<T>::ldraw4(y_out + (size_t)p * 64 + 4 * c4);
+            ri[i] = Act<T>::ldraw4(y_in + (size_t)p * 64 + 4 * c4);
+            if (!FROM_POOL) rg[i] = Act<T>::ldraw4(g + (size_t)p * 64 + 4 * c4);
         }
     };
     if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
@@ -141,7 +150,8 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const float *__restrict__ g, 
             const int row = (tid >> 4) + 16 * i;
             const long p = p0 + row;
             const bool ok = p < M;
-            const float4 yo = ro[i];
+            const float4 yo = Act<T>::cvt4(ro[i]);
+            const float4 yr = Act<T>::cvt4(ri[i]);
             float4 dz;
             if (FROM_POOL) {
                 const float4 dp = *reinterpret_cast<const float4 *>(dpool + (size_t)((ok ? p : M - 1) / HW) * 64 + 4 * c4);
@@ -150,14 +160,14 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const float *__restrict__ g, 
                 dz.z = fmaf(yo.z, so.z, to.z) > 0.f ? dp.z : 0.f;
                 dz.w = fmaf(yo.w, so.w, to.w) > 0.f ? dp.w : 0.f;
             } else {
-                dz = rg[i];
+                dz = Act<T>::cvt4(rg[i]);
             }
             float4 dy, yi;
             dy.x = ok ? fmaf(cA.x, dz.x, fmaf(cB.x, yo.x, cC.x)) : 0.f;
             dy.y = ok ? fmaf(cA.y, dz.y, fmaf(cB.y, yo.y, cC.y)) : 0.f;
             dy.z = ok ? fmaf(cA.z, dz.z, fmaf(cB.z, yo.z, cC.z)) : 0.f;
             dy.w = ok ? fmaf(cA.w, dz.w, fmaf(cB.w, yo.w, cC.w)) : 0.f;
-            yi.x = ok ? ri[i].x : 0.f; yi.y = ok ? ri[i].y : 0.f; yi.z = ok ? ri[i].z : 0.f; yi.w = ok ? ri[i].w : 0.f;
+            yi.x = ok ? yr.x : 0.f; yi.y = ok ? yr.y : 0.f; yi.z = ok ? yr.z : 0.f; yi.w = ok ? yr.w : 0.f;
             *reinterpret_cast<float4 *>(dyt + row * PW_LD + 4 * c4) = dy;   // rows past M: dy = 0, y_in = 0
             *reinterpret_cast<float4 *>(yit + row * PW_LD + 4 * c4) = yi;
         }
@@ -180,8 +190,12 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const float *__restrict__ g, 
                 const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 const long p = p0 + prow;
                 const float yv = yit[prow * PW_LD + 32 * n + r];
-                const float d = fmaf(yv, sci, sfi) > 0.f ? acc[reg] : 0.f;
-                if (p < M) g_in[(size_t)p * 64 + 32 * n + r] = d;
+                const float d = Act<T>::round1(fmaf(yv, sci, sfi) > 0.f ? acc[reg] : 0.f);
+                if constexpr (Act<T>::is_f32) {
+                    if (p < M) g_in[(size_t)p * 64 + 32 * n + r] = d;
+                } else {
+                    otile[prow * PW_LD + 32 * n + r] = d;
+                }
                 st1 += d;
                 st2 = fmaf(d, (yv - mui) * rsi, st2);
             }
@@ -195,10 +209,21 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const float *__restrict__ g, 
             dwacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dyv, av, dwacc, 0, 0, 0);
         }
         __syncthreads();
+        if constexpr (!Act<T>::is_f32) {
+            // packed 8-byte stores of g_in; otile is rewritten only after the next tile's first barrier
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (tid >> 4) + 16 * i;
+                if (p0 + row < M)
+                    Act<T>::st4(g_in + (size_t)(p0 + row) * 64 + 4 * c4,
+                                *reinterpret_cast<const float4 *>(otile + row * PW_LD + 4 * c4));
+            }
+        }
     }
     // ---- block partials: statistics (sum over the two row-halves), dW quadrant straight from registers
     st1 += __shfl_xor(st1, 32);
     st2 += __shfl_xor(st2, 32);
+    __syncthreads();
     float *shs = lds;  // [wave][kind][32]
     if (h == 0) {
         shs[wv * 64 + r] = st1;
@@ -224,41 +249,49 @@ struct DwGeom {
 
 constexpr int DW_HS = 10;   // max rows per strip segment (matches ww_conv_fwd.hip)
 
-__device__ __forceinline__ void dwb_issue(const float *__restrict__ gimg, const float *__restrict__ yimg, int h, int w0,
-                                          int H, int W, int cl, float2 (&rg)[6], float2 (&ry)[6]) {
+template <typename T>
+__device__ __forceinline__ void dwb_issue(const T *__restrict__ gimg, const T *__restrict__ yimg, int h, int w0, int H,
+                                          int W, int cl, typename Act<T>::raw2 (&rg)[6],
+                                          typename Act<T>::raw2 (&ry)[6]) {
     const int hh = min(max(h, 0), H - 1);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int wc = min(max(w0 - 1 + i, 0), W - 1);
         const size_t o = ((size_t)hh * W + wc) * 64 + 2 * cl;
-        rg[i] = *reinterpret_cast<const float2 *>(gimg + o);
-        ry[i] = *reinterpret_cast<const float2 *>(yimg + o);
+        rg[i] = Act<T>::ldraw2(gimg + o);
+        ry[i] = Act<T>::ldraw2(yimg + o);
     }
 }
 // dy = A*g + Bc*y + Cc inside the image, 0 outside (zero padding of the transposed conv)
-__device__ __forceinline__ void dwb_finish(const float2 (&rg)[6], const float2 (&ry)[6], int h, int w0, int H, int W,
-                                           float2 cA, float2 cB, float2 cC, float2 (&r)[6]) {
+template <typename T>
+__device__ __forceinline__ void dwb_finish(const typename Act<T>::raw2 (&rg)[6], const typename Act<T>::raw2 (&ry)[6],
+                                           int h, int w0, int H, int W, float2 cA, float2 cB, float2 cC,
+                                           float2 (&r)[6]) {
     const bool hv = (h >= 0) && (h < H);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int wc = w0 - 1 + i;
         const bool ok = hv && wc >= 0 && wc < W;
-        r[i].x = ok ? fmaf(cA.x, rg[i].x, fmaf(cB.x, ry[i].x, cC.x)) : 0.f;
-        r[i].y = ok ? fmaf(cA.y, rg[i].y, fmaf(cB.y, ry[i].y, cC.y)) : 0.f;
+        const float2 gv = Act<T>::cvt2(rg[i]), yv = Act<T>::cvt2(ry[i]);
+        r[i].x = ok ? fmaf(cA.x, gv.x, fmaf(cB.x, yv.x, cC.x)) : 0.f;
+        r[i].y = ok ? fmaf(cA.y, gv.y, fmaf(cB.y, yv.y, cC.y)) : 0.f;
     }
 }
-__device__ __forceinline__ void dwb_issue_centre(const float *__restrict__ yin_img, int h, int w0, int H, int W, int cl,
-                                                 float2 (&rc)[4]) {
+template <typename T>
+__device__ __forceinline__ void dwb_issue_centre(const T *__restrict__ yin_img, int h, int w0, int H, int W, int cl,
+                                                 typename Act<T>::raw2 (&rc)[4]) {
     const int hh = min(max(h, 0), H - 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int wc = min(w0 + i, W - 1);
-        rc[i] = *reinterpret_cast<const float2 *>(yin_img + ((size_t)hh * W + wc) * 64 + 2 * cl);
+        rc[i] = Act<T>::ldraw2(yin_img + ((size_t)hh * W + wc) * 64 + 2 * cl);
     }
 }
 
 // centre row h:  rs0 = dy[h+1] (pairs with weight row 0), rs1 = dy[h], rs2 = dy[h-1]; yc = y_in[h][w0..w0+3]
-__device__ __forceinline__ void dwb_row(const float2 (&yc)[4], float *__restrict__ gin_img, int h, int w0, int W, int cl,
+template <typename T>
+__device__ __forceinline__ void dwb_row(const typename Act<T>::raw2 (&yc)[4], T *__restrict__ gin_img, int h, int w0,
+                                        int W, int cl,
                                         const float2 (&rs0)[6], const float2 (&rs1)[6], const float2 (&rs2)[6],
                                         const float (&wa)[9], const float (&wb)[9], float2 sc, float2 sf, float2 mu,
                                         float2 rsd, float (&dwa)[9], float (&dwb)[9], float &s1a, float &s1b, float &s2a,
@@ -266,7 +299,7 @@ __device__ __forceinline__ void dwb_row(const float2 (&yc)[4], float *__restrict
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (w0 + i < W) {
-            const float2 yv = yc[i];
+            const float2 yv = Act<T>::cvt2(yc[i]);
             const float z0 = fmaf(yv.x, sc.x, sf.x), z1 = fmaf(yv.y, sc.y, sf.y);
             const float a0 = fmaxf(z0, 0.f), a1 = fmaxf(z1, 0.f);
             float d0 = 0.f, d1 = 0.f;
@@ -280,8 +313,9 @@ __device__ __forceinline__ void dwb_row(const float2 (&yc)[4], float *__restrict
                 dwa[3 + kw] = fmaf(a0, t1.x, dwa[3 + kw]); dwb[3 + kw] = fmaf(a1, t1.y, dwb[3 + kw]);
                 dwa[6 + kw] = fmaf(a0, t2.x, dwa[6 + kw]); dwb[6 + kw] = fmaf(a1, t2.y, dwb[6 + kw]);
             }
-            const float g0 = z0 > 0.f ? d0 : 0.f, g1 = z1 > 0.f ? d1 : 0.f;
-            *reinterpret_cast<float2 *>(gin_img + ((size_t)h * W + w0 + i) * 64 + 2 * cl) = make_float2(g0, g1);
+            const float2 go = Act<T>::round2(make_float2(z0 > 0.f ? d0 : 0.f, z1 > 0.f ? d1 : 0.f));
+            const float g0 = go.x, g1 = go.y;
+            Act<T>::st2(gin_img + ((size_t)h * W + w0 + i) * 64 + 2 * cl, go);
             s1a += g0; s1b += g1;
             s2a = fmaf(g0, (yv.x - mu.x) * rsd.x, s2a);
             s2b = fmaf(g1, (yv.y - mu.y) * rsd.y, s2b);
@@ -289,12 +323,14 @@ __device__ __forceinline__ void dwb_row(const float2 (&yc)[4], float *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_dw_bwd(const float *__restrict__ g, const float *__restrict__ y_out,
-                                                const float *__restrict__ coef, const float *__restrict__ y_in,
+template <typename T>
+__global__ __launch_bounds__(256) void k_dw_bwd(const T *__restrict__ g, const T *__restrict__ y_out,
+                                                const float *__restrict__ coef, const T *__restrict__ y_in,
                                                 const float *__restrict__ ss_in, const float *__restrict__ mr_in,
-                                                const float *__restrict__ w, DwGeom gm, float *__restrict__ g_in,
+                                                const float *__restrict__ w, DwGeom gm, T *__restrict__ g_in,
                                                 float *__restrict__ stat_partials, float *__restrict__ dw_partials) {
     __shared__ float sh[8 * 576];
+    typedef typename Act<T>::raw2 raw2;
     const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
     float wa[9], wb[9], dwa[9], dwb[9];
 #pragma unroll
@@ -319,19 +355,20 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const float *__restrict__ g, con
         const int seg = (int)(t % gm.nseg), b = (int)(t / gm.nseg);
         const int w0 = cs * 4, hs = seg * gm.hs_len;
         const int he = min(gm.H, hs + gm.hs_len);
-        const float *gimg = g + (size_t)b * img_stride;
-        const float *yoimg = y_out + (size_t)b * img_stride;
-        const float *yiimg = y_in + (size_t)b * img_stride;
-        float *giimg = g_in + (size_t)b * img_stride;
+        const T *gimg = g + (size_t)b * img_stride;
+        const T *yoimg = y_out + (size_t)b * img_stride;
+        const T *yiimg = y_in + (size_t)b * img_stride;
+        T *giimg = g_in + (size_t)b * img_stride;
         // rows[i%3] = dy[h-1], rows[(i+1)%3] = dy[h], rows[(i+2)%3] = dy[h+1]; raw dy row h+2 and the raw centre row
         // h+1 are in flight while row h is processed
-        float2 rows[3][6], rg[6], ry[6], ag[6], ay[6], yc[4], ayc[4];
-        dwb_issue(gimg, yoimg, hs - 1, w0, gm.H, gm.W, cl, rg, ry);
-        dwb_finish(rg, ry, hs - 1, w0, gm.H, gm.W, cA, cB, cC, rows[0]);
-        dwb_issue(gimg, yoimg, hs, w0, gm.H, gm.W, cl, rg, ry);
-        dwb_finish(rg, ry, hs, w0, gm.H, gm.W, cA, cB, cC, rows[1]);
-        dwb_issue(gimg, yoimg, hs + 1, w0, gm.H, gm.W, cl, ag, ay);
-        dwb_issue_centre(yiimg, hs, w0, gm.H, gm.W, cl, ayc);
+        float2 rows[3][6];
+        raw2 rg[6], ry[6], ag[6], ay[6], yc[4], ayc[4];
+        dwb_issue<T>(gimg, yoimg, hs - 1, w0, gm.H, gm.W, cl, rg, ry);
+        dwb_finish<T>(rg, ry, hs - 1, w0, gm.H, gm.W, cA, cB, cC, rows[0]);
+        dwb_issue<T>(gimg, yoimg, hs, w0, gm.H, gm.W, cl, rg, ry);
+        dwb_finish<T>(rg, ry, hs, w0, gm.H, gm.W, cA, cB, cC, rows[1]);
+        dwb_issue<T>(gimg, yoimg, hs + 1, w0, gm.H, gm.W, cl, ag, ay);
+        dwb_issue_centre<T>(yiimg, hs, w0, gm.H, gm.W, cl, ayc);
 #pragma unroll
         for (int i = 0; i < DW_HS; ++i) {
             const int h = hs + i;
@@ -341,11 +378,11 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const float *__restrict__ g, con
 #pragma unroll
                 for (int c = 0; c < 4; ++c) yc[c] = ayc[c];
                 if (i + 1 < DW_HS) {
-                    dwb_issue(gimg, yoimg, h + 2, w0, gm.H, gm.W, cl, ag, ay);
-                    dwb_issue_centre(yiimg, h + 1, w0, gm.H, gm.W, cl, ayc);
+                    dwb_issue<T>(gimg, yoimg, h + 2, w0, gm.H, gm.W, cl, ag, ay);
+                    dwb_issue_centre<T>(yiimg, h + 1, w0, gm.H, gm.W, cl, ayc);
                 }
-                dwb_finish(rg, ry, h + 1, w0, gm.H, gm.W, cA, cB, cC, rows[(i + 2) % 3]);
-                dwb_row(yc, giimg, h, w0, gm.W, cl, rows[(i + 2) % 3], rows[(i + 1) % 3], rows[i % 3], wa, wb, sc, sf, mu,
+                dwb_finish<T>(rg, ry, h + 1, w0, gm.H, gm.W, cA, cB, cC, rows[(i + 2) % 3]);
+                dwb_row<T>(yc, giimg, h, w0, gm.W, cl, rows[(i + 2) % 3], rows[(i + 1) % 3], rows[i % 3], wa, wb, sc, sf, mu,
                         rsd, dwa, dwb, s1a, s1b, s2a, s2b);
             }
         }
@@ -377,7 +414,8 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const float *__restrict__ g, con
 }
 
 // ------------------------------------------------------------------------------------- stem
-__global__ __launch_bounds__(256) void k_stem_bwd(const float *__restrict__ g, const float *__restrict__ y_out,
+template <typename T>
+__global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const T *__restrict__ y_out,
                                                   const float *__restrict__ coef, const float *__restrict__ x, int B,
                                                   int Hin, int Win, int Ho, int Wo, float *__restrict__ dw_partials) {
     __shared__ float sh[8 * 576];
@@ -394,8 +432,8 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const float *__restrict__ g, c
         const float *xb = x + (size_t)b * Hin * Win;
         for (int ow = slot; ow < Wo; ow += 8) {
             const size_t o = ((size_t)row * Wo + ow) * 64 + 2 * cl;
-            const float2 gz = *reinterpret_cast<const float2 *>(g + o);
-            const float2 yo = *reinterpret_cast<const float2 *>(y_out + o);
+            const float2 gz = Act<T>::cvt2(Act<T>::ldraw2(g + o));
+            const float2 yo = Act<T>::cvt2(Act<T>::ldraw2(y_out + o));
             const float d0 = fmaf(cA.x, gz.x, fmaf(cB.x, yo.x, cC.x));
             const float d1 = fmaf(cA.y, gz.y, fmaf(cB.y, yo.y, cC.y));
 #pragma unroll
@@ -440,7 +478,7 @@ extern "C" int ww_head_bwd(ww_ctx *ctx, const float *dlogits, const float *pd, c
     const int use_dropout = training && dropout_p > 0.f;
     const float scale = (float)(1.0 / (1.0 - (double)dropout_p));
     ww_prof_scope ps_(ctx, WW_K_HEAD_LOSS, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_head_bwd, dim3(1), dim3(256), 0, (hipStream_t)stream, dlogits, pd, pool, B, HW, fc_w, scale,
+    hipLaunchKernelGGL(k_head_bwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, dlogits, pd, pool, B, HW, fc_w, scale,
                        ww_prob_threshold((double)dropout_p), use_dropout, (uint32_t)seed, (uint32_t)(seed >> 32),
                        (uint32_t)step, (uint32_t)(step >> 32), sample_offset, gamma_last, mr_last, dfc_w, dfc_b, dpool,
                        coef_last, dgamma_last, dbeta_last);
@@ -448,80 +486,132 @@ extern "C" int ww_head_bwd(ww_ctx *ctx, const float *dlogits, const float *pd, c
     return WW_OK;
 }
 
-extern "C" int ww_pwconv1x1_bwd(ww_ctx *ctx, const float *g, const float *dpool, const float *y_out,
-                                const float *ss_out, const float *coef, const float *y_in, const float *ss_in,
+namespace {
+int check_act_b(const char *who, int act_dtype) {
+    WW_REQUIRE(act_dtype == WW_ACT_F32 || act_dtype == WW_ACT_BF16, WW_E_INVALID, "%s: unknown act_dtype %d", who,
+               act_dtype);
+    return WW_OK;
+}
+
+template <typename T>
+int launch_pw_bwd(ww_ctx *ctx, const void *g, const float *dpool, const void *y_out, const float *ss_out,
+                  const float *coef, const void *y_in, const float *ss_in, const float *mr_in, const float *w, long M,
+                  int HW, void *g_in, float *stat, float *dwp, int *grid_out, hipStream_t st) {
+    const long ntiles = (M + PWB_TILE - 1) / PWB_TILE;
+    int grid;
+    ww_prof_scope ps_(ctx, WW_K_PW_BWD, st);
+    if (g) {
+        grid = ww_occupancy_grid((const void *)k_pw_bwd<T, false>, 256, 0, ntiles, WW_DW_SLAB_ROWS);
+        hipLaunchKernelGGL((k_pw_bwd<T, false>), dim3(grid), dim3(256), 0, st, (const T *)g, dpool, (const T *)y_out,
+                           ss_out, coef, (const T *)y_in, ss_in, mr_in, w, M, HW, (T *)g_in, stat, dwp);
+    } else {
+        grid = ww_occupancy_grid((const void *)k_pw_bwd<T, true>, 256, 0, ntiles, WW_DW_SLAB_ROWS);
+        hipLaunchKernelGGL((k_pw_bwd<T, true>), dim3(grid), dim3(256), 0, st, (const T *)g, dpool, (const T *)y_out,
+                           ss_out, coef, (const T *)y_in, ss_in, mr_in, w, M, HW, (T *)g_in, stat, dwp);
+    }
+    *grid_out = grid;
+    return WW_OK;
+}
+
+template <typename T>
+int launch_dw_bwd(ww_ctx *ctx, const void *g, const void *y_out, const float *coef, const void *y_in,
+                  const float *ss_in, const float *mr_in, const float *w, const DwGeom &gm, void *g_in, float *stat,
+                  float *dwp, int *grid_out, hipStream_t st) {
+    const long nblk = (gm.items + 7) / 8;
+    const int grid = ww_occupancy_grid((const void *)k_dw_bwd<T>, 256, 0, nblk, WW_MAX_PARTIALS);
+    ww_prof_scope ps_(ctx, WW_K_DW_BWD, st);
+    hipLaunchKernelGGL(k_dw_bwd<T>, dim3(grid), dim3(256), 0, st, (const T *)g, (const T *)y_out, coef, (const T *)y_in,
+                       ss_in, mr_in, w, gm, (T *)g_in, stat, dwp);
+    *grid_out = grid;
+    return WW_OK;
+}
+
+template <typename T>
+int launch_stem_bwd(ww_ctx *ctx, const void *g, const void *y_out, const float *coef, const float *x, int B, int Hin,
+                    int Win, float *dwp, int *grid_out, hipStream_t st) {
+    const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
+    const long nrows = (long)B * Ho;
+    const int grid = ww_occupancy_grid((const void *)k_stem_bwd<T>, 256, 0, nrows, WW_MAX_PARTIALS);
+    ww_prof_scope ps_(ctx, WW_K_STEM_BWD, st);
+    hipLaunchKernelGGL(k_stem_bwd<T>, dim3(grid), dim3(256), 0, st, (const T *)g, (const T *)y_out, coef, x, B, Hin, Win,
+                       Ho, Wo, dwp);
+    *grid_out = grid;
+    return WW_OK;
+}
+}  // namespace
+
+extern "C" int ww_pwconv1x1_bwd(ww_ctx *ctx, int act_dtype, const void *g, const float *dpool, const void *y_out,
+                                const float *ss_out, const float *coef, const void *y_in, const float *ss_in,
                                 const float *mr_in, const float *gamma_in, const float *w, int B, int H, int W,
-                                float *g_in, float *dw, float *coef_in, float *dgamma_in, float *dbeta_in,
+                                void *g_in, float *dw, float *coef_in, float *dgamma_in, float *dbeta_in,
                                 void *scratch, ww_stream_t stream) {
     WW_REQUIRE(ctx && y_out && coef && y_in && ss_in && mr_in && gamma_in && w && g_in && dw && coef_in && dgamma_in &&
                    dbeta_in && scratch,
                WW_E_INVALID, "ww_pwconv1x1_bwd: null argument");
     WW_REQUIRE(g || (dpool && ss_out), WW_E_INVALID, "ww_pwconv1x1_bwd: need g, or dpool + ss_out for the last layer");
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_pwconv1x1_bwd: bad shape (%d,%d,%d)", B, H, W);
+    int rc = check_act_b("ww_pwconv1x1_bwd", act_dtype);
+    if (rc) return rc;
     const long M = (long)B * H * W;
-    const long ntiles = (M + PWB_TILE - 1) / PWB_TILE;
-    const size_t smem = 0;   // static LDS
     hipStream_t st = (hipStream_t)stream;
     float *stat = (float *)scratch, *dwp = stat + WW_STAT_SLAB_FLOATS;
-    int grid;
-    {
-    ww_prof_scope ps_(ctx, WW_K_PW_BWD, st);
-    if (g) {
-        grid = ww_occupancy_grid((const void *)k_pw_bwd<false>, 256, smem, ntiles, WW_DW_SLAB_ROWS);
-        hipLaunchKernelGGL(k_pw_bwd<false>, dim3(grid), dim3(256), smem, st, g, dpool, y_out, ss_out, coef, y_in, ss_in,
-                           mr_in, w, M, H * W, g_in, stat, dwp);
-    } else {
-        grid = ww_occupancy_grid((const void *)k_pw_bwd<true>, 256, smem, ntiles, WW_DW_SLAB_ROWS);
-        hipLaunchKernelGGL(k_pw_bwd<true>, dim3(grid), dim3(256), smem, st, g, dpool, y_out, ss_out, coef, y_in, ss_in,
-                           mr_in, w, M, H * W, g_in, stat, dwp);
-    }
-    }
+    int grid = 0;
+    rc = act_dtype == WW_ACT_BF16
+             ? launch_pw_bwd<ww_bf16>(ctx, g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, w, M, H * W, g_in, stat, dwp,
+                                      &grid, st)
+             : launch_pw_bwd<float>(ctx, g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, w, M, H * W, g_in, stat, dwp,
+                                    &grid, st);
+    if (rc) return rc;
     WW_LAUNCH_CHECK();
     ww_prof_scope pf_(ctx, WW_K_FINALIZE, st);
-    int rc = ww_launch_bn_bwd_finalize(stat, grid, (double)M, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, st);
+    rc = ww_launch_bn_bwd_finalize(stat, grid, (double)M, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, st);
     if (rc) return rc;
     return ww_launch_colsum(dwp, grid, 4096, dw, st);
 }
 
-extern "C" int ww_dwconv3x3_bwd(ww_ctx *ctx, const float *g, const float *y_out, const float *coef, const float *y_in,
-                                const float *ss_in, const float *mr_in, const float *gamma_in, const float *w, int B,
-                                int H, int W, float *g_in, float *dw, float *coef_in, float *dgamma_in,
-                                float *dbeta_in, void *scratch, ww_stream_t stream) {
+extern "C" int ww_dwconv3x3_bwd(ww_ctx *ctx, int act_dtype, const void *g, const void *y_out, const float *coef,
+                                const void *y_in, const float *ss_in, const float *mr_in, const float *gamma_in,
+                                const float *w, int B, int H, int W, void *g_in, float *dw, float *coef_in,
+                                float *dgamma_in, float *dbeta_in, void *scratch, ww_stream_t stream) {
     WW_REQUIRE(ctx && g && y_out && coef && y_in && ss_in && mr_in && gamma_in && w && g_in && dw && coef_in &&
                    dgamma_in && dbeta_in && scratch,
                WW_E_INVALID, "ww_dwconv3x3_bwd: null argument");
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_dwconv3x3_bwd: bad shape (%d,%d,%d)", B, H, W);
+    int rc = check_act_b("ww_dwconv3x3_bwd", act_dtype);
+    if (rc) return rc;
     DwGeom gm;
     gm.B = B; gm.H = H; gm.W = W;
     gm.ncs = (W + 3) / 4;
     gm.nseg = (H + DW_HS - 1) / DW_HS;
     gm.hs_len = (H + gm.nseg - 1) / gm.nseg;   // <= DW_HS
     gm.items = (long)B * gm.nseg * gm.ncs;
-    const long nblk = (gm.items + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
     float *stat = (float *)scratch, *dwp = stat + WW_STAT_SLAB_FLOATS;
-    const int grid = ww_occupancy_grid((const void *)k_dw_bwd, 256, 0, nblk, WW_MAX_PARTIALS);
-    { ww_prof_scope ps_(ctx, WW_K_DW_BWD, st);
-      hipLaunchKernelGGL(k_dw_bwd, dim3(grid), dim3(256), 0, st, g, y_out, coef, y_in, ss_in, mr_in, w, gm, g_in, stat,
-                         dwp); }
+    int grid = 0;
+    rc = act_dtype == WW_ACT_BF16
+             ? launch_dw_bwd<ww_bf16>(ctx, g, y_out, coef, y_in, ss_in, mr_in, w, gm, g_in, stat, dwp, &grid, st)
+             : launch_dw_bwd<float>(ctx, g, y_out, coef, y_in, ss_in, mr_in, w, gm, g_in, stat, dwp, &grid, st);
+    if (rc) return rc;
     WW_LAUNCH_CHECK();
     ww_prof_scope pf_(ctx, WW_K_FINALIZE, st);
-    int rc = ww_launch_bn_bwd_finalize(stat, grid, (double)B * H * W, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, st);
+    rc = ww_launch_bn_bwd_finalize(stat, grid, (double)B * H * W, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, st);
     if (rc) return rc;
     return ww_launch_colsum(dwp, grid, 576, dw, st);
 }
 
-extern "C" int ww_conv_stem_bwd(ww_ctx *ctx, const float *g, const float *y_out, const float *coef, const float *x,
-                                int B, int Hin, int Win, float *dw, void *scratch, ww_stream_t stream) {
+extern "C" int ww_conv_stem_bwd(ww_ctx *ctx, int act_dtype, const void *g, const void *y_out, const float *coef,
+                                const float *x, int B, int Hin, int Win, float *dw, void *scratch,
+                                ww_stream_t stream) {
     WW_REQUIRE(ctx && g && y_out && coef && x && dw && scratch, WW_E_INVALID, "ww_conv_stem_bwd: null argument");
     WW_REQUIRE(B >= 1 && Hin >= 1 && Win >= 1, WW_E_INVALID, "ww_conv_stem_bwd: bad shape (%d,%d,%d)", B, Hin, Win);
-    const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
-    const long nrows = (long)B * Ho;
+    int rc = check_act_b("ww_conv_stem_bwd", act_dtype);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     float *dwp = (float *)scratch + WW_STAT_SLAB_FLOATS;
-    const int grid = ww_occupancy_grid((const void *)k_stem_bwd, 256, 0, nrows, WW_MAX_PARTIALS);
-    { ww_prof_scope ps_(ctx, WW_K_STEM_BWD, st);
-      hipLaunchKernelGGL(k_stem_bwd, dim3(grid), dim3(256), 0, st, g, y_out, coef, x, B, Hin, Win, Ho, Wo, dwp); }
+    int grid = 0;
+    rc = act_dtype == WW_ACT_BF16 ? launch_stem_bwd<ww_bf16>(ctx, g, y_out, coef, x, B, Hin, Win, dwp, &grid, st)
+                                  : launch_stem_bwd<float>(ctx, g, y_out, coef, x, B, Hin, Win, dwp, &grid, st);
+    if (rc) return rc;
     WW_LAUNCH_CHECK();
     ww_prof_scope pf_(ctx, WW_K_FINALIZE, st);
     return ww_launch_colsum(dwp, grid, 576, dw, st);

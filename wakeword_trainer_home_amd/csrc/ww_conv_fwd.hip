@@ -1,4 +1,5 @@
-// Forward kernels of the depthwise-separable conv stack (channels-last, C = 64, fp32).
+// Forward kernels of the depthwise-separable conv stack (channels-last, C = 64).
+// Activation tensors y_l are stored as fp32 (parity mode) or bf16 (ww_act.h); arithmetic is fp32.
 //
 // Every conv kernel (a) applies the PRODUCER layer's BatchNorm+ReLU while loading (scale/shift
 // per channel), (b) writes its own PRE-BatchNorm output once, and (c) accumulates the
@@ -18,6 +19,7 @@
 //                            (272-byte padded rows) -> conflict-free ds_read_b128 fragments; the
 //                            64x64 weight lives in 64 VGPRs per lane for the whole kernel.
 #include "ww_internal.h"
+#include "ww_act.h"
 
 namespace {
 
@@ -46,8 +48,9 @@ __device__ __forceinline__ void reduce_stats_slots(float s0, float s1, float q0,
 
 // ------------------------------------------------------------------------------------- stem
 // x (B,Hin,Win) -> y (B,Ho,Wo,64) ; 3x3 stride 2 pad 1 ; one (b,oh) output row per iteration
+template <typename T>
 __global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ x, const float *__restrict__ w, int B,
-                                                  int Hin, int Win, int Ho, int Wo, float *__restrict__ y,
+                                                  int Hin, int Win, int Ho, int Wo, T *__restrict__ y,
                                                   float *__restrict__ partials) {
     __shared__ float sh[8 * 128];
     const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
@@ -75,9 +78,10 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ x, c
                     a1 = fmaf(v, w1[kh * 3 + kw], a1);
                 }
             }
-            *reinterpret_cast<float2 *>(y + ((size_t)row * Wo + ow) * 64 + 2 * cl) = make_float2(a0, a1);
-            s0 += a0; s1 += a1;
-            q0 = fmaf(a0, a0, q0); q1 = fmaf(a1, a1, q1);
+            const float2 o = Act<T>::round2(make_float2(a0, a1));
+            Act<T>::st2(y + ((size_t)row * Wo + ow) * 64 + 2 * cl, o);
+            s0 += o.x; s1 += o.y;
+            q0 = fmaf(o.x, o.x, q0); q1 = fmaf(o.y, o.y, q1);
         }
     }
     if (partials) reduce_stats_slots(s0, s1, q0, q1, sh, partials + (size_t)blockIdx.x * 128);
@@ -92,29 +96,33 @@ struct DwGeom {
 constexpr int DW_HS = 10;   // max rows per strip segment (compile-time so the row loop fully unrolls)
 
 // raw (pre-BatchNorm) row of 6 pixels around the strip; addresses are clamped so the loads are branch-free
-__device__ __forceinline__ void dw_issue_row(const float *__restrict__ img, int h, int w0, int H, int W, int cl,
-                                             float2 (&raw)[6]) {
+template <typename T>
+__device__ __forceinline__ void dw_issue_row(const T *__restrict__ img, int h, int w0, int H, int W, int cl,
+                                             typename Act<T>::raw2 (&raw)[6]) {
     const int hh = min(max(h, 0), H - 1);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int wc = min(max(w0 - 1 + i, 0), W - 1);
-        raw[i] = *reinterpret_cast<const float2 *>(img + ((size_t)hh * W + wc) * 64 + 2 * cl);
+        raw[i] = Act<T>::ldraw2(img + ((size_t)hh * W + wc) * 64 + 2 * cl);
     }
 }
 // BatchNorm+ReLU of a raw row; positions outside the image are the conv's zero padding (in activation space)
-__device__ __forceinline__ void dw_finish_row(const float2 (&raw)[6], int h, int w0, int H, int W, float2 sc, float2 sf,
-                                              float2 (&r)[6]) {
+template <typename T>
+__device__ __forceinline__ void dw_finish_row(const typename Act<T>::raw2 (&raw)[6], int h, int w0, int H, int W,
+                                              float2 sc, float2 sf, float2 (&r)[6]) {
     const bool hv = (h >= 0) && (h < H);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int wc = w0 - 1 + i;
         const bool ok = hv && wc >= 0 && wc < W;
-        r[i].x = ok ? bnrelu(raw[i].x, sc.x, sf.x) : 0.f;
-        r[i].y = ok ? bnrelu(raw[i].y, sc.y, sf.y) : 0.f;
+        const float2 v = Act<T>::cvt2(raw[i]);
+        r[i].x = ok ? bnrelu(v.x, sc.x, sf.x) : 0.f;
+        r[i].y = ok ? bnrelu(v.y, sc.y, sf.y) : 0.f;
     }
 }
 
-__device__ __forceinline__ void dw_out_row(float *__restrict__ oimg, int h, int w0, int W, int cl,
+template <typename T>
+__device__ __forceinline__ void dw_out_row(T *__restrict__ oimg, int h, int w0, int W, int cl,
                                            const float2 (&top)[6], const float2 (&mid)[6], const float2 (&bot)[6],
                                            const float (&wa)[9], const float (&wb)[9], float &s0, float &s1, float &q0,
                                            float &q1) {
@@ -131,17 +139,20 @@ __device__ __forceinline__ void dw_out_row(float *__restrict__ oimg, int h, int 
             a1 = fmaf(bot[i + kw].y, wb[6 + kw], a1);
         }
         if (w0 + i < W) {
-            *reinterpret_cast<float2 *>(oimg + ((size_t)h * W + w0 + i) * 64 + 2 * cl) = make_float2(a0, a1);
-            s0 += a0; s1 += a1;
-            q0 = fmaf(a0, a0, q0); q1 = fmaf(a1, a1, q1);
+            const float2 o = Act<T>::round2(make_float2(a0, a1));
+            Act<T>::st2(oimg + ((size_t)h * W + w0 + i) * 64 + 2 * cl, o);
+            s0 += o.x; s1 += o.y;
+            q0 = fmaf(o.x, o.x, q0); q1 = fmaf(o.y, o.y, q1);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_dw_fwd(const float *__restrict__ yin, const float *__restrict__ ss,
-                                                const float *__restrict__ w, DwGeom g, float *__restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void k_dw_fwd(const T *__restrict__ yin, const float *__restrict__ ss,
+                                                const float *__restrict__ w, DwGeom g, T *__restrict__ y,
                                                 float *__restrict__ partials) {
     __shared__ float sh[8 * 128];
+    typedef typename Act<T>::raw2 raw2;
     const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
     float wa[9], wb[9];
 #pragma unroll
@@ -159,24 +170,25 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const float *__restrict__ yin, c
         const int seg = (int)(t % g.nseg), b = (int)(t / g.nseg);
         const int w0 = cs * 4, hs = seg * g.hs_len;
         const int he = min(g.H, hs + g.hs_len);
-        const float *img = yin + (size_t)b * img_stride;
-        float *oimg = y + (size_t)b * img_stride;
+        const T *img = yin + (size_t)b * img_stride;
+        T *oimg = y + (size_t)b * img_stride;
         // rows[(i)%3] = row h-1, rows[(i+1)%3] = row h, rows[(i+2)%3] = row h+1 ; `ahead` = raw row h+2 in flight
-        float2 rows[3][6], raw[6], ahead[6];
-        dw_issue_row(img, hs - 1, w0, g.H, g.W, cl, raw);
-        dw_finish_row(raw, hs - 1, w0, g.H, g.W, sc, sf, rows[0]);
-        dw_issue_row(img, hs, w0, g.H, g.W, cl, raw);
-        dw_finish_row(raw, hs, w0, g.H, g.W, sc, sf, rows[1]);
-        dw_issue_row(img, hs + 1, w0, g.H, g.W, cl, ahead);
+        float2 rows[3][6];
+        raw2 raw[6], ahead[6];
+        dw_issue_row<T>(img, hs - 1, w0, g.H, g.W, cl, raw);
+        dw_finish_row<T>(raw, hs - 1, w0, g.H, g.W, sc, sf, rows[0]);
+        dw_issue_row<T>(img, hs, w0, g.H, g.W, cl, raw);
+        dw_finish_row<T>(raw, hs, w0, g.H, g.W, sc, sf, rows[1]);
+        dw_issue_row<T>(img, hs + 1, w0, g.H, g.W, cl, ahead);
 #pragma unroll
         for (int i = 0; i < DW_HS; ++i) {
             const int h = hs + i;
             if (h < he) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) raw[c] = ahead[c];
-                if (i + 1 < DW_HS) dw_issue_row(img, h + 2, w0, g.H, g.W, cl, ahead);   // one row ahead of its use
-                dw_finish_row(raw, h + 1, w0, g.H, g.W, sc, sf, rows[(i + 2) % 3]);
-                dw_out_row(oimg, h, w0, g.W, cl, rows[i % 3], rows[(i + 1) % 3], rows[(i + 2) % 3], wa, wb, s0, s1, q0,
+                if (i + 1 < DW_HS) dw_issue_row<T>(img, h + 2, w0, g.H, g.W, cl, ahead);   // one row ahead of its use
+                dw_finish_row<T>(raw, h + 1, w0, g.H, g.W, sc, sf, rows[(i + 2) % 3]);
+                dw_out_row<T>(oimg, h, w0, g.W, cl, rows[i % 3], rows[(i + 1) % 3], rows[(i + 2) % 3], wa, wb, s0, s1, q0,
                            q1);
             }
         }
@@ -188,10 +200,15 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const float *__restrict__ yin, c
 constexpr int PW_TILE = 128;    // pixels per workgroup tile (32 per wavefront)
 constexpr int PW_LD = 68;       // padded LDS row (floats): 272 B -> conflict-free ds_read_b128 / ds_write_b128
 
-__global__ __launch_bounds__(256) void k_pw_fwd(const float *__restrict__ yin, const float *__restrict__ ss,
-                                                const float *__restrict__ w, long M, float *__restrict__ y,
+// LDS (dynamic): tile[128][68] (+ otile[128][68] for the bf16 output staging)
+template <typename T>
+__global__ __launch_bounds__(256) void k_pw_fwd(const T *__restrict__ yin, const float *__restrict__ ss,
+                                                const float *__restrict__ w, long M, T *__restrict__ y,
                                                 float *__restrict__ partials) {
-    __shared__ __align__(16) float tile[PW_TILE * PW_LD];
+    extern __shared__ __align__(16) float pw_lds[];
+    float *tile = pw_lds;
+    float *otile = pw_lds + PW_TILE * PW_LD;     // carved for bf16 only
+    typedef typename Act<T>::raw4 raw4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     // wave (rh, n) owns pixels [64rh, 64rh+64) x output channels [32n, 32n+32) of the tile
@@ -212,13 +229,13 @@ __global__ __launch_bounds__(256) void k_pw_fwd(const float *__restrict__ yin, c
     // software pipeline: the NEXT tile's global loads are issued right after the LDS barrier, so they are in
     // flight while this tile's MFMAs run (co-resident workgroups otherwise fall into lockstep: all load, then
     // all compute, and time = HBM + MFMA instead of max(HBM, MFMA))
-    float4 raw[8];
+    raw4 raw[8];
     auto issue = [&](long ti) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             long p = ti * PW_TILE + (tid >> 4) + 16 * i;
             p = p < M ? p : M - 1;                       // clamped, branch-free; masked when consumed
-            raw[i] = *reinterpret_cast<const float4 *>(yin + (size_t)p * 64 + 4 * c4);
+            raw[i] = Act<T>::ldraw4(yin + (size_t)p * 64 + 4 * c4);
         }
     };
     if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
@@ -229,9 +246,10 @@ __global__ __launch_bounds__(256) void k_pw_fwd(const float *__restrict__ yin, c
         for (int i = 0; i < 8; ++i) {
             const int row = (tid >> 4) + 16 * i;
             const bool ok = p0 + row < M;
+            const float4 v = Act<T>::cvt4(raw[i]);
             float4 a;
-            a.x = ok ? bnrelu(raw[i].x, sc.x, sf.x) : 0.f; a.y = ok ? bnrelu(raw[i].y, sc.y, sf.y) : 0.f;
-            a.z = ok ? bnrelu(raw[i].z, sc.z, sf.z) : 0.f; a.w = ok ? bnrelu(raw[i].w, sc.w, sf.w) : 0.f;
+            a.x = ok ? bnrelu(v.x, sc.x, sf.x) : 0.f; a.y = ok ? bnrelu(v.y, sc.y, sf.y) : 0.f;
+            a.z = ok ? bnrelu(v.z, sc.z, sf.z) : 0.f; a.w = ok ? bnrelu(v.w, sc.w, sf.w) : 0.f;
             *reinterpret_cast<float4 *>(tile + row * PW_LD + 4 * c4) = a;
         }
         __syncthreads();
@@ -251,18 +269,33 @@ __global__ __launch_bounds__(256) void k_pw_fwd(const float *__restrict__ yin, c
             // D layout: col = lane&31 (output channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const long p = p0 + rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const float v = acc[reg];
-                if (p < M) y[(size_t)p * 64 + 32 * n + r] = v;
+                const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const float v = Act<T>::round1(acc[reg]);
+                if constexpr (Act<T>::is_f32) {
+                    if (p0 + prow < M) y[(size_t)(p0 + prow) * 64 + 32 * n + r] = v;
+                } else {
+                    otile[prow * PW_LD + 32 * n + r] = v;     // staged: packed 8-byte stores below
+                }
                 s1 += v;                      // rows past M are exact zeros
                 s2 = fmaf(v, v, s2);
             }
         }
         __syncthreads();
+        if constexpr (!Act<T>::is_f32) {
+            // otile is rewritten only after the next tile's barrier, i.e. after every thread finished this pass
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = (tid >> 4) + 16 * i;
+                if (p0 + row < M)
+                    Act<T>::st4(y + (size_t)(p0 + row) * 64 + 4 * c4,
+                                *reinterpret_cast<const float4 *>(otile + row * PW_LD + 4 * c4));
+            }
+        }
     }
     if (partials) {
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
+        __syncthreads();
         float *sh = tile;  // [wave][kind][32]
         if (h == 0) {
             sh[wv * 64 + r] = s1;
@@ -278,18 +311,21 @@ __global__ __launch_bounds__(256) void k_pw_fwd(const float *__restrict__ yin, c
 
 // -------------------------------------------------------------------------------------- GAP
 // pool[b] = [sum relu(z) (64) | sum_{z>0} yhat (64) | count_{z>0} (64)]
-__global__ __launch_bounds__(256) void k_gap_fwd(const float *__restrict__ y, const float *__restrict__ ss,
-                                                 const float *__restrict__ mr, int HW, float *__restrict__ pool) {
-    __shared__ float sh[8 * 192];
+// one 1024-thread workgroup per clip (32 pixel slots): 32 waves/CU keep enough loads in flight for a pure read
+template <typename T>
+__global__ __launch_bounds__(1024) void k_gap_fwd(const T *__restrict__ y, const float *__restrict__ ss,
+                                                  const float *__restrict__ mr, int HW, float *__restrict__ pool) {
+    __shared__ float sh[32 * 192];
     const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31, b = blockIdx.x;
     const float2 sc = *reinterpret_cast<const float2 *>(ss + 2 * cl);
     const float2 sf = *reinterpret_cast<const float2 *>(ss + 64 + 2 * cl);
     const float2 mu = *reinterpret_cast<const float2 *>(mr + 2 * cl);
     const float2 rs = *reinterpret_cast<const float2 *>(mr + 64 + 2 * cl);
-    const float *yb = y + (size_t)b * HW * 64;
+    const T *yb = y + (size_t)b * HW * 64;
     float a0 = 0.f, a1 = 0.f, h0 = 0.f, h1 = 0.f, c0 = 0.f, c1 = 0.f;
-    for (int p = slot; p < HW; p += 8) {
-        const float2 v = *reinterpret_cast<const float2 *>(yb + (size_t)p * 64 + 2 * cl);
+#pragma unroll 4
+    for (int p = slot; p < HW; p += 32) {
+        const float2 v = Act<T>::cvt2(Act<T>::ldraw2(yb + (size_t)p * 64 + 2 * cl));
         const float z0 = fmaf(v.x, sc.x, sf.x), z1 = fmaf(v.y, sc.y, sf.y);
         if (z0 > 0.f) { a0 += z0; h0 += (v.x - mu.x) * rs.x; c0 += 1.f; }
         if (z1 > 0.f) { a1 += z1; h1 += (v.y - mu.y) * rs.y; c1 += 1.f; }
@@ -300,8 +336,8 @@ __global__ __launch_bounds__(256) void k_gap_fwd(const float *__restrict__ y, co
     __syncthreads();
     if (tid < 192) {
         float t = 0.f;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) t += sh[s * 192 + tid];
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) t += sh[s * 192 + tid];
         pool[(size_t)b * 192 + tid] = t;
     }
 }
@@ -351,72 +387,128 @@ int check_bn(const char *who, const ww_bn_t *bn, const float *ss_out, const floa
     return WW_OK;
 }
 
+int check_act(const char *who, int act_dtype) {
+    WW_REQUIRE(act_dtype == WW_ACT_F32 || act_dtype == WW_ACT_BF16, WW_E_INVALID, "%s: unknown act_dtype %d", who,
+               act_dtype);
+    return WW_OK;
+}
+
+template <typename T>
+int launch_stem_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int Hin, int Win, void *y, float *partials,
+                    int *grid_out, hipStream_t st) {
+    const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
+    const long nrows = (long)B * Ho;
+    const int grid = ww_occupancy_grid((const void *)k_stem_fwd<T>, 256, 0, nrows, WW_MAX_PARTIALS);
+    {
+        ww_prof_scope ps_(ctx, WW_K_STEM_FWD, st);
+        hipLaunchKernelGGL(k_stem_fwd<T>, dim3(grid), dim3(256), 0, st, x, w, B, Hin, Win, Ho, Wo, (T *)y, partials);
+    }
+    WW_LAUNCH_CHECK();
+    *grid_out = grid;
+    return WW_OK;
+}
+
+template <typename T>
+int launch_dw_fwd(ww_ctx *ctx, const void *y_in, const float *ss_in, const float *w, const DwGeom &g, void *y,
+                  float *partials, int *grid_out, hipStream_t st) {
+    const long nblk = (g.items + 7) / 8;
+    const int grid = ww_occupancy_grid((const void *)k_dw_fwd<T>, 256, 0, nblk, WW_MAX_PARTIALS);
+    {
+        ww_prof_scope ps_(ctx, WW_K_DW_FWD, st);
+        hipLaunchKernelGGL(k_dw_fwd<T>, dim3(grid), dim3(256), 0, st, (const T *)y_in, ss_in, w, g, (T *)y, partials);
+    }
+    WW_LAUNCH_CHECK();
+    *grid_out = grid;
+    return WW_OK;
+}
+
+template <typename T>
+int launch_pw_fwd(ww_ctx *ctx, const void *y_in, const float *ss_in, const float *w, long M, void *y, float *partials,
+                  int *grid_out, hipStream_t st) {
+    const long ntiles = (M + PW_TILE - 1) / PW_TILE;
+    const size_t smem = (size_t)(Act<T>::is_f32 ? 1 : 2) * PW_TILE * PW_LD * sizeof(float);
+    WW_HIP(hipFuncSetAttribute((const void *)k_pw_fwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int grid = ww_occupancy_grid((const void *)k_pw_fwd<T>, 256, smem, ntiles, WW_MAX_PARTIALS);
+    {
+        ww_prof_scope ps_(ctx, WW_K_PW_FWD, st);
+        hipLaunchKernelGGL(k_pw_fwd<T>, dim3(grid), dim3(256), smem, st, (const T *)y_in, ss_in, w, M, (T *)y, partials);
+    }
+    WW_LAUNCH_CHECK();
+    *grid_out = grid;
+    return WW_OK;
+}
+
 }  // namespace
 
-extern "C" int ww_conv_stem_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int Hin, int Win, float *y,
-                                const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch, ww_stream_t stream) {
+extern "C" int ww_conv_stem_fwd(ww_ctx *ctx, int act_dtype, const float *x, const float *w, int B, int Hin, int Win,
+                                void *y, const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch,
+                                ww_stream_t stream) {
     WW_REQUIRE(ctx && x && w && y, WW_E_INVALID, "ww_conv_stem_fwd: null argument");
     WW_REQUIRE(B >= 1 && Hin >= 1 && Win >= 1, WW_E_INVALID, "ww_conv_stem_fwd: bad shape (%d,%d,%d)", B, Hin, Win);
     int rc = check_bn("ww_conv_stem_fwd", bn, ss_out, mr_out, scratch);
-    if (rc) return rc;
-    const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
-    const long nrows = (long)B * Ho;
-    const int grid = ww_occupancy_grid((const void *)k_stem_fwd, 256, 0, nrows, WW_MAX_PARTIALS);
+    if (rc || (rc = check_act("ww_conv_stem_fwd", act_dtype))) return rc;
     hipStream_t st = (hipStream_t)stream;
     float *partials = bn->training ? (float *)scratch : nullptr;
-    { ww_prof_scope ps_(ctx, WW_K_STEM_FWD, st);
-      hipLaunchKernelGGL(k_stem_fwd, dim3(grid), dim3(256), 0, st, x, w, B, Hin, Win, Ho, Wo, y, partials); }
-    WW_LAUNCH_CHECK();
-    return finish_bn(ctx, partials, grid, (double)B * Ho * Wo, bn, ss_out, mr_out, st);
+    int grid = 0;
+    rc = act_dtype == WW_ACT_BF16 ? launch_stem_fwd<ww_bf16>(ctx, x, w, B, Hin, Win, y, partials, &grid, st)
+                                  : launch_stem_fwd<float>(ctx, x, w, B, Hin, Win, y, partials, &grid, st);
+    if (rc) return rc;
+    return finish_bn(ctx, partials, grid, (double)B * ((Hin + 1) / 2) * ((Win + 1) / 2), bn, ss_out, mr_out, st);
 }
 
-extern "C" int ww_dwconv3x3_fwd(ww_ctx *ctx, const float *y_in, const float *ss_in, const float *w, int B, int H,
-                                int W, float *y, const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch,
-                                ww_stream_t stream) {
+extern "C" int ww_dwconv3x3_fwd(ww_ctx *ctx, int act_dtype, const void *y_in, const float *ss_in, const float *w,
+                                int B, int H, int W, void *y, const ww_bn_t *bn, float *ss_out, float *mr_out,
+                                void *scratch, ww_stream_t stream) {
     WW_REQUIRE(ctx && y_in && ss_in && w && y, WW_E_INVALID, "ww_dwconv3x3_fwd: null argument");
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_dwconv3x3_fwd: bad shape (%d,%d,%d)", B, H, W);
     int rc = check_bn("ww_dwconv3x3_fwd", bn, ss_out, mr_out, scratch);
-    if (rc) return rc;
+    if (rc || (rc = check_act("ww_dwconv3x3_fwd", act_dtype))) return rc;
     DwGeom g;
     g.B = B; g.H = H; g.W = W;
     g.ncs = (W + 3) / 4;
     g.nseg = (H + DW_HS - 1) / DW_HS;
     g.hs_len = (H + g.nseg - 1) / g.nseg;      // <= DW_HS
     g.items = (long)B * g.nseg * g.ncs;
-    const long nblk = (g.items + 7) / 8;
-    const int grid = ww_occupancy_grid((const void *)k_dw_fwd, 256, 0, nblk, WW_MAX_PARTIALS);
     hipStream_t st = (hipStream_t)stream;
     float *partials = bn->training ? (float *)scratch : nullptr;
-    { ww_prof_scope ps_(ctx, WW_K_DW_FWD, st);
-      hipLaunchKernelGGL(k_dw_fwd, dim3(grid), dim3(256), 0, st, y_in, ss_in, w, g, y, partials); }
-    WW_LAUNCH_CHECK();
+    int grid = 0;
+    rc = act_dtype == WW_ACT_BF16 ? launch_dw_fwd<ww_bf16>(ctx, y_in, ss_in, w, g, y, partials, &grid, st)
+                                  : launch_dw_fwd<float>(ctx, y_in, ss_in, w, g, y, partials, &grid, st);
+    if (rc) return rc;
     return finish_bn(ctx, partials, grid, (double)B * H * W, bn, ss_out, mr_out, st);
 }
 
-extern "C" int ww_pwconv1x1_fwd(ww_ctx *ctx, const float *y_in, const float *ss_in, const float *w, int B, int H,
-                                int W, float *y, const ww_bn_t *bn, float *ss_out, float *mr_out, void *scratch,
-                                ww_stream_t stream) {
+extern "C" int ww_pwconv1x1_fwd(ww_ctx *ctx, int act_dtype, const void *y_in, const float *ss_in, const float *w,
+                                int B, int H, int W, void *y, const ww_bn_t *bn, float *ss_out, float *mr_out,
+                                void *scratch, ww_stream_t stream) {
     WW_REQUIRE(ctx && y_in && ss_in && w && y, WW_E_INVALID, "ww_pwconv1x1_fwd: null argument");
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_pwconv1x1_fwd: bad shape (%d,%d,%d)", B, H, W);
     int rc = check_bn("ww_pwconv1x1_fwd", bn, ss_out, mr_out, scratch);
-    if (rc) return rc;
+    if (rc || (rc = check_act("ww_pwconv1x1_fwd", act_dtype))) return rc;
     const long M = (long)B * H * W;
-    const long ntiles = (M + PW_TILE - 1) / PW_TILE;
-    const int grid = ww_occupancy_grid((const void *)k_pw_fwd, 256, 0, ntiles, WW_MAX_PARTIALS);
     hipStream_t st = (hipStream_t)stream;
     float *partials = bn->training ? (float *)scratch : nullptr;
-    { ww_prof_scope ps_(ctx, WW_K_PW_FWD, st);
-      hipLaunchKernelGGL(k_pw_fwd, dim3(grid), dim3(256), 0, st, y_in, ss_in, w, M, y, partials); }
-    WW_LAUNCH_CHECK();
+    int grid = 0;
+    rc = act_dtype == WW_ACT_BF16 ? launch_pw_fwd<ww_bf16>(ctx, y_in, ss_in, w, M, y, partials, &grid, st)
+                                  : launch_pw_fwd<float>(ctx, y_in, ss_in, w, M, y, partials, &grid, st);
+    if (rc) return rc;
     return finish_bn(ctx, partials, grid, (double)M, bn, ss_out, mr_out, st);
 }
 
-extern "C" int ww_gap_fwd(ww_ctx *ctx, const float *y, const float *ss, const float *mr, int B, int H, int W,
-                          float *pool, ww_stream_t stream) {
+extern "C" int ww_gap_fwd(ww_ctx *ctx, int act_dtype, const void *y, const float *ss, const float *mr, int B, int H,
+                          int W, float *pool, ww_stream_t stream) {
     WW_REQUIRE(ctx && y && ss && mr && pool, WW_E_INVALID, "ww_gap_fwd: null argument");
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_gap_fwd: bad shape (%d,%d,%d)", B, H, W);
-    { ww_prof_scope ps_(ctx, WW_K_GAP_FWD, (hipStream_t)stream);
-      hipLaunchKernelGGL(k_gap_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, y, ss, mr, H * W, pool); }
+    int rc = check_act("ww_gap_fwd", act_dtype);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        ww_prof_scope ps_(ctx, WW_K_GAP_FWD, st);
+        if (act_dtype == WW_ACT_BF16)
+            hipLaunchKernelGGL(k_gap_fwd<ww_bf16>, dim3(B), dim3(1024), 0, st, (const ww_bf16 *)y, ss, mr, H * W, pool);
+        else
+            hipLaunchKernelGGL(k_gap_fwd<float>, dim3(B), dim3(1024), 0, st, (const float *)y, ss, mr, H * W, pool);
+    }
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

@@ -7,22 +7,25 @@ namespace {
 
 constexpr int NL = 9;  // conv layers: 0 stem, 1+2i dw_i, 2+2i pw_i
 
+// all offsets in BYTES from the workspace base
 struct Layout {
     int Ho, Wo;
-    size_t A;                       // floats per activation tensor
+    size_t A;                       // elements per activation tensor
     size_t y[NL], g[2], ss[NL], mr[NL], coef[NL], pool, pd, dpool, scratch, total;
 };
 
-Layout make_layout(int B, int F, int T) {
+Layout make_layout(int B, int F, int T, int act_dtype) {
     Layout L;
     L.Ho = (F + 1) / 2;
     L.Wo = (T + 1) / 2;
     L.A = (size_t)B * L.Ho * L.Wo * 64;
+    const size_t esz = act_dtype == WW_ACT_BF16 ? 2 : 4;
     size_t o = 0;
-    auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~(size_t)63; return r; };
-    for (int i = 0; i < NL; ++i) L.y[i] = take(L.A);
-    L.g[0] = take(L.A);
-    L.g[1] = take(L.A);
+    auto takeb = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    auto take = [&](size_t nfloat) { return takeb(nfloat * sizeof(float)); };
+    for (int i = 0; i < NL; ++i) L.y[i] = takeb(L.A * esz);
+    L.g[0] = takeb(L.A * esz);
+    L.g[1] = takeb(L.A * esz);
     for (int i = 0; i < NL; ++i) { L.ss[i] = take(128); L.mr[i] = take(128); L.coef[i] = take(192); }
     L.pool = take((size_t)B * 192);
     L.pd = take((size_t)B * 64);
@@ -49,13 +52,15 @@ ww_bn_t make_bn(void *const *p, int l, int training, float mom, float eps) {
     return bn;
 }
 
-int check_common(const char *who, ww_ctx *ctx, void *const *params, const void *x, int B, int F, int T, void *ws,
-                 size_t ws_bytes) {
+int check_common(const char *who, ww_ctx *ctx, int act_dtype, void *const *params, const void *x, int B, int F, int T,
+                 void *ws, size_t ws_bytes) {
+    WW_REQUIRE(act_dtype == WW_ACT_F32 || act_dtype == WW_ACT_BF16, WW_E_INVALID, "%s: unknown act_dtype %d", who,
+               act_dtype);
     WW_REQUIRE(ctx && params && x && ws, WW_E_INVALID, "%s: null argument", who);
     WW_REQUIRE(B >= 1 && F >= 1 && T >= 1, WW_E_INVALID, "%s: bad shape (%d,1,%d,%d)", who, B, F, T);
     for (int i = 0; i < WW_CNN_SMALL_NPTR; ++i)
         WW_REQUIRE(params[i] != nullptr, WW_E_INVALID, "%s: params[%d] is null", who, i);
-    const size_t need = ww_cnn_small_workspace_bytes(B, F, T);
+    const size_t need = ww_cnn_small_workspace_bytes(B, F, T, act_dtype);
     WW_REQUIRE(ws_bytes >= need, WW_E_WORKSPACE, "%s: workspace %zu B < required %zu B", who, ws_bytes, need);
     WW_REQUIRE(((uintptr_t)ws & 255) == 0, WW_E_INVALID, "%s: workspace must be 256-byte aligned", who);
     return WW_OK;
@@ -63,49 +68,51 @@ int check_common(const char *who, ww_ctx *ctx, void *const *params, const void *
 
 }  // namespace
 
-extern "C" size_t ww_cnn_small_workspace_bytes(int B, int F, int T) {
+extern "C" size_t ww_cnn_small_workspace_bytes(int B, int F, int T, int act_dtype) {
     if (B < 1 || F < 1 || T < 1) return 0;
-    return make_layout(B, F, T).total * sizeof(float);
+    return make_layout(B, F, T, act_dtype).total;
 }
 
-extern "C" int ww_cnn_small_fwd(ww_ctx *ctx, void *const *params, const float *x, int B, int F, int T, int training,
+extern "C" int ww_cnn_small_fwd(ww_ctx *ctx, int act_dtype, void *const *params, const float *x, int B, int F, int T, int training,
                                 float bn_momentum, float bn_eps, float dropout_p, uint64_t seed, uint64_t step,
                                 uint64_t sample_offset, void *ws, size_t ws_bytes, float *logits, ww_stream_t stream) {
-    int rc = check_common("ww_cnn_small_fwd", ctx, params, x, B, F, T, ws, ws_bytes);
+    int rc = check_common("ww_cnn_small_fwd", ctx, act_dtype, params, x, B, F, T, ws, ws_bytes);
     if (rc) return rc;
     WW_REQUIRE(logits != nullptr, WW_E_INVALID, "ww_cnn_small_fwd: logits is null");
-    const Layout L = make_layout(B, F, T);
-    float *w = (float *)ws;
+    const Layout L = make_layout(B, F, T, act_dtype);
+    char *w = (char *)ws;
+    auto Fp = [&](size_t off) { return (float *)(w + off); };
     void *scratch = w + L.scratch;
     ww_bn_t bn = make_bn(params, 0, training, bn_momentum, bn_eps);
-    rc = ww_conv_stem_fwd(ctx, x, (const float *)params[0], B, F, T, w + L.y[0], &bn, w + L.ss[0], w + L.mr[0], scratch,
-                          stream);
+    rc = ww_conv_stem_fwd(ctx, act_dtype, x, (const float *)params[0], B, F, T, w + L.y[0], &bn, Fp(L.ss[0]), Fp(L.mr[0]),
+                          scratch, stream);
     if (rc) return rc;
     for (int i = 0; i < 4; ++i) {
         const int ld = 1 + 2 * i, lp = 2 + 2 * i;
         bn = make_bn(params, ld, training, bn_momentum, bn_eps);
-        rc = ww_dwconv3x3_fwd(ctx, w + L.y[ld - 1], w + L.ss[ld - 1], (const float *)params[widx(ld)], B, L.Ho, L.Wo,
-                              w + L.y[ld], &bn, w + L.ss[ld], w + L.mr[ld], scratch, stream);
+        rc = ww_dwconv3x3_fwd(ctx, act_dtype, w + L.y[ld - 1], Fp(L.ss[ld - 1]), (const float *)params[widx(ld)], B, L.Ho,
+                              L.Wo, w + L.y[ld], &bn, Fp(L.ss[ld]), Fp(L.mr[ld]), scratch, stream);
         if (rc) return rc;
         bn = make_bn(params, lp, training, bn_momentum, bn_eps);
-        rc = ww_pwconv1x1_fwd(ctx, w + L.y[ld], w + L.ss[ld], (const float *)params[widx(lp)], B, L.Ho, L.Wo,
-                              w + L.y[lp], &bn, w + L.ss[lp], w + L.mr[lp], scratch, stream);
+        rc = ww_pwconv1x1_fwd(ctx, act_dtype, w + L.y[ld], Fp(L.ss[ld]), (const float *)params[widx(lp)], B, L.Ho, L.Wo,
+                              w + L.y[lp], &bn, Fp(L.ss[lp]), Fp(L.mr[lp]), scratch, stream);
         if (rc) return rc;
     }
-    rc = ww_gap_fwd(ctx, w + L.y[8], w + L.ss[8], w + L.mr[8], B, L.Ho, L.Wo, w + L.pool, stream);
+    rc = ww_gap_fwd(ctx, act_dtype, w + L.y[8], Fp(L.ss[8]), Fp(L.mr[8]), B, L.Ho, L.Wo, Fp(L.pool), stream);
     if (rc) return rc;
-    return ww_head_fwd(ctx, w + L.pool, B, L.Ho * L.Wo, (const float *)params[45], (const float *)params[46], dropout_p,
-                       training, seed, step, sample_offset, w + L.pd, logits, stream);
+    return ww_head_fwd(ctx, Fp(L.pool), B, L.Ho * L.Wo, (const float *)params[45], (const float *)params[46], dropout_p,
+                       training, seed, step, sample_offset, Fp(L.pd), logits, stream);
 }
 
-extern "C" int ww_cnn_small_bwd(ww_ctx *ctx, void *const *params, void *const *grads, const float *x,
+extern "C" int ww_cnn_small_bwd(ww_ctx *ctx, int act_dtype, void *const *params, void *const *grads, const float *x,
                                 const float *dlogits, int B, int F, int T, float dropout_p, uint64_t seed, uint64_t step,
                                 uint64_t sample_offset, void *ws, size_t ws_bytes, ww_stream_t stream) {
-    int rc = check_common("ww_cnn_small_bwd", ctx, params, x, B, F, T, ws, ws_bytes);
+    int rc = check_common("ww_cnn_small_bwd", ctx, act_dtype, params, x, B, F, T, ws, ws_bytes);
     if (rc) return rc;
     WW_REQUIRE(grads && dlogits, WW_E_INVALID, "ww_cnn_small_bwd: null argument");
-    const Layout L = make_layout(B, F, T);
-    float *w = (float *)ws;
+    const Layout L = make_layout(B, F, T, act_dtype);
+    char *w = (char *)ws;
+    auto Fp = [&](size_t off) { return (float *)(w + off); };
     void *scratch = w + L.scratch;
     auto G = [&](int i) { return (float *)grads[i]; };
     for (int l = 0; l < NL; ++l) {
@@ -114,28 +121,28 @@ extern "C" int ww_cnn_small_bwd(ww_ctx *ctx, void *const *params, void *const *g
     }
     WW_REQUIRE(grads[45] && grads[46], WW_E_INVALID, "ww_cnn_small_bwd: missing classifier gradient buffers");
     const int HW = L.Ho * L.Wo;
-    rc = ww_head_bwd(ctx, dlogits, w + L.pd, w + L.pool, B, HW, (const float *)params[45], dropout_p, 1, seed, step,
-                     sample_offset, (const float *)params[bnidx(8)], w + L.mr[8], G(45), G(46), w + L.dpool,
-                     w + L.coef[8], G(bnidx(8)), G(bnidx(8) + 1), stream);
+    rc = ww_head_bwd(ctx, dlogits, Fp(L.pd), Fp(L.pool), B, HW, (const float *)params[45], dropout_p, 1, seed, step,
+                     sample_offset, (const float *)params[bnidx(8)], Fp(L.mr[8]), G(45), G(46), Fp(L.dpool),
+                     Fp(L.coef[8]), G(bnidx(8)), G(bnidx(8) + 1), stream);
     if (rc) return rc;
     int cur = 0;  // g[cur] holds dL/dz of the layer about to be processed (unused for layer 8)
     for (int i = 3; i >= 0; --i) {
         const int ld = 1 + 2 * i, lp = 2 + 2 * i;
-        const float *gp = (lp == 8) ? nullptr : w + L.g[cur];
+        const void *gp = (lp == 8) ? nullptr : w + L.g[cur];
         const int nxt = (lp == 8) ? 0 : cur ^ 1;
-        rc = ww_pwconv1x1_bwd(ctx, gp, w + L.dpool, w + L.y[lp], w + L.ss[lp], w + L.coef[lp], w + L.y[ld], w + L.ss[ld],
-                              w + L.mr[ld], (const float *)params[bnidx(ld)], (const float *)params[widx(lp)], B, L.Ho,
-                              L.Wo, w + L.g[nxt], G(widx(lp)), w + L.coef[ld], G(bnidx(ld)), G(bnidx(ld) + 1), scratch,
-                              stream);
+        rc = ww_pwconv1x1_bwd(ctx, act_dtype, gp, Fp(L.dpool), w + L.y[lp], Fp(L.ss[lp]), Fp(L.coef[lp]), w + L.y[ld],
+                              Fp(L.ss[ld]), Fp(L.mr[ld]), (const float *)params[bnidx(ld)],
+                              (const float *)params[widx(lp)], B, L.Ho, L.Wo, w + L.g[nxt], G(widx(lp)), Fp(L.coef[ld]),
+                              G(bnidx(ld)), G(bnidx(ld) + 1), scratch, stream);
         if (rc) return rc;
         cur = nxt;
         const int lprev = ld - 1;
-        rc = ww_dwconv3x3_bwd(ctx, w + L.g[cur], w + L.y[ld], w + L.coef[ld], w + L.y[lprev], w + L.ss[lprev],
-                              w + L.mr[lprev], (const float *)params[bnidx(lprev)], (const float *)params[widx(ld)], B,
-                              L.Ho, L.Wo, w + L.g[cur ^ 1], G(widx(ld)), w + L.coef[lprev], G(bnidx(lprev)),
+        rc = ww_dwconv3x3_bwd(ctx, act_dtype, w + L.g[cur], w + L.y[ld], Fp(L.coef[ld]), w + L.y[lprev], Fp(L.ss[lprev]),
+                              Fp(L.mr[lprev]), (const float *)params[bnidx(lprev)], (const float *)params[widx(ld)], B,
+                              L.Ho, L.Wo, w + L.g[cur ^ 1], G(widx(ld)), Fp(L.coef[lprev]), G(bnidx(lprev)),
                               G(bnidx(lprev) + 1), scratch, stream);
         if (rc) return rc;
         cur ^= 1;
     }
-    return ww_conv_stem_bwd(ctx, w + L.g[cur], w + L.y[0], w + L.coef[0], x, B, F, T, G(0), scratch, stream);
+    return ww_conv_stem_bwd(ctx, act_dtype, w + L.g[cur], w + L.y[0], Fp(L.coef[0]), x, B, F, T, G(0), scratch, stream);
 }

@@ -58,8 +58,9 @@ class CNNSmallWakeword(nn.Module):
     N_BLOCKS = 4
 
     def __init__(self, num_classes: int = 2, pretrained: bool = False, dropout: float = 0.3,
-                 input_channels: int = 1, dropout_seed: int = 0):
+                 input_channels: int = 1, dropout_seed: int = 0, act_dtype: str = "fp32"):
         super().__init__()
+        self.act = nat.act_code(act_dtype)   # storage of the conv-stack activations: fp32 (parity) | bf16
         if num_classes != 2:
             raise ValueError(f"cnn_small: the HIP classifier/loss kernels implement num_classes == 2, got {num_classes}")
         if input_channels != 1:
@@ -138,11 +139,16 @@ class CNNSmallWakeword(nn.Module):
         """The one flat fp32 gradient bucket (all-reduce / clip operate on it)."""
         return self._flat_grad
 
+    def set_act_dtype(self, act_dtype):
+        """'fp32' (parity mode) or 'bf16' (half the HBM traffic; fp32 arithmetic and statistics)."""
+        self.act = nat.act_code(act_dtype)
+        self._ws = {}
+
     def _workspace(self, B, F, T, dev, hold):
-        key = (B, F, T)
+        key = (B, F, T, self.act)
         slot = self._ws.get(key)
         if slot is None or slot["busy"]:
-            n = nat.cnn_small_workspace_bytes(B, F, T)
+            n = nat.cnn_small_workspace_bytes(B, F, T, self.act)
             slot = {"buf": torch.empty(n // 4, dtype=torch.float32, device=dev), "busy": False}
             self._ws[key] = slot
         slot["busy"] = hold
@@ -171,7 +177,8 @@ class CNNSmallWakeword(nn.Module):
         step = self.dropout_step
         nat.cnn_small_fwd(self._pptr, x, slot["buf"], logits, training=training,
                           bn_momentum=bn0.momentum if bn0.momentum is not None else 0.1, bn_eps=bn0.eps,
-                          dropout_p=self.p, seed=self.dropout_seed, step=step, sample_offset=self.sample_offset)
+                          dropout_p=self.p, seed=self.dropout_seed, step=step, sample_offset=self.sample_offset,
+                          act=self.act)
         if training:
             self.dropout_step += 1
             self._pending_tracked += 1
@@ -189,7 +196,7 @@ class CNNSmallWakeword(nn.Module):
                 off += (t.numel() + 3) // 4 * 4
             gptr = nat.ptr_array([views.get(id(t)) for t in tens])
         nat.cnn_small_bwd(self._pptr, gptr, x, dlogits.contiguous(), slot["buf"], dropout_p=self.p,
-                          seed=self.dropout_seed, step=step, sample_offset=self.sample_offset)
+                          seed=self.dropout_seed, step=step, sample_offset=self.sample_offset, act=self.act)
         slot["busy"] = False
         for p in self._plist:
             if fresh:
@@ -214,7 +221,7 @@ def create_model(architecture: str, num_classes: int = 2, pretrained: bool = Fal
     if name == "cnn_small":
         return CNNSmallWakeword(num_classes=num_classes, pretrained=pretrained, dropout=kwargs.get("dropout", 0.3),
                                 input_channels=kwargs.get("input_channels", 1),
-                                dropout_seed=kwargs.get("dropout_seed", 0))
+                                dropout_seed=kwargs.get("dropout_seed", 0), act_dtype=kwargs.get("act_dtype", "fp32"))
     if name in _REFERENCE_ONLY:
         raise ValueError(f"Architecture '{architecture}' exists in the reference but is outside this build's "
                          f"HIP hot path (DESIGN.md 'Out of scope'). Supported: {_SUPPORTED}")

@@ -83,8 +83,10 @@ class Trainer:
         self.optimizer, self.scheduler = create_optimizer_and_scheduler(self.model, config)
         self.use_mixed_precision = config.optimizer.mixed_precision
         if self.native and self.use_mixed_precision:
-            logger.warning("mixed_precision=True: the HIP path computes and stores in fp32 in this build "
-                           "(fp16 autocast/GradScaler apply to generic modules only)")
+            # the reference's AMP switch (fp16 autocast + GradScaler, trainer.py:92,172) maps to the HIP path's
+            # reduced-precision mode: bf16 activation/gradient storage, fp32 arithmetic, no loss scaling needed
+            self.model.set_act_dtype("bf16")
+            logger.info("mixed_precision=True -> bf16 activation storage on the HIP path")
         self.scaler = create_grad_scaler(enabled=self.use_mixed_precision and not self.native)
         self.gradient_clip = config.optimizer.gradient_clip
 
