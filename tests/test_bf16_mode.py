@@ -49,7 +49,10 @@ def test_conv_fwd_layers_bf16(nat, kind, B, H, W):
     y, ss, mr = fn(cu(nhwc(y_in), BF), cu(torch.cat([s_in, t_in])), cu(w), bn, nat.layer_scratch(DEV))
     assert y.dtype == BF
     yd = y.float().cpu().double()
-    assert (yd - nhwc(ref)).abs().max() <= EPS_BF16 * nhwc(ref).abs().max()
+    # depthwise: one rounding (the stored output).  pointwise (bf16 MFMA): activations and weights are rounded to
+    # bf16 as MFMA operands as well -> three roundings
+    tol = EPS_BF16 * (3 if kind == "pw" else 1)
+    assert (yd - nhwc(ref)).abs().max() <= tol * nhwc(ref).abs().max()
     # the statistics describe exactly the stored (rounded) tensor
     mean = yd.mean(dim=(0, 1, 2))
     var = yd.var(dim=(0, 1, 2), unbiased=False)
@@ -92,8 +95,10 @@ def test_conv_bwd_layers_bf16(nat, kind, B, H, W):
         g_in, dw, coef_in, dgamma, dbeta = nat.pwconv1x1_bwd(cu(nhwc(g), BF), None, ss_out=None, **args)
     assert g_in.dtype == BF
     gi = g_in.float().cpu().double()
-    assert (gi - nhwc(z_in.grad)).abs().max() <= EPS_BF16 * z_in.grad.abs().max()
-    assert rel_err(dw.cpu().reshape(-1), w.grad.reshape(-1)) < 1e-4           # fp32 accumulation of exact inputs
+    tol = EPS_BF16 * (3 if kind == "pw" else 1)       # pointwise: dy and W are bf16 MFMA operands
+    assert (gi - nhwc(z_in.grad)).abs().max() <= tol * z_in.grad.abs().max()
+    # pointwise: dy and relu(bn(y_in)) are rounded to bf16 for the MFMA (fp32 accumulation); depthwise: fp32 operands
+    assert rel_err(dw.cpu().reshape(-1), w.grad.reshape(-1)) < (4e-3 if kind == "pw" else 1e-4)
     # sums are taken over the ROUNDED g_in: compare with sums of the device tensor itself
     yhat_in = (nhwc(y_in) - mean_in) * rstd_in
     assert rel_err(dbeta.cpu(), gi.sum(dim=(0, 1, 2))) < 1e-4

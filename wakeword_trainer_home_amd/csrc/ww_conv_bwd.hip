@@ -241,6 +241,167 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const T *__restrict__ g, cons
     }
 }
 
+// ---- bf16 mode: dX and dW on v_mfma_f32_32x32x16_bf16.  Three bf16 [64][72] LDS tiles: dy, raw y_in (ReLU mask
+// and yhat of the input layer in the epilogue) and a = relu(bn(y_in)).  dX reads dy rows with ds_read_b128; dW needs
+// its operands pixel-major (K = pixels) and takes them from the same [pixel][channel] tiles with the transposing
+// read ds_read_b64_tr_b16: a 16-lane group reads 4 pixels x 16 channels and lane i receives channel i's 4 pixels.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+constexpr int PWH_LD = 72;      // bf16 elements per LDS row (144 B)
+
+__device__ __forceinline__ bf16x8 pack8b(const float (&v)[8]) {
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    return __builtin_convertvector(f, bf16x8);
+}
+// A/B operand of a 32x32x16 MFMA whose K index is the PIXEL: channels c0..c0+31 (lane&31), pixels p0 + 8*(lane>>5) .. +7
+__device__ __forceinline__ bf16x8 tr_operand(const ww_bf16 *tile, int p0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const ww_bf16 *base = tile + (p0 + 8 * (g >> 1) + q) * PWH_LD + c0 + 16 * (g & 1) + 4 * pp;
+    typedef short4v __attribute__((address_space(3))) * lds_p;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * PWH_LD));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <bool FROM_POOL>
+__global__ __launch_bounds__(256) void k_pw_bwd_bf16(const ww_bf16 *__restrict__ g, const float *__restrict__ dpool,
+                                                     const ww_bf16 *__restrict__ y_out, const float *__restrict__ ss_out,
+                                                     const float *__restrict__ coef, const ww_bf16 *__restrict__ y_in,
+                                                     const float *__restrict__ ss_in, const float *__restrict__ mr_in,
+                                                     const float *__restrict__ w, long M, int HW,
+                                                     ww_bf16 *__restrict__ g_in, float *__restrict__ stat_partials,
+                                                     float *__restrict__ dw_partials) {
+    __shared__ __align__(16) ww_bf16 tiles[3 * PWB_TILE * PWH_LD];
+    __shared__ __align__(16) float otile[PWB_TILE * PW_LD];
+    ww_bf16 *dyt = tiles, *yit = tiles + PWB_TILE * PWH_LD, *at = tiles + 2 * PWB_TILE * PWH_LD;
+    typedef Act<ww_bf16> A16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int rh = wv >> 1, n = wv & 1;   // dX: pixels [32rh,+32) x in-channels [32n,+32); dW: quadrant (jt,kt) = (rh,n)
+    // dX B operand of k-step t: B[j = 16t + 8h + jj][k = 32n + r] = w[j][k]
+    bf16x8 wt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w[(size_t)(16 * t + 8 * h + j) * 64 + 32 * n + r];
+        wt[t] = pack8b(v);
+    }
+    const int c4 = tid & 15;
+    const float4 cA = *reinterpret_cast<const float4 *>(coef + 4 * c4);
+    const float4 cB = *reinterpret_cast<const float4 *>(coef + 64 + 4 * c4);
+    const float4 cC = *reinterpret_cast<const float4 *>(coef + 128 + 4 * c4);
+    const float4 si = *reinterpret_cast<const float4 *>(ss_in + 4 * c4);
+    const float4 ti4 = *reinterpret_cast<const float4 *>(ss_in + 64 + 4 * c4);
+    float4 so = make_float4(0.f, 0.f, 0.f, 0.f), to = so;
+    if (FROM_POOL) {
+        so = *reinterpret_cast<const float4 *>(ss_out + 4 * c4);
+        to = *reinterpret_cast<const float4 *>(ss_out + 64 + 4 * c4);
+    }
+    const float sci = ss_in[32 * n + r], sfi = ss_in[64 + 32 * n + r];
+    const float mui = mr_in[32 * n + r], rsi = mr_in[64 + 32 * n + r];
+    floatx16 dwacc = {0.f};
+    float st1 = 0.f, st2 = 0.f;
+
+    const long ntiles = (M + PWB_TILE - 1) / PWB_TILE;
+    A16::raw4 rg[4], ro[4], ri[4];
+    auto issue = [&](long ti) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long p = ti * PWB_TILE + (tid >> 4) + 16 * i;
+            p = p < M ? p : M - 1;
+            ro[i] = A16::ldraw4(y_out + (size_t)p * 64 + 4 * c4);
+            ri[i] = A16::ldraw4(y_in + (size_t)p * 64 + 4 * c4);
+            if (!FROM_POOL) rg[i] = A16::ldraw4(g + (size_t)p * 64 + 4 * c4);
+        }
+    };
+    if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
+    for (long ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const long p0 = ti * PWB_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 4) + 16 * i;
+            const long p = p0 + row;
+            const bool ok = p < M;
+            const float4 yo = A16::cvt4(ro[i]);
+            const float4 yr = A16::cvt4(ri[i]);
+            float4 dz;
+            if (FROM_POOL) {
+                const float4 dp = *reinterpret_cast<const float4 *>(dpool + (size_t)((ok ? p : M - 1) / HW) * 64 + 4 * c4);
+                dz.x = fmaf(yo.x, so.x, to.x) > 0.f ? dp.x : 0.f;
+                dz.y = fmaf(yo.y, so.y, to.y) > 0.f ? dp.y : 0.f;
+                dz.z = fmaf(yo.z, so.z, to.z) > 0.f ? dp.z : 0.f;
+                dz.w = fmaf(yo.w, so.w, to.w) > 0.f ? dp.w : 0.f;
+            } else {
+                dz = A16::cvt4(rg[i]);
+            }
+            const float d0 = ok ? fmaf(cA.x, dz.x, fmaf(cB.x, yo.x, cC.x)) : 0.f;
+            const float d1 = ok ? fmaf(cA.y, dz.y, fmaf(cB.y, yo.y, cC.y)) : 0.f;
+            const float d2 = ok ? fmaf(cA.z, dz.z, fmaf(cB.z, yo.z, cC.z)) : 0.f;
+            const float d3 = ok ? fmaf(cA.w, dz.w, fmaf(cB.w, yo.w, cC.w)) : 0.f;
+            const float a0 = ok ? fmaxf(fmaf(yr.x, si.x, ti4.x), 0.f) : 0.f, a1 = ok ? fmaxf(fmaf(yr.y, si.y, ti4.y), 0.f) : 0.f;
+            const float a2 = ok ? fmaxf(fmaf(yr.z, si.z, ti4.z), 0.f) : 0.f, a3 = ok ? fmaxf(fmaf(yr.w, si.w, ti4.w), 0.f) : 0.f;
+            *reinterpret_cast<uint2 *>(dyt + row * PWH_LD + 4 * c4) = make_uint2(A16::pack2(d0, d1), A16::pack2(d2, d3));
+            *reinterpret_cast<uint2 *>(at + row * PWH_LD + 4 * c4) = make_uint2(A16::pack2(a0, a1), A16::pack2(a2, a3));
+            *reinterpret_cast<uint2 *>(yit + row * PWH_LD + 4 * c4) = ok ? ri[i] : make_uint2(0u, 0u);
+        }
+        __syncthreads();
+        if (ti + gridDim.x < ntiles) issue(ti + gridDim.x);
+        // ---- dX = dy . W
+        {
+            const int rbase = 32 * rh;
+            floatx16 acc = {0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(dyt + (rbase + r) * PWH_LD + 16 * t + 8 * h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wt[t], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const float yv = (float)yit[prow * PWH_LD + 32 * n + r];
+                const float d = A16::round1(fmaf(yv, sci, sfi) > 0.f ? acc[reg] : 0.f);
+                otile[prow * PW_LD + 32 * n + r] = d;
+                st1 += d;
+                st2 = fmaf(d, (yv - mui) * rsi, st2);
+            }
+        }
+        // ---- dW[j][k] += sum_p dy[p][j] * a[p][k]   (K = the tile's 64 pixels, 4 k-steps, transposing LDS reads)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 dyop = tr_operand(dyt, 16 * t, 32 * rh, lane);
+            const bf16x8 aop = tr_operand(at, 16 * t, 32 * n, lane);
+            dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dyop, aop, dwacc, 0, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 4) + 16 * i;
+            if (p0 + row < M)
+                A16::st4(g_in + (size_t)(p0 + row) * 64 + 4 * c4, *reinterpret_cast<const float4 *>(otile + row * PW_LD + 4 * c4));
+        }
+    }
+    st1 += __shfl_xor(st1, 32);
+    st2 += __shfl_xor(st2, 32);
+    __syncthreads();
+    float *shs = otile;  // [wave][kind][32]
+    if (h == 0) {
+        shs[wv * 64 + r] = st1;
+        shs[wv * 64 + 32 + r] = st2;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int kind = tid >> 6, c = tid & 63, nn = c >> 5, rr = c & 31;
+        stat_partials[(size_t)blockIdx.x * 128 + tid] = shs[nn * 64 + kind * 32 + rr] + shs[(2 + nn) * 64 + kind * 32 + rr];
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int j = 32 * rh + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        dw_partials[(size_t)blockIdx.x * 4096 + j * 64 + 32 * n + r] = dwacc[reg];
+    }
+}
+
 // -------------------------------------------------------------------------------- depthwise
 struct DwGeom {
     int B, H, W, ncs, nseg, hs_len;
@@ -493,6 +654,26 @@ int check_act_b(const char *who, int act_dtype) {
     return WW_OK;
 }
 
+int launch_pw_bwd_bf16(ww_ctx *ctx, const void *g, const float *dpool, const void *y_out, const float *ss_out,
+                       const float *coef, const void *y_in, const float *ss_in, const float *mr_in, const float *w, long M,
+                       int HW, void *g_in, float *stat, float *dwp, int *grid_out, hipStream_t st) {
+    typedef const ww_bf16 *cp;
+    const long ntiles = (M + PWB_TILE - 1) / PWB_TILE;
+    int grid;
+    ww_prof_scope ps_(ctx, WW_K_PW_BWD, st);
+    if (g) {
+        grid = ww_occupancy_grid((const void *)k_pw_bwd_bf16<false>, 256, 0, ntiles, WW_DW_SLAB_ROWS);
+        hipLaunchKernelGGL(k_pw_bwd_bf16<false>, dim3(grid), dim3(256), 0, st, (cp)g, dpool, (cp)y_out, ss_out, coef,
+                           (cp)y_in, ss_in, mr_in, w, M, HW, (ww_bf16 *)g_in, stat, dwp);
+    } else {
+        grid = ww_occupancy_grid((const void *)k_pw_bwd_bf16<true>, 256, 0, ntiles, WW_DW_SLAB_ROWS);
+        hipLaunchKernelGGL(k_pw_bwd_bf16<true>, dim3(grid), dim3(256), 0, st, (cp)g, dpool, (cp)y_out, ss_out, coef,
+                           (cp)y_in, ss_in, mr_in, w, M, HW, (ww_bf16 *)g_in, stat, dwp);
+    }
+    *grid_out = grid;
+    return WW_OK;
+}
+
 template <typename T>
 int launch_pw_bwd(ww_ctx *ctx, const void *g, const float *dpool, const void *y_out, const float *ss_out,
                   const float *coef, const void *y_in, const float *ss_in, const float *mr_in, const float *w, long M,
@@ -557,8 +738,8 @@ extern "C" int ww_pwconv1x1_bwd(ww_ctx *ctx, int act_dtype, const void *g, const
     float *stat = (float *)scratch, *dwp = stat + WW_STAT_SLAB_FLOATS;
     int grid = 0;
     rc = act_dtype == WW_ACT_BF16
-             ? launch_pw_bwd<ww_bf16>(ctx, g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, w, M, H * W, g_in, stat, dwp,
-                                      &grid, st)
+             ? launch_pw_bwd_bf16(ctx, g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, w, M, H * W, g_in, stat, dwp,
+                                  &grid, st)
              : launch_pw_bwd<float>(ctx, g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, w, M, H * W, g_in, stat, dwp,
                                     &grid, st);
     if (rc) return rc;

@@ -309,6 +309,109 @@ __global__ __launch_bounds__(256) void k_pw_fwd(const T *__restrict__ yin, const
     }
 }
 
+// ---- bf16 mode: the same GEMM on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate, so the kernel is purely
+// HBM-bound).  LDS tile holds relu(bn(y_in)) as bf16 with 144-byte rows (conflict-free ds_read_b128 fragments);
+// lane (r,h) of k-step t reads channels 16t+8h .. +7 of pixel r.  Weights are rounded to bf16 once per kernel
+// (what autocast does to conv weights); accumulation is fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int PWH_LD = 72;      // bf16 elements per LDS row (64 + 8 pad = 144 B)
+
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    return __builtin_convertvector(f, bf16x8);
+}
+
+__global__ __launch_bounds__(256) void k_pw_fwd_bf16(const ww_bf16 *__restrict__ yin, const float *__restrict__ ss,
+                                                     const float *__restrict__ w, long M, ww_bf16 *__restrict__ y,
+                                                     float *__restrict__ partials) {
+    extern __shared__ __align__(16) unsigned char pwh_lds[];
+    ww_bf16 *atile = reinterpret_cast<ww_bf16 *>(pwh_lds);                       // [128][72] bf16
+    float *otile = reinterpret_cast<float *>(pwh_lds + PW_TILE * PWH_LD * 2);    // [128][68] fp32
+    typedef Act<ww_bf16> A16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int rh = wv >> 1, n = wv & 1;
+    // B operand of k-step t: B[k = 16t + 8h + j][col r] = w[32n + r][16t + 8h + j]
+    bf16x8 wb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w[(size_t)(32 * n + r) * 64 + 16 * t + 8 * h + j];
+        wb[t] = pack8(v);
+    }
+    const int c4 = tid & 15;
+    const float4 sc = *reinterpret_cast<const float4 *>(ss + 4 * c4);
+    const float4 sf = *reinterpret_cast<const float4 *>(ss + 64 + 4 * c4);
+    float s1 = 0.f, s2 = 0.f;
+    const long ntiles = (M + PW_TILE - 1) / PW_TILE;
+    A16::raw4 raw[8];
+    auto issue = [&](long ti) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            long p = ti * PW_TILE + (tid >> 4) + 16 * i;
+            p = p < M ? p : M - 1;
+            raw[i] = A16::ldraw4(yin + (size_t)p * 64 + 4 * c4);
+        }
+    };
+    if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
+    for (long ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+        const long p0 = ti * PW_TILE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (tid >> 4) + 16 * i;
+            const bool ok = p0 + row < M;
+            const float4 v = A16::cvt4(raw[i]);
+            const float a0 = ok ? bnrelu(v.x, sc.x, sf.x) : 0.f, a1 = ok ? bnrelu(v.y, sc.y, sf.y) : 0.f;
+            const float a2 = ok ? bnrelu(v.z, sc.z, sf.z) : 0.f, a3 = ok ? bnrelu(v.w, sc.w, sf.w) : 0.f;
+            *reinterpret_cast<uint2 *>(atile + row * PWH_LD + 4 * c4) = make_uint2(A16::pack2(a0, a1), A16::pack2(a2, a3));
+        }
+        __syncthreads();
+        if (ti + gridDim.x < ntiles) issue(ti + gridDim.x);
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int rbase = 64 * rh + 32 * t2;
+            floatx16 acc = {0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(atile + (rbase + r) * PWH_LD + 16 * t + 8 * h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wb[t], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const float v = A16::round1(acc[reg]);
+                otile[prow * PW_LD + 32 * n + r] = v;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (tid >> 4) + 16 * i;
+            if (p0 + row < M)
+                A16::st4(y + (size_t)(p0 + row) * 64 + 4 * c4, *reinterpret_cast<const float4 *>(otile + row * PW_LD + 4 * c4));
+        }
+    }
+    if (partials) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        __syncthreads();
+        float *sh = otile;  // [wave][kind][32]
+        if (h == 0) {
+            sh[wv * 64 + r] = s1;
+            sh[wv * 64 + 32 + r] = s2;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int kind = tid >> 6, c = tid & 63, nn = c >> 5, rr = c & 31;
+            partials[(size_t)blockIdx.x * 128 + tid] = sh[nn * 64 + kind * 32 + rr] + sh[(2 + nn) * 64 + kind * 32 + rr];
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------- GAP
 // pool[b] = [sum relu(z) (64) | sum_{z>0} yhat (64) | count_{z>0} (64)]
 // one 1024-thread workgroup per clip (32 pixel slots): 32 waves/CU keep enough loads in flight for a pure read
@@ -422,6 +525,21 @@ int launch_dw_fwd(ww_ctx *ctx, const void *y_in, const float *ss_in, const float
     return WW_OK;
 }
 
+int launch_pw_fwd_bf16(ww_ctx *ctx, const void *y_in, const float *ss_in, const float *w, long M, void *y,
+                       float *partials, int *grid_out, hipStream_t st) {
+    const long ntiles = (M + PW_TILE - 1) / PW_TILE;
+    const size_t smem = (size_t)PW_TILE * PWH_LD * 2 + (size_t)PW_TILE * PW_LD * sizeof(float);
+    const int grid = ww_occupancy_grid((const void *)k_pw_fwd_bf16, 256, smem, ntiles, WW_MAX_PARTIALS);
+    {
+        ww_prof_scope ps_(ctx, WW_K_PW_FWD, st);
+        hipLaunchKernelGGL(k_pw_fwd_bf16, dim3(grid), dim3(256), smem, st, (const ww_bf16 *)y_in, ss_in, w, M,
+                           (ww_bf16 *)y, partials);
+    }
+    WW_LAUNCH_CHECK();
+    *grid_out = grid;
+    return WW_OK;
+}
+
 template <typename T>
 int launch_pw_fwd(ww_ctx *ctx, const void *y_in, const float *ss_in, const float *w, long M, void *y, float *partials,
                   int *grid_out, hipStream_t st) {
@@ -489,7 +607,7 @@ extern "C" int ww_pwconv1x1_fwd(ww_ctx *ctx, int act_dtype, const void *y_in, co
     hipStream_t st = (hipStream_t)stream;
     float *partials = bn->training ? (float *)scratch : nullptr;
     int grid = 0;
-    rc = act_dtype == WW_ACT_BF16 ? launch_pw_fwd<ww_bf16>(ctx, y_in, ss_in, w, M, y, partials, &grid, st)
+    rc = act_dtype == WW_ACT_BF16 ? launch_pw_fwd_bf16(ctx, y_in, ss_in, w, M, y, partials, &grid, st)
                                   : launch_pw_fwd<float>(ctx, y_in, ss_in, w, M, y, partials, &grid, st);
     if (rc) return rc;
     return finish_bn(ctx, partials, grid, (double)M, bn, ss_out, mr_out, st);
