@@ -129,8 +129,10 @@ def main():
     model = create_model("cnn_small", num_classes=2, pretrained=False, dropout=cfg.model.dropout,
                          act_dtype="bf16" if args.dtype == "bf16" else "fp32")
     esz = 2 if args.dtype == "bf16" else 4
+    import contextlib
     import tempfile
-    trainer = Trainer(model, [], [], cfg, checkpoint_dir=Path(tempfile.mkdtemp(prefix="wwbench_")), device=dev)
+    with contextlib.redirect_stdout(sys.stderr):          # stdout carries exactly ONE JSON line
+        trainer = Trainer(model, [], [], cfg, checkpoint_dir=Path(tempfile.mkdtemp(prefix="wwbench_")), device=dev)
     # a few distinct synthetic batches, generated on the device, rank-specific seeds (weak scaling)
     pool = [make_synthetic_batch(args.batch, N_SAMPLES, seed=1234 + 97 * rank + i, device=dev) for i in range(4)]
     trainer.model.train()

@@ -485,7 +485,7 @@ __device__ __forceinline__ void dwb_row(const typename Act<T>::raw2 (&yc)[4], T 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_dw_bwd(const T *__restrict__ g, const T *__restrict__ y_out,
+__global__ __launch_bounds__(256, Act<T>::is_f32 ? 2 : 3) void k_dw_bwd(const T *__restrict__ g, const T *__restrict__ y_out,
                                                 const float *__restrict__ coef, const T *__restrict__ y_in,
                                                 const float *__restrict__ ss_in, const float *__restrict__ mr_in,
                                                 const float *__restrict__ w, DwGeom gm, T *__restrict__ g_in,
@@ -530,22 +530,26 @@ __global__ __launch_bounds__(256) void k_dw_bwd(const T *__restrict__ g, const T
         dwb_finish<T>(rg, ry, hs, w0, gm.H, gm.W, cA, cB, cC, rows[1]);
         dwb_issue<T>(gimg, yoimg, hs + 1, w0, gm.H, gm.W, cl, ag, ay);
         dwb_issue_centre<T>(yiimg, hs, w0, gm.H, gm.W, cl, ayc);
+#pragma unroll 1
+        for (int i0 = 0; i0 < DW_HS; i0 += 3) {
 #pragma unroll
-        for (int i = 0; i < DW_HS; ++i) {
+          for (int ii = 0; ii < 3; ++ii) {
+            const int i = i0 + ii;           // i % 3 == ii: the row rotation stays compile-time
             const int h = hs + i;
             if (h < he) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) { rg[c] = ag[c]; ry[c] = ay[c]; }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) yc[c] = ayc[c];
-                if (i + 1 < DW_HS) {
+                if (h + 1 < he) {
                     dwb_issue<T>(gimg, yoimg, h + 2, w0, gm.H, gm.W, cl, ag, ay);
                     dwb_issue_centre<T>(yiimg, h + 1, w0, gm.H, gm.W, cl, ayc);
                 }
-                dwb_finish<T>(rg, ry, h + 1, w0, gm.H, gm.W, cA, cB, cC, rows[(i + 2) % 3]);
-                dwb_row<T>(yc, giimg, h, w0, gm.W, cl, rows[(i + 2) % 3], rows[(i + 1) % 3], rows[i % 3], wa, wb, sc, sf, mu,
+                dwb_finish<T>(rg, ry, h + 1, w0, gm.H, gm.W, cA, cB, cC, rows[(ii + 2) % 3]);
+                dwb_row<T>(yc, giimg, h, w0, gm.W, cl, rows[(ii + 2) % 3], rows[(ii + 1) % 3], rows[ii % 3], wa, wb, sc, sf, mu,
                         rsd, dwa, dwb, s1a, s1b, s2a, s2b);
             }
+          }
         }
     }
     // statistics partial
@@ -580,7 +584,9 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const
                                                   const float *__restrict__ coef, const float *__restrict__ x, int B,
                                                   int Hin, int Win, int Ho, int Wo, float *__restrict__ dw_partials) {
     __shared__ float sh[8 * 576];
+    extern __shared__ float xs[];            // [3][Win + 2] zero-padded input rows (see k_stem_fwd)
     const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
+    const int ld = Win + 2;
     const float2 cA = *reinterpret_cast<const float2 *>(coef + 2 * cl);
     const float2 cB = *reinterpret_cast<const float2 *>(coef + 64 + 2 * cl);
     const float2 cC = *reinterpret_cast<const float2 *>(coef + 128 + 2 * cl);
@@ -591,6 +597,13 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const
     for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int b = (int)(row / Ho), oh = (int)(row - (long)b * Ho);
         const float *xb = x + (size_t)b * Hin * Win;
+        __syncthreads();
+        for (int i = tid; i < 3 * ld; i += 256) {
+            const int kh = i / ld, c = i - kh * ld;
+            const int ih = 2 * oh - 1 + kh, iw = c - 1;
+            xs[i] = (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+        }
+        __syncthreads();
         for (int ow = slot; ow < Wo; ow += 8) {
             const size_t o = ((size_t)row * Wo + ow) * 64 + 2 * cl;
             const float2 gz = Act<T>::cvt2(Act<T>::ldraw2(g + o));
@@ -598,16 +611,13 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const
             const float d0 = fmaf(cA.x, gz.x, fmaf(cB.x, yo.x, cC.x));
             const float d1 = fmaf(cA.y, gz.y, fmaf(cB.y, yo.y, cC.y));
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int ih = 2 * oh - 1 + kh;
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const int iw = 2 * ow - 1 + kw;
-                    const float v = (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+                    const float v = xs[kh * ld + 2 * ow + kw];
                     dwa[kh * 3 + kw] = fmaf(d0, v, dwa[kh * 3 + kw]);
                     dwb[kh * 3 + kw] = fmaf(d1, v, dwb[kh * 3 + kw]);
                 }
-            }
         }
     }
 #pragma unroll
@@ -712,9 +722,10 @@ int launch_stem_bwd(ww_ctx *ctx, const void *g, const void *y_out, const float *
                     int Win, float *dwp, int *grid_out, hipStream_t st) {
     const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
     const long nrows = (long)B * Ho;
-    const int grid = ww_occupancy_grid((const void *)k_stem_bwd<T>, 256, 0, nrows, WW_MAX_PARTIALS);
+    const size_t smem = (size_t)3 * (Win + 2) * sizeof(float);
+    const int grid = ww_occupancy_grid((const void *)k_stem_bwd<T>, 256, smem, nrows, WW_MAX_PARTIALS);
     ww_prof_scope ps_(ctx, WW_K_STEM_BWD, st);
-    hipLaunchKernelGGL(k_stem_bwd<T>, dim3(grid), dim3(256), 0, st, (const T *)g, (const T *)y_out, coef, x, B, Hin, Win,
+    hipLaunchKernelGGL(k_stem_bwd<T>, dim3(grid), dim3(256), smem, st, (const T *)g, (const T *)y_out, coef, x, B, Hin, Win,
                        Ho, Wo, dwp);
     *grid_out = grid;
     return WW_OK;

@@ -47,13 +47,17 @@ __device__ __forceinline__ void reduce_stats_slots(float s0, float s1, float q0,
 }
 
 // ------------------------------------------------------------------------------------- stem
-// x (B,Hin,Win) -> y (B,Ho,Wo,64) ; 3x3 stride 2 pad 1 ; one (b,oh) output row per iteration
+// x (B,Hin,Win) -> y (B,Ho,Wo,64) ; 3x3 stride 2 pad 1 ; one (b,oh) output row per iteration.
+// The three input rows are staged zero-padded in LDS, so the inner loop is 9 LDS broadcast reads + 18 FMAs per
+// pixel (the first version re-derived bounds per tap from global memory and was instruction-issue-bound).
 template <typename T>
 __global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ x, const float *__restrict__ w, int B,
                                                   int Hin, int Win, int Ho, int Wo, T *__restrict__ y,
                                                   float *__restrict__ partials) {
     __shared__ float sh[8 * 128];
+    extern __shared__ float xs[];            // [3][Win + 2] : xs[kh][iw + 1], zero outside the image
     const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
+    const int ld = Win + 2;
     float w0[9], w1[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -65,19 +69,23 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ x, c
     for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int b = (int)(row / Ho), oh = (int)(row - (long)b * Ho);
         const float *xb = x + (size_t)b * Hin * Win;
+        __syncthreads();                     // previous row's readers are done
+        for (int i = tid; i < 3 * ld; i += 256) {
+            const int kh = i / ld, c = i - kh * ld;
+            const int ih = 2 * oh - 1 + kh, iw = c - 1;
+            xs[i] = (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+        }
+        __syncthreads();
         for (int ow = slot; ow < Wo; ow += 8) {
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int ih = 2 * oh - 1 + kh;
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const int iw = 2 * ow - 1 + kw;
-                    const float v = (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+                    const float v = xs[kh * ld + 2 * ow + kw];
                     a0 = fmaf(v, w0[kh * 3 + kw], a0);
                     a1 = fmaf(v, w1[kh * 3 + kw], a1);
                 }
-            }
             const float2 o = Act<T>::round2(make_float2(a0, a1));
             Act<T>::st2(y + ((size_t)row * Wo + ow) * 64 + 2 * cl, o);
             s0 += o.x; s1 += o.y;
@@ -180,17 +188,21 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const T *__restrict__ yin, const
         dw_issue_row<T>(img, hs, w0, g.H, g.W, cl, raw);
         dw_finish_row<T>(raw, hs, w0, g.H, g.W, sc, sf, rows[1]);
         dw_issue_row<T>(img, hs + 1, w0, g.H, g.W, cl, ahead);
+#pragma unroll 1
+        for (int i0 = 0; i0 < DW_HS; i0 += 3) {
 #pragma unroll
-        for (int i = 0; i < DW_HS; ++i) {
+          for (int ii = 0; ii < 3; ++ii) {
+            const int i = i0 + ii;           // i % 3 == ii: the row rotation stays compile-time
             const int h = hs + i;
             if (h < he) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) raw[c] = ahead[c];
-                if (i + 1 < DW_HS) dw_issue_row<T>(img, h + 2, w0, g.H, g.W, cl, ahead);   // one row ahead of its use
-                dw_finish_row<T>(raw, h + 1, w0, g.H, g.W, sc, sf, rows[(i + 2) % 3]);
-                dw_out_row<T>(oimg, h, w0, g.W, cl, rows[i % 3], rows[(i + 1) % 3], rows[(i + 2) % 3], wa, wb, s0, s1, q0,
-                           q1);
+                if (h + 1 < he) dw_issue_row<T>(img, h + 2, w0, g.H, g.W, cl, ahead);   // one row ahead of its use
+                dw_finish_row<T>(raw, h + 1, w0, g.H, g.W, sc, sf, rows[(ii + 2) % 3]);
+                dw_out_row<T>(oimg, h, w0, g.W, cl, rows[ii % 3], rows[(ii + 1) % 3], rows[(ii + 2) % 3], wa, wb, s0, s1,
+                              q0, q1);
             }
+          }
         }
     }
     if (partials) reduce_stats_slots(s0, s1, q0, q1, sh, partials + (size_t)blockIdx.x * 128);
@@ -501,10 +513,11 @@ int launch_stem_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int Hin,
                     int *grid_out, hipStream_t st) {
     const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
     const long nrows = (long)B * Ho;
-    const int grid = ww_occupancy_grid((const void *)k_stem_fwd<T>, 256, 0, nrows, WW_MAX_PARTIALS);
+    const size_t smem = (size_t)3 * (Win + 2) * sizeof(float);
+    const int grid = ww_occupancy_grid((const void *)k_stem_fwd<T>, 256, smem, nrows, WW_MAX_PARTIALS);
     {
         ww_prof_scope ps_(ctx, WW_K_STEM_FWD, st);
-        hipLaunchKernelGGL(k_stem_fwd<T>, dim3(grid), dim3(256), 0, st, x, w, B, Hin, Win, Ho, Wo, (T *)y, partials);
+        hipLaunchKernelGGL(k_stem_fwd<T>, dim3(grid), dim3(256), smem, st, x, w, B, Hin, Win, Ho, Wo, (T *)y, partials);
     }
     WW_LAUNCH_CHECK();
     *grid_out = grid;
