@@ -38,6 +38,7 @@ __global__ __launch_bounds__(1024) void k_head_bwd(const float *__restrict__ dlo
     const float w0 = fc_w[c], w1 = fc_w[64 + c];
     const float inv_hw = 1.0f / (float)HW;
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
     for (int b = part; b < B; b += 16) {
         const float dl0 = dlogits[(size_t)b * 2], dl1 = dlogits[(size_t)b * 2 + 1];
         const float pv = pd[(size_t)b * 64 + c];
@@ -723,7 +724,8 @@ int launch_stem_bwd(ww_ctx *ctx, const void *g, const void *y_out, const float *
     const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
     const long nrows = (long)B * Ho;
     const size_t smem = (size_t)3 * (Win + 2) * sizeof(float);
-    const int grid = ww_occupancy_grid((const void *)k_stem_bwd<T>, 256, smem, nrows, WW_MAX_PARTIALS);
+    // only the weight-gradient slab is used (576 columns): room for 2048 rows -> full occupancy
+    const int grid = ww_occupancy_grid((const void *)k_stem_bwd<T>, 256, smem, nrows, 2048);
     ww_prof_scope ps_(ctx, WW_K_STEM_BWD, st);
     hipLaunchKernelGGL(k_stem_bwd<T>, dim3(grid), dim3(256), smem, st, (const T *)g, (const T *)y_out, coef, x, B, Hin, Win,
                        Ho, Wo, dwp);
@@ -756,9 +758,7 @@ extern "C" int ww_pwconv1x1_bwd(ww_ctx *ctx, int act_dtype, const void *g, const
     if (rc) return rc;
     WW_LAUNCH_CHECK();
     ww_prof_scope pf_(ctx, WW_K_FINALIZE, st);
-    rc = ww_launch_bn_bwd_finalize(stat, grid, (double)M, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, st);
-    if (rc) return rc;
-    return ww_launch_colsum(dwp, grid, 4096, dw, st);
+    return ww_launch_bwd_finalize(stat, grid, (double)M, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, dwp, 4096, dw, st);
 }
 
 extern "C" int ww_dwconv3x3_bwd(ww_ctx *ctx, int act_dtype, const void *g, const void *y_out, const float *coef,
@@ -786,9 +786,8 @@ extern "C" int ww_dwconv3x3_bwd(ww_ctx *ctx, int act_dtype, const void *g, const
     if (rc) return rc;
     WW_LAUNCH_CHECK();
     ww_prof_scope pf_(ctx, WW_K_FINALIZE, st);
-    rc = ww_launch_bn_bwd_finalize(stat, grid, (double)B * H * W, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, st);
-    if (rc) return rc;
-    return ww_launch_colsum(dwp, grid, 576, dw, st);
+    return ww_launch_bwd_finalize(stat, grid, (double)B * H * W, gamma_in, mr_in, coef_in, dgamma_in, dbeta_in, dwp, 576,
+                                  dw, st);
 }
 
 extern "C" int ww_conv_stem_bwd(ww_ctx *ctx, int act_dtype, const void *g, const void *y_out, const float *coef,

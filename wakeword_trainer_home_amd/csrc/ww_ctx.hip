@@ -248,12 +248,11 @@ __global__ void k_bn_eval_ss(ww_bn_t bn, float *__restrict__ ss, float *__restri
 // BatchNorm2d backward reduction: partial columns = [sum dz (64) | sum dz*yhat (64)].
 //   dgamma = sum dz*yhat, dbeta = sum dz,
 //   dy = gamma*rstd*(dz - mean(dz) - yhat*mean(dz*yhat))  ==  A*dz + Bc*y + Cc
-__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restrict__ partials, int rows,
-                                                          double count, const float *__restrict__ gamma,
-                                                          const float *__restrict__ mr, float *__restrict__ coef,
-                                                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    __shared__ double sh[32 * 128];
-    __shared__ double tot[128];
+__device__ __forceinline__ void bn_bwd_finalize_body(const float *__restrict__ partials, int rows, double count,
+                                                     const float *__restrict__ gamma, const float *__restrict__ mr,
+                                                     float *__restrict__ coef, float *__restrict__ dgamma,
+                                                     float *__restrict__ dbeta, double *sh /*32*128*/,
+                                                     double *tot /*128*/) {
     double t = ww_col128_sum(partials, rows, sh);
     if (threadIdx.x < 128) tot[threadIdx.x] = t;
     __syncthreads();
@@ -271,13 +270,21 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restric
     }
 }
 
+__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restrict__ partials, int rows,
+                                                          double count, const float *__restrict__ gamma,
+                                                          const float *__restrict__ mr, float *__restrict__ coef,
+                                                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ double sh[32 * 128];
+    __shared__ double tot[128];
+    bn_bwd_finalize_body(partials, rows, count, gamma, mr, coef, dgamma, dbeta, sh, tot);
+}
+
 // generic column sum: out[col] = sum_r partials[r][col]; block = 64 columns (16 float4 groups) x 64 row parts.
 // cols must be a multiple of 4 (576 and 4096 here).
-__global__ __launch_bounds__(1024) void k_colsum(const float *__restrict__ partials, int rows, int cols,
-                                                 float *__restrict__ out) {
-    __shared__ double sh[64 * 64];
+__device__ __forceinline__ void colsum_body(const float *__restrict__ partials, int rows, int cols,
+                                            float *__restrict__ out, int blk, double *sh /*64*64*/) {
     const int c4 = threadIdx.x & 15, part = threadIdx.x >> 4;
-    const int col = blockIdx.x * 64 + 4 * c4;
+    const int col = blk * 64 + 4 * c4;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (col < cols) {
 #pragma unroll 4
@@ -289,12 +296,33 @@ __global__ __launch_bounds__(1024) void k_colsum(const float *__restrict__ parti
     sh[part * 64 + 4 * c4] = a0; sh[part * 64 + 4 * c4 + 1] = a1;
     sh[part * 64 + 4 * c4 + 2] = a2; sh[part * 64 + 4 * c4 + 3] = a3;
     __syncthreads();
-    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < cols) {
+    if (threadIdx.x < 64 && blk * 64 + threadIdx.x < cols) {
         double t = 0.0;
 #pragma unroll 8
         for (int p = 0; p < 64; ++p) t += sh[p * 64 + threadIdx.x];
-        out[blockIdx.x * 64 + threadIdx.x] = (float)t;
+        out[blk * 64 + threadIdx.x] = (float)t;
     }
+}
+
+__global__ __launch_bounds__(1024) void k_colsum(const float *__restrict__ partials, int rows, int cols,
+                                                 float *__restrict__ out) {
+    __shared__ double sh[64 * 64];
+    colsum_body(partials, rows, cols, out, blockIdx.x, sh);
+}
+
+// one launch for a backward layer's two reductions: block 0 = BatchNorm-backward constants of the input layer,
+// blocks 1.. = column sums of the weight-gradient slab
+__global__ __launch_bounds__(1024) void k_bwd_finalize(const float *__restrict__ stat, int rows, double count,
+                                                       const float *__restrict__ gamma, const float *__restrict__ mr,
+                                                       float *__restrict__ coef, float *__restrict__ dgamma,
+                                                       float *__restrict__ dbeta, const float *__restrict__ dwp,
+                                                       int cols, float *__restrict__ dw) {
+    __shared__ double sh[64 * 64];
+    __shared__ double tot[128];
+    if (blockIdx.x == 0)
+        bn_bwd_finalize_body(stat, rows, count, gamma, mr, coef, dgamma, dbeta, sh, tot);
+    else
+        colsum_body(dwp, rows, cols, dw, blockIdx.x - 1, sh);
 }
 
 int ww_launch_bn_fwd_finalize(const float *partials, int rows, double count, const ww_bn_t *bn, float *ss_out,
@@ -312,6 +340,14 @@ int ww_launch_bn_bwd_finalize(const float *partials, int rows, double count, con
                               const float *mr, float *coef_out, float *dgamma, float *dbeta, hipStream_t st) {
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(1024), 0, st, partials, rows, count, gamma, mr, coef_out,
                        dgamma, dbeta);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+int ww_launch_bwd_finalize(const float *stat, int rows, double count, const float *gamma, const float *mr,
+                           float *coef, float *dgamma, float *dbeta, const float *dwp, int cols, float *dw,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(k_bwd_finalize, dim3(1 + (cols + 63) / 64), dim3(1024), 0, st, stat, rows, count, gamma, mr, coef,
+                       dgamma, dbeta, dwp, cols, dw);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

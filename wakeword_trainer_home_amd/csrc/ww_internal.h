@@ -103,6 +103,9 @@ int ww_launch_bn_eval_ss(const ww_bn_t *bn, float *ss_out, float *mr_out, hipStr
 int ww_launch_bn_bwd_finalize(const float *partials, int rows, double count, const float *gamma,
                               const float *mr, float *coef_out, float *dgamma, float *dbeta, hipStream_t st);
 int ww_launch_colsum(const float *partials, int rows, int cols, float *out, hipStream_t st);
+int ww_launch_bwd_finalize(const float *stat, int rows, double count, const float *gamma, const float *mr,
+                           float *coef, float *dgamma, float *dbeta, const float *dwp, int cols, float *dw,
+                           hipStream_t st);
 
 int ww_occupancy_grid(const void *fn, int block, size_t smem, long want, int cap);
 

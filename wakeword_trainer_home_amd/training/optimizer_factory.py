@@ -70,7 +70,9 @@ def create_optimizer(model: nn.Module, optimizer_name: str = "adam", learning_ra
     if not all(0 <= b <= 1 for b in betas):
         raise ValueError(f"Betas must be in [0, 1], got {betas}")
     name = optimizer_name.lower()
-    params = model.parameters()
+    params = list(model.parameters())
+    if name in ("adam", "adamw") and "fused" not in kwargs and params and all(p.is_cuda for p in params):
+        kwargs["fused"] = True        # one multi-tensor kernel per step instead of ~9 (same update rule)
     if name == "adam":
         return optim.Adam(params, lr=learning_rate, betas=betas, weight_decay=weight_decay, **kwargs)
     if name == "adamw":
