@@ -137,11 +137,13 @@ def main():
     pool = [make_synthetic_batch(args.batch, N_SAMPLES, seed=1234 + 97 * rank + i, device=dev) for i in range(4)]
     trainer.model.train()
 
+    last_done = [None]
+
     def step(i):
         wave, y = pool[i % len(pool)]
-        r = trainer._step_native(wave, y, i)
-        trainer.state.global_step += 1
-        return r
+        for done in trainer._step_native(wave, y, i):     # results arrive one step late (deferred_metrics)
+            trainer.state.global_step += 1
+            last_done[0] = done
 
     def fence():
         if world > 1:
@@ -159,10 +161,12 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    last = None
     for i in range(args.steps):
-        last = step(args.warmup + i)
+        step(args.warmup + i)
+    for done in trainer._flush_pending():
+        last_done[0] = done
     fence()
+    last = None if last_done[0] is None else (last_done[0][1], last_done[0][2])
     dt = time.perf_counter() - t0
     prof = nat.prof_collect(dev)
     nat.prof_enable(dev, [])

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 2
+#define WW_ABI_VERSION 3
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -191,6 +191,11 @@ typedef struct {
     int32_t nonfinite;  /* != 0 if the loss is not finite (trainer.py:177) */
     int32_t bad_target; /* != 0 if any target is outside [0,2) (losses.py:72) */
     int32_t count;      /* B */
+    float found_inf;    /* 1.0 if this step must not update parameters (non-finite loss, bad target, or -- after
+                           ww_grad_norm_clip -- non-finite gradient norm), else 0.0.  Layout-compatible with the
+                           `found_inf` tensor of PyTorch's fused optimizers, so the reference's "skip the batch"
+                           (trainer.py:177-179) needs no host round trip before optimizer.step(). */
+    int32_t reserved;
 } ww_step_stats;
 int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64_t *targets, int B, int loss_kind,
                         float label_smoothing, float focal_alpha, float focal_gamma, float *loss_out,
@@ -199,7 +204,7 @@ int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64_t *targets
  * (src/training/optimizer_factory.py:446-452) on one flat gradient bucket.  max_norm <= 0:
  * only the norm is computed.  norm_out (nullable) receives the pre-clip L2 norm.          */
 int ww_grad_norm_clip(ww_ctx *ctx, float *flat_grads, size_t n, float max_norm, float *norm_out,
-                      ww_stream_t stream);
+                      ww_step_stats *stats /* nullable: grad_norm and found_inf are updated */, ww_stream_t stream);
 /* ------------------------------------------------------------------ measurement
  * Opt-in timing of kernel classes with hipEvents recorded on the launch stream around the
  * class's main kernel (bench.py's roofline leg; no reference counterpart -- the reference never

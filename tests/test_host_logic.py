@@ -298,7 +298,7 @@ def test_library_exports_the_whole_c_abi():
     nat_lib = _native.load()
     assert nat_lib.ww_abi_version() == _native.ABI_VERSION
     assert _native.num_frames(24000, 160) == 151
-    assert ctypes.sizeof(_native.StepStats) == 40
+    assert ctypes.sizeof(_native.StepStats) == 48
     # host-side pieces of the ABI follow the oracle's integer law
     from oracle.philox import philox4x32_10, prob_threshold
     assert _native.philox([1, 2, 3, 4], [5, 6]) == [int(v) for v in philox4x32_10(np.array([1, 2, 3, 4], np.uint64),

@@ -166,3 +166,59 @@ def test_feature_extractor_and_specaugment_api():
     spec = torch.randn(1, 64, 50, device=DEV)      # test_training_pipeline.py:259-262
     out = sa(spec)
     assert out.shape == spec.shape and (out == 0).any() and not (spec == 0).any()
+
+
+@pytest.mark.parametrize("deferred", [True, False])
+def test_nonfinite_batch_is_skipped_on_the_device(tmp_path, deferred):
+    """Reference semantics (trainer.py:177-179, Q5): a batch with a non-finite loss changes no parameter, fires no
+    on_batch_end, but still counts in the epoch-loss denominator.  Here the decision reaches the fused optimizer as
+    a device flag; with deferred_metrics the callbacks arrive one step late but complete and in order."""
+    from wakeword_trainer_home_amd.config import WakewordConfig
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    cfg = WakewordConfig()
+    cfg.training.epochs, cfg.optimizer.warmup_epochs = 1, 0
+    cfg.training.deferred_metrics = deferred
+    cfg.model.architecture = "cnn_small"
+    torch.manual_seed(1)
+    model = create_model("cnn_small", dropout=0.0)
+    x, y = make_inputs(21, 32)
+    bad = x[8:16].clone()
+    bad[3, 0, 5, 7] = float("nan")
+    badt = y[16:24].clone()
+    badt[2] = 5                                       # invalid target: the reference raises ValueError and skips
+    batches = [(x[0:8], y[0:8]), (bad, y[8:16]), (x[16:24], badt), (x[24:32], y[24:32])]
+    t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=tmp_path, device=DEV)
+    assert t.deferred_metrics == deferred and t._skip_on_device
+    seen = []
+    snaps = []
+
+    class CB:
+        def on_batch_end(self, idx, loss, acc):
+            seen.append(idx)
+            assert np.isfinite(loss)
+    t.add_callback(CB())
+    # step by step, snapshotting parameters after each launched step
+    t.model.train()
+    t.train_metrics_tracker.reset()
+    for i, (xi, yi) in enumerate(batches):
+        t._step_native(xi, yi, i)
+        torch.cuda.synchronize()
+        snaps.append(torch.cat([p.detach().flatten().clone() for p in t.model.parameters()]))
+    t._flush_pending()
+    assert not torch.equal(snaps[0], snaps[3])
+    assert torch.equal(snaps[0], snaps[1]), "NaN batch must not change the parameters"
+    assert torch.equal(snaps[1], snaps[2]), "invalid-target batch must not change the parameters"
+    assert torch.isfinite(snaps[3]).all()
+    # full epoch through the public API: callbacks for the 2 good batches only, denominator = 4
+    model2 = create_model("cnn_small", dropout=0.0)
+    t2 = Trainer(model2, batches, batches[:1], cfg, checkpoint_dir=tmp_path, device=DEV)
+    rec = _Rec()
+    t2.add_callback(rec)
+    avg, _ = t2.train_epoch(0)
+    assert len(rec.loss) == 2 and t2.state.global_step == 2
+    assert avg == pytest.approx(sum(rec.loss) / 4)
+    # a NaN input reaches the logits as in torch (ReLU propagates NaN): eval forward is NaN, not silently finite
+    model2.eval()
+    with torch.no_grad():
+        assert torch.isnan(model2(bad.to(DEV))).any()

@@ -13,7 +13,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ACT_F32, ACT_BF16 = 0, 1
 LOSS_CE, LOSS_FOCAL = 0, 1
 WAVE_F32, WAVE_I16 = 0, 1
@@ -42,7 +42,7 @@ class BN(C.Structure):
 class StepStats(C.Structure):
     _fields_ = [("loss", C.c_float), ("grad_norm", C.c_float), ("correct", C.c_int32), ("tp", C.c_int32),
                 ("tn", C.c_int32), ("fp", C.c_int32), ("fn", C.c_int32), ("nonfinite", C.c_int32),
-                ("bad_target", C.c_int32), ("count", C.c_int32)]
+                ("bad_target", C.c_int32), ("count", C.c_int32), ("found_inf", C.c_float), ("reserved", C.c_int32)]
 
 
 STEP_STATS_BYTES = C.sizeof(StepStats)
@@ -74,7 +74,7 @@ _SIGS = {
     "ww_cnn_small_bwd": (C.c_int, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i, _i, _i, _f, _u64, _u64, _u64,
                                    _vp, _sz, _vp]),
     "ww_ce2_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
-    "ww_grad_norm_clip": (C.c_int, [_vp, _vp, _sz, _f, _vp, _vp]),
+    "ww_grad_norm_clip": (C.c_int, [_vp, _vp, _sz, _f, _vp, _vp, _vp]),
     "ww_prof_num_classes": (C.c_int, []),
     "ww_prof_class_name": (C.c_char_p, [_i]),
     "ww_prof_enable": (C.c_int, [_vp, C.c_uint32]),
@@ -402,14 +402,19 @@ def ce2_loss_fwd_bwd(logits, targets, kind=LOSS_CE, label_smoothing=0.0, focal_a
     return loss, dl, stats
 
 
-def grad_norm_clip_(flat, max_norm, norm_out=None):
-    dev = _dev(flat, norm_out)
-    if norm_out is None:
+def grad_norm_clip_(flat, max_norm, norm_out=None, stats=None):
+    """clip_grad_norm_ on a flat bucket.  `stats` (uint8[STEP_STATS_BYTES], optional): its grad_norm / found_inf
+    fields are updated on the device."""
+    dev = _dev(flat, norm_out, stats)
+    if norm_out is None and stats is None:
         norm_out = torch.empty(1, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _check(load().ww_grad_norm_clip(ctx(dev), _p(flat), flat.numel(), float(max_norm), _p(norm_out), _stream(dev)),
-               "ww_grad_norm_clip")
+        _check(load().ww_grad_norm_clip(ctx(dev), _p(flat), flat.numel(), float(max_norm), _p(norm_out), _p(stats),
+                                        _stream(dev)), "ww_grad_norm_clip")
     return norm_out
+
+
+FOUND_INF_FLOAT_INDEX = StepStats.found_inf.offset // 4
 
 
 def prof_classes():

@@ -49,6 +49,7 @@ class TrainingConfig(_Section):
     checkpoint_frequency: str = "best_only"   # best_only | every_epoch | every_5_epochs | every_10_epochs
     save_best_only: bool = True
     data_parallel: bool = True                # all-reduce gradients when torch.distributed is initialised
+    deferred_metrics: bool = True             # HIP model: read a step's stats while the next step runs
 
 
 @dataclass

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const T *__restrict__ g, cons
         for (int s = 0; s < 32; ++s) {
             const int prow = 32 * h + s;
             const float dyv = dyt[prow * PW_LD + 32 * rh + r];
-            const float av = fmaxf(fmaf(yit[prow * PW_LD + 32 * n + r], sci, sfi), 0.f);
+            const float zv = fmaf(yit[prow * PW_LD + 32 * n + r], sci, sfi);
+            const float av = zv < 0.f ? 0.f : zv;
             dwacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dyv, av, dwacc, 0, 0, 0);
         }
         __syncthreads();
@@ -341,8 +342,10 @@ __global__ __launch_bounds__(256) void k_pw_bwd_bf16(const ww_bf16 *__restrict__
             const float d1 = ok ? fmaf(cA.y, dz.y, fmaf(cB.y, yo.y, cC.y)) : 0.f;
             const float d2 = ok ? fmaf(cA.z, dz.z, fmaf(cB.z, yo.z, cC.z)) : 0.f;
             const float d3 = ok ? fmaf(cA.w, dz.w, fmaf(cB.w, yo.w, cC.w)) : 0.f;
-            const float a0 = ok ? fmaxf(fmaf(yr.x, si.x, ti4.x), 0.f) : 0.f, a1 = ok ? fmaxf(fmaf(yr.y, si.y, ti4.y), 0.f) : 0.f;
-            const float a2 = ok ? fmaxf(fmaf(yr.z, si.z, ti4.z), 0.f) : 0.f, a3 = ok ? fmaxf(fmaf(yr.w, si.w, ti4.w), 0.f) : 0.f;
+            const float z0 = fmaf(yr.x, si.x, ti4.x), z1 = fmaf(yr.y, si.y, ti4.y);
+            const float z2 = fmaf(yr.z, si.z, ti4.z), z3 = fmaf(yr.w, si.w, ti4.w);
+            const float a0 = !ok || z0 < 0.f ? 0.f : z0, a1 = !ok || z1 < 0.f ? 0.f : z1;
+            const float a2 = !ok || z2 < 0.f ? 0.f : z2, a3 = !ok || z3 < 0.f ? 0.f : z3;
             *reinterpret_cast<uint2 *>(dyt + row * PWH_LD + 4 * c4) = make_uint2(A16::pack2(d0, d1), A16::pack2(d2, d3));
             *reinterpret_cast<uint2 *>(at + row * PWH_LD + 4 * c4) = make_uint2(A16::pack2(a0, a1), A16::pack2(a2, a3));
             *reinterpret_cast<uint2 *>(yit + row * PWH_LD + 4 * c4) = ok ? ri[i] : make_uint2(0u, 0u);
@@ -463,7 +466,7 @@ __device__ __forceinline__ void dwb_row(const typename Act<T>::raw2 (&yc)[4], T 
         if (w0 + i < W) {
             const float2 yv = Act<T>::cvt2(yc[i]);
             const float z0 = fmaf(yv.x, sc.x, sf.x), z1 = fmaf(yv.y, sc.y, sf.y);
-            const float a0 = fmaxf(z0, 0.f), a1 = fmaxf(z1, 0.f);
+            const float a0 = z0 < 0.f ? 0.f : z0, a1 = z1 < 0.f ? 0.f : z1;
             float d0 = 0.f, d1 = 0.f;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {

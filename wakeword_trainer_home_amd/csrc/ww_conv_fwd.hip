@@ -25,7 +25,11 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float bnrelu(float y, float s, float t) { return fmaxf(fmaf(y, s, t), 0.f); }
+// BatchNorm + ReLU on load.  ReLU propagates NaN like torch.relu (v_max would silently turn it into 0).
+__device__ __forceinline__ float bnrelu(float y, float s, float t) {
+    const float z = fmaf(y, s, t);
+    return z < 0.f ? 0.f : z;
+}
 
 // block-level reduction of per-lane channel statistics -> partial row [sum(64) | sumsq(64)]
 // lanes: cl = tid & 31 owns channels 2cl, 2cl+1 ; 8 pixel slots per 256-thread block
@@ -442,8 +446,10 @@ __global__ __launch_bounds__(1024) void k_gap_fwd(const T *__restrict__ y, const
     for (int p = slot; p < HW; p += 32) {
         const float2 v = Act<T>::cvt2(Act<T>::ldraw2(yb + (size_t)p * 64 + 2 * cl));
         const float z0 = fmaf(v.x, sc.x, sf.x), z1 = fmaf(v.y, sc.y, sf.y);
-        if (z0 > 0.f) { a0 += z0; h0 += (v.x - mu.x) * rs.x; c0 += 1.f; }
-        if (z1 > 0.f) { a1 += z1; h1 += (v.y - mu.y) * rs.y; c1 += 1.f; }
+        a0 += z0 < 0.f ? 0.f : z0;                       // NaN-propagating ReLU, as torch
+        a1 += z1 < 0.f ? 0.f : z1;
+        if (z0 > 0.f) { h0 += (v.x - mu.x) * rs.x; c0 += 1.f; }
+        if (z1 > 0.f) { h1 += (v.y - mu.y) * rs.y; c1 += 1.f; }
     }
     sh[slot * 192 + 2 * cl] = a0;        sh[slot * 192 + 2 * cl + 1] = a1;
     sh[slot * 192 + 64 + 2 * cl] = h0;   sh[slot * 192 + 64 + 2 * cl + 1] = h1;

@@ -362,7 +362,8 @@ int ww_launch_colsum(const float *partials, int rows, int cols, float *out, hipS
 // MobileNetV3-small; deterministic fixed-order reduction)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_grad_norm_clip(float *__restrict__ g, size_t n, float max_norm,
-                                                         float *__restrict__ norm_out) {
+                                                         float *__restrict__ norm_out,
+                                                         ww_step_stats *__restrict__ stats) {
     __shared__ double sh[1024];
     __shared__ float coef_sh;
     double acc = 0.0;
@@ -379,6 +380,10 @@ __global__ __launch_bounds__(1024) void k_grad_norm_clip(float *__restrict__ g, 
     if (threadIdx.x == 0) {
         const float norm = (float)sqrt(sh[0]);
         if (norm_out) *norm_out = norm;
+        if (stats) {
+            stats->grad_norm = norm;
+            if (!isfinite(norm)) stats->found_inf = 1.0f;
+        }
         float c = 1.0f;
         if (max_norm > 0.f) {
             c = max_norm / (norm + 1e-6f);   // torch: clamp(max_norm/(total_norm+1e-6), max=1)
@@ -393,12 +398,12 @@ __global__ __launch_bounds__(1024) void k_grad_norm_clip(float *__restrict__ g, 
 }
 
 extern "C" int ww_grad_norm_clip(ww_ctx *ctx, float *flat_grads, size_t n, float max_norm, float *norm_out,
-                                 ww_stream_t stream) {
+                                 ww_step_stats *stats, ww_stream_t stream) {
     WW_REQUIRE(ctx && flat_grads, WW_E_INVALID, "ww_grad_norm_clip: null argument");
     if (n == 0) return WW_OK;
     ww_prof_scope ps_(ctx, WW_K_CLIP, (hipStream_t)stream);
     hipLaunchKernelGGL(k_grad_norm_clip, dim3(1), dim3(1024), 0, (hipStream_t)stream, flat_grads, n, max_norm,
-                       norm_out);
+                       norm_out, stats);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

@@ -87,6 +87,9 @@ __global__ __launch_bounds__(1024) void k_ce2_loss(const float *__restrict__ log
             stats->nonfinite = isfinite(loss) ? 0 : 1;
             stats->bad_target = shc[5][0] ? 1 : 0;
             stats->count = B;
+            stats->grad_norm = 0.f;
+            stats->found_inf = (!isfinite(loss) || shc[5][0]) ? 1.0f : 0.0f;
+            stats->reserved = 0;
         }
     }
 }

@@ -125,7 +125,9 @@ class CNNSmallWakeword(nn.Module):
         self._pkey = key
         self._pptr = nat.ptr_array(tensors)
         self._plist = [t for t in tensors if isinstance(t, nn.Parameter)]
-        sizes = [(t.numel() + 3) // 4 * 4 for t in self._plist]
+        # no alignment padding: EVERY element of the bucket is rewritten by each backward, so a non-finite step
+        # (clip multiplies by NaN) cannot leave poison behind in never-written slots
+        sizes = [t.numel() for t in self._plist]
         self._flat_grad = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         views, off = {}, 0
         for t, n in zip(self._plist, sizes):
@@ -193,7 +195,7 @@ class CNNSmallWakeword(nn.Module):
             views, off, tens = {}, 0, self._ordered()
             for t in self._plist:
                 views[id(t)] = tmp[off:off + t.numel()].view_as(t)
-                off += (t.numel() + 3) // 4 * 4
+                off += t.numel()
             gptr = nat.ptr_array([views.get(id(t)) for t in tens])
         nat.cnn_small_bwd(self._pptr, gptr, x, dlogits.contiguous(), slot["buf"], dropout_p=self.p,
                           seed=self.dropout_seed, step=step, sample_offset=self.sample_offset, act=self.act)

@@ -15,7 +15,11 @@ Replaced (the hot path, :165-203): when the model is HIP-backed the step is
 ``frontend (optional) -> ww_cnn_small_fwd -> ww_ce2_loss_fwd_bwd -> ww_cnn_small_bwd ->
 [all-reduce of the flat gradient bucket] -> ww_grad_norm_clip -> optimizer.step`` with ONE 40-byte
 device->host read per step (loss, accuracy counters, finite flag, grad norm) instead of the
-reference's >= 6 synchronisations.  Extension: 2-D inputs ``(B, N)`` are raw waveforms and go
+reference's >= 6 synchronisations, and none of them before ``optimizer.step()``: the "skip this batch" decision
+(non-finite loss, invalid targets, non-finite gradient norm) reaches the fused optimizer as a device flag.  With
+``config.training.deferred_metrics`` (default on for the HIP model) a step's stats are read while the next step
+runs, so ``on_batch_end`` fires one step late (same order, same values; flushed at epoch end); set it to False for
+the reference's strict timing.  Extension: 2-D inputs ``(B, N)`` are raw waveforms and go
 through the fused log-mel + SpecAugment kernel first.  Any other ``nn.Module`` takes the
 reference's autograd step unchanged, so the class stays a drop-in.
 """
@@ -112,6 +116,14 @@ class Trainer:
                 for t in list(self.model.parameters()) + list(self.model.buffers()):
                     self._dist.broadcast(t, src=0)
         self._stats_host = None
+        # native step pipelining (see _launch_native): the optimizer consumes the device-side found_inf flag, so no
+        # host read sits between backward and optimizer.step(); with deferred_metrics a step's 48-byte stats are
+        # resolved while the NEXT step is already running (callbacks fire one step late, same order and content).
+        self._skip_on_device = bool(getattr(self.optimizer, "_step_supports_amp_scaling", False))
+        self.deferred_metrics = (bool(getattr(config.training, "deferred_metrics", True)) and self.native
+                                 and self._native_loss and self._skip_on_device)
+        self._pending = None
+        self._host_bufs, self._buf_i = None, 0
         logger.info("Trainer initialized (device=%s, model=%s, native=%s, optimizer=%s, scheduler=%s, loss=%s, "
                     "world=%d)", device, config.model.architecture, self.native, config.optimizer.optimizer,
                     config.optimizer.scheduler, config.loss.loss_function, self.world_size)
@@ -148,7 +160,7 @@ class Trainer:
         wave = inputs.to(self.device, non_blocking=True)
         if wave.dtype not in (torch.float32, torch.int16):
             wave = wave.float()
-        return nat.logmel_fwd(wave.contiguous(), cfg, sa, seed=a.seed, step=self.state.global_step,
+        return nat.logmel_fwd(wave.contiguous(), cfg, sa, seed=a.seed, step=self._launch_step_index(),
                               sample_offset=self.rank * wave.shape[0])
 
     def _read_stats(self, stats: torch.Tensor) -> dict:
@@ -173,7 +185,36 @@ class Trainer:
                     p.grad.div_(self.world_size)
 
     # ------------------------------------------------------------------------------- inner steps
-    def _step_native(self, inputs, targets, batch_idx) -> Optional[Tuple[float, float]]:
+    def _launch_step_index(self) -> int:
+        """Counter of the Philox streams (SpecAugment): the index of the step being launched."""
+        return self.state.global_step + (1 if self._pending is not None else 0)
+
+    def _resolve(self, pending):
+        """Read one launched step's stats (waits for that step only) -> (batch_idx, loss, acc) or None if skipped."""
+        batch_idx, buf, event = pending
+        event.synchronize()
+        s = nat.decode_stats(buf)
+        if s["bad_target"]:
+            logger.error("Unexpected error at batch %d: Target values must be in [0, 1]", batch_idx)
+            return None
+        if s["found_inf"] != 0.0:
+            logger.error("Non-finite loss detected at batch %d: %s", batch_idx, s["loss"])
+            return None
+        self.train_metrics_tracker.update_counts(s["tp"], s["tn"], s["fp"], s["fn"])
+        self.last_grad_norm = s["grad_norm"]
+        return batch_idx, s["loss"], s["correct"] / max(s["count"], 1)
+
+    def _flush_pending(self):
+        out = []
+        if self._pending is not None:
+            r = self._resolve(self._pending)
+            self._pending = None
+            if r is not None:
+                out.append(r)
+        return out
+
+    def _step_native(self, inputs, targets, batch_idx):
+        """Launch one native step; returns the list of steps whose results became available."""
         if inputs.dim() == 2:
             inputs = self._features(inputs, training=True)
         else:
@@ -186,21 +227,40 @@ class Trainer:
         loss.backward()
         self._allreduce_grads()
         stats = self.criterion.last_stats
-        nat.grad_norm_clip_(self.model.flat_grad, max(float(self.gradient_clip), 0.0),
-                            norm_out=stats.view(torch.float32)[1:2])
-        s = self._read_stats(stats)
-        if s["bad_target"]:
-            raise ValueError("Target values must be in [0, 1]")
-        if s["nonfinite"] or (self._dist and s["grad_norm"] != s["grad_norm"]):
-            logger.error("Non-finite loss detected at batch %d: %s", batch_idx, s["loss"])
-            self.optimizer.zero_grad(set_to_none=True)
-            return None
-        self.optimizer.step()
-        self.train_metrics_tracker.update_counts(s["tp"], s["tn"], s["fp"], s["fn"])
-        self.last_grad_norm = s["grad_norm"]
-        return s["loss"], s["correct"] / max(s["count"], 1)
+        nat.grad_norm_clip_(self.model.flat_grad, max(float(self.gradient_clip), 0.0), stats=stats)
+        if self._skip_on_device:
+            # the reference skips a batch whose loss is not finite (trainer.py:177-179) or whose targets are invalid
+            # (losses.py:72) before touching the parameters; here the fused optimizer gets that decision as a
+            # device flag (the mechanism GradScaler uses), so nothing on the host waits for the GPU
+            self.optimizer.grad_scale = None
+            self.optimizer.found_inf = stats.view(torch.float32)[nat.FOUND_INF_FLOAT_INDEX]
+            try:
+                self.optimizer.step()
+            finally:
+                del self.optimizer.grad_scale, self.optimizer.found_inf
+        if self._host_bufs is None:
+            self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        buf = self._host_bufs[self._buf_i]
+        self._buf_i ^= 1
+        buf.copy_(stats, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        launched = (batch_idx, buf, event)
+        if not self._skip_on_device:               # optimizer cannot skip on the device: decide on the host
+            r = self._resolve(launched)
+            if r is None:
+                self.optimizer.zero_grad(set_to_none=True)
+                return []
+            self.optimizer.step()
+            return [r]
+        if not self.deferred_metrics:
+            r = self._resolve(launched)
+            return [] if r is None else [r]
+        done = self._flush_pending()               # previous step: finished long ago, no stall
+        self._pending = launched
+        return done
 
-    def _step_generic(self, inputs, targets, batch_idx) -> Optional[Tuple[float, float]]:
+    def _step_generic(self, inputs, targets, batch_idx):
         inputs = inputs.to(self.device, non_blocking=True, memory_format=torch.channels_last)
         targets = targets.to(self.device, non_blocking=True)
         self.optimizer.zero_grad(set_to_none=True)
@@ -210,7 +270,7 @@ class Trainer:
             loss = self.criterion(outputs, targets)
         if not torch.isfinite(loss):
             logger.error("Non-finite loss detected at batch %d: %s", batch_idx, loss.item())
-            return None
+            return []
         self.scaler.scale(loss).backward()
         self._allreduce_grads()
         if self.gradient_clip > 0:
@@ -223,7 +283,7 @@ class Trainer:
         with torch.no_grad():
             acc = (outputs.argmax(dim=1) == targets).float().mean().item()
         self.train_metrics_tracker.update(outputs.detach(), targets.detach())
-        return loss.item(), acc
+        return [(batch_idx, loss.item(), acc)]
 
     def _eval_batch(self, inputs, targets) -> Optional[float]:
         if self.native and self._native_loss:
@@ -274,15 +334,10 @@ class Trainer:
         epoch_loss = 0.0
         step = self._step_native if (self.native and self._native_loss) else self._step_generic
         bar = self._bar(self.train_loader, f"Epoch {epoch + 1}/{self.config.training.epochs} [Train]")
-        for batch_idx, batch in enumerate(bar):
-            try:
-                parsed = self._unpack(batch, batch_idx, "batch")
-                if parsed is None:
-                    continue
-                result = step(parsed[0], parsed[1], batch_idx)
-                if result is None:
-                    continue
-                loss_value, batch_acc = result
+
+        def account(done):
+            nonlocal epoch_loss
+            for idx, loss_value, batch_acc in done:
                 self.metric_monitor.update_batch(loss_value, batch_acc)
                 epoch_loss += loss_value
                 if bar is not self.train_loader:
@@ -290,7 +345,14 @@ class Trainer:
                     bar.set_postfix({"loss": f"{avg['loss']:.4f}", "acc": f"{avg['accuracy']:.4f}",
                                      "lr": f"{get_learning_rate(self.optimizer):.6f}"})
                 self.state.global_step += 1
-                self._call_callbacks("on_batch_end", batch_idx, loss_value, batch_acc)
+                self._call_callbacks("on_batch_end", idx, loss_value, batch_acc)
+
+        for batch_idx, batch in enumerate(bar):
+            try:
+                parsed = self._unpack(batch, batch_idx, "batch")
+                if parsed is None:
+                    continue
+                account(step(parsed[0], parsed[1], batch_idx))
             except RuntimeError as e:
                 if "out of memory" in str(e).lower():
                     logger.error("GPU OOM at batch %d. Clearing cache and skipping batch.", batch_idx)
@@ -301,6 +363,7 @@ class Trainer:
             except Exception as e:
                 logger.exception("Unexpected error at batch %d: %s", batch_idx, e)
                 continue
+        account(self._flush_pending())            # the last step's deferred results
         epoch_loss, num_batches = self._epoch_reduce(self.train_metrics_tracker, epoch_loss, num_batches)
         avg_loss = epoch_loss / max(num_batches, 1)
         train_metrics = self.train_metrics_tracker.compute()
