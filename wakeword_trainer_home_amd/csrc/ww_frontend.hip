@@ -81,6 +81,15 @@ struct FeatArgs {
     int n_mel_w;
 };
 
+// order a wave's own LDS traffic (cross-lane hand-off inside one wavefront): LDS processes one wave's operations in
+// issue order, so only the compiler has to be kept from reordering.  A wavefront touches only its own FFT / power
+// buffers inside a round, so no workgroup barrier is needed there (PMC: 47 % of wave-cycles were parked).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename WaveT>
 __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ out,
                                                 int use_mask, ww_mask_params mp, int32_t *__restrict__ mask_idx) {
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
             cmul_c(r, i, t.x, t.y);
             buf[kb * BUF_STRIDE + lane] = make_float2(r, i);
         }
-        __syncthreads();
+        wave_sync();
         // ---- pass 2: lane = kb*4 + q ; radix-16 over m (n1 = 4m + q), twiddle W64^(q*kc)
         const int kb2 = lane >> 2, q = lane & 3;
 #pragma unroll
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
             cmul_c(r, i, t.x, t.y);
             buf[kb2 * BUF_STRIDE + kc * 4 + q] = make_float2(r, i);
         }
-        __syncthreads();
+        wave_sync();
         // ---- pass 3 (in place): radix-4 over q for (kb, kc = (lane&3) + 4u); slot [kb][4kc + kd] <- X[16kc + 256kd + kb]
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
             s4[2] = make_float2(r2, i2);
             s4[3] = make_float2(r3, i3);
         }
-        __syncthreads();
+        wave_sync();
         // ---- separate the two real spectra, power -> pbuf[frame][k];  X[k] lives at [k&15][4*((k>>4)&15) + (k>>8)]
 #pragma unroll
         for (int u = 0; u < 9; ++u) {
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
                 pbuf[516 + k] = 0.25f * (yr * yr + yi * yi);
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- mel band sums: item = ((frame, mel), half); the two halves of a band sit in adjacent lanes
         for (int it0 = 0; it0 < 4 * a.M; it0 += 64) {
             const int it = it0 + lane;
@@ -219,8 +228,9 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
             acc += __shfl_xor(acc, 1);
             if (act && half == 0) lm[(fa + fr) * a.M + m] = logf(acc + a.log_eps);
         }
-        __syncthreads();
+        wave_sync();
     }
+    __syncthreads();
 
     if (a.use_dct) {
         for (int it = tid; it < FR * a.F; it += 256) {
