@@ -139,9 +139,18 @@ def main():
 
     last_done = [None]
 
-    def step(i):
+    staged = {}
+
+    def prepare(i):                                       # input stage of step i on the side stream (Trainer's pipeline)
         wave, y = pool[i % len(pool)]
-        for done in trainer._step_native(wave, y, i):     # results arrive one step late (deferred_metrics)
+        staged[i] = trainer._prepare_native(wave, y, i)
+
+    def step(i):
+        if i not in staged:
+            prepare(i)
+        prep = staged.pop(i)
+        prepare(i + 1)                                    # one batch of lookahead, as Trainer.train_epoch does
+        for done in trainer._step_native(None, None, i, prepared=prep):   # results arrive one step late
             trainer.state.global_step += 1
             last_done[0] = done
 

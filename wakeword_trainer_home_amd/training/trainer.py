@@ -124,6 +124,7 @@ class Trainer:
                                  and self._native_loss and self._skip_on_device)
         self._pending = None
         self._host_bufs, self._buf_i = None, 0
+        self._in_stream = None
         logger.info("Trainer initialized (device=%s, model=%s, native=%s, optimizer=%s, scheduler=%s, loss=%s, "
                     "world=%d)", device, config.model.architecture, self.native, config.optimizer.optimizer,
                     config.optimizer.scheduler, config.loss.loss_function, self.world_size)
@@ -145,7 +146,7 @@ class Trainer:
             return None
         return inputs, targets
 
-    def _features(self, inputs: torch.Tensor, training: bool) -> torch.Tensor:
+    def _features(self, inputs: torch.Tensor, training: bool, step: Optional[int] = None) -> torch.Tensor:
         """Native front end for raw waveform batches (B,N): fused log-mel/MFCC (+SpecAugment when training)."""
         d, a = self.config.data, self.config.augmentation
         mfcc = d.feature_type == "mfcc"
@@ -160,7 +161,8 @@ class Trainer:
         wave = inputs.to(self.device, non_blocking=True)
         if wave.dtype not in (torch.float32, torch.int16):
             wave = wave.float()
-        return nat.logmel_fwd(wave.contiguous(), cfg, sa, seed=a.seed, step=self._launch_step_index(),
+        return nat.logmel_fwd(wave.contiguous(), cfg, sa, seed=a.seed,
+                              step=self._launch_step_index() if step is None else step,
                               sample_offset=self.rank * wave.shape[0])
 
     def _read_stats(self, stats: torch.Tensor) -> dict:
@@ -213,13 +215,31 @@ class Trainer:
                 out.append(r)
         return out
 
-    def _step_native(self, inputs, targets, batch_idx):
+    def _prepare_native(self, inputs, targets, step_index):
+        """Input stage of a native step on its own HIP stream: H2D (if needed) + fused log-mel/SpecAugment.  It has no
+        dependency on the model, so for batch k+1 it runs while step k's conv stack (HBM-bound) is executing -- the
+        front end is LDS/latency-bound, the two overlap well.  Returns (features, targets, ready_event)."""
+        if self._in_stream is None:
+            self._in_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._in_stream):
+            if inputs.dim() == 2:
+                feats = self._features(inputs, training=True, step=step_index)
+            else:
+                feats = inputs.to(self.device, non_blocking=True)
+            tg = targets.to(self.device, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self._in_stream)
+        return feats, tg, ready
+
+    def _step_native(self, inputs, targets, batch_idx, prepared=None):
         """Launch one native step; returns the list of steps whose results became available."""
-        if inputs.dim() == 2:
-            inputs = self._features(inputs, training=True)
-        else:
-            inputs = inputs.to(self.device, non_blocking=True)
-        targets = targets.to(self.device, non_blocking=True)
+        if prepared is None:
+            prepared = self._prepare_native(inputs, targets, self._launch_step_index())
+        inputs, targets, ready = prepared
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ready)
+        inputs.record_stream(main)
+        targets.record_stream(main)
         self.model.sample_offset = self.rank * inputs.shape[0]
         self.optimizer.zero_grad(set_to_none=True)
         outputs = self.model(inputs)
@@ -347,12 +367,54 @@ class Trainer:
                 self.state.global_step += 1
                 self._call_callbacks("on_batch_end", idx, loss_value, batch_acc)
 
-        for batch_idx, batch in enumerate(bar):
+        pipelined = self.native and self._native_loss
+        launched = 0                                # native steps launched this epoch (Philox step = base + launched)
+        base_step = self.state.global_step
+
+        def stage(item):
+            """fetch-side work for one loader item: validate, and (native) enqueue its input stage on the side stream"""
+            nonlocal launched
+            idx, batch = item
             try:
-                parsed = self._unpack(batch, batch_idx, "batch")
+                parsed = self._unpack(batch, idx, "batch")
                 if parsed is None:
-                    continue
-                account(step(parsed[0], parsed[1], batch_idx))
+                    return None
+                prep = None
+                if pipelined:
+                    prep = self._prepare_native(parsed[0], parsed[1], base_step + launched)
+                    launched += 1
+                return idx, parsed, prep
+            except RuntimeError as e:
+                if "out of memory" in str(e).lower():
+                    logger.error("GPU OOM at batch %d. Clearing cache and skipping batch.", idx)
+                    torch.cuda.empty_cache()
+                    return None
+                logger.exception("Runtime error at batch %d: %s", idx, e)
+                raise
+            except Exception as e:
+                logger.exception("Unexpected error at batch %d: %s", idx, e)
+                return None
+
+        it = iter(enumerate(bar))
+        nxt = next(it, None)
+        staged = None
+        batch_idx = -1
+        while nxt is not None or staged is not None:
+            try:
+                if staged is None and nxt is not None:      # prime / refill
+                    staged, nxt = stage(nxt), next(it, None)
+                    if staged is None:
+                        continue
+                cur = staged
+                # look one batch ahead: its input stage overlaps the step launched below
+                staged = None
+                while nxt is not None and staged is None:
+                    staged, nxt = stage(nxt), next(it, None)
+                batch_idx, parsed, prep = cur
+                if pipelined:
+                    account(self._step_native(None, None, batch_idx, prepared=prep))
+                else:
+                    account(step(parsed[0], parsed[1], batch_idx))
             except RuntimeError as e:
                 if "out of memory" in str(e).lower():
                     logger.error("GPU OOM at batch %d. Clearing cache and skipping batch.", batch_idx)
