@@ -37,6 +37,13 @@ ALGO_BYTES = {
 }
 
 
+# HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01_g_pmc_summary.md), measured
+# on exactly this command at the default batch 512 / bf16.  Reported as roofline.traffic only for that configuration.
+TRAFFIC_BYTES_B512_BF16 = {"dwconv3x3_bwd": 442.2e6, "pwconv1x1_bwd": 382.8e6, "dwconv3x3_fwd": 216.4e6,
+                           "pwconv1x1_fwd": 199.9e6, "conv_stem_bwd": 223.5e6, "conv_stem_fwd": 119.7e6, "gap_fwd": 100.1e6,
+                           "logmel_specaug": 84.6e6}
+
+
 def algo_bytes(kernel, esz):
     """fp32 figures above scale with the activation element size (features stay fp32)."""
     b = ALGO_BYTES.get(kernel, 0)
@@ -202,7 +209,9 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "last_loss": None if last is None else round(last[0], 6)},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": (TRAFFIC_BYTES_B512_BF16.get(dominant) if (args.batch == 512 and args.dtype == "bf16")
+                                     else None),
                          "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": launches,
                          "algorithmic_bytes_per_launch": algo,
                          "step_frac_of_hbm_roofline": round(value / world * step_algo_bytes(esz) / (HBM_PEAK_GBS * 1e9), 4)},

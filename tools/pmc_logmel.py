@@ -38,5 +38,13 @@ else:
             nat.dwconv3x3_bwd(g, y_in, coef, y_in, ss, mr, t[0], wdw, scratch)
         elif what == "pw_bwd":
             nat.pwconv1x1_bwd(g, None, y_in, None, coef, y_in, ss, mr, t[0], wpw, scratch)
+        elif what == "gap":
+            nat.gap_fwd(y_in, ss, mr)
+        elif what == "all":
+            nat.gap_fwd(y_in, ss, mr)
+            nat.dwconv3x3_fwd(y_in, ss, wdw, bn, scratch)
+            nat.pwconv1x1_fwd(y_in, ss, wpw, bn, scratch)
+            nat.dwconv3x3_bwd(g, y_in, coef, y_in, ss, mr, t[0], wdw, scratch)
+            nat.pwconv1x1_bwd(g, None, y_in, None, coef, y_in, ss, mr, t[0], wpw, scratch)
 torch.cuda.synchronize()
 print("done", what)
