@@ -95,6 +95,20 @@ def cpu_baseline(batch, seconds_budget=20.0):
                       f"{dt:.1f} s wall"}
 
 
+class _fd1_to_stderr:
+    """RCCL prints its version banner on fd 1 when the communicator is created; stdout must carry ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +120,8 @@ def main():
                          "BASELINE config 2 names bf16, f32 is the 1e-3 parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=128)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even for one rank (plumbing test on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -120,9 +136,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        with _fd1_to_stderr():
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)                      # communicator (and its banner) are created here
+            torch.cuda.synchronize()
 
     from wakeword_trainer_home_amd import _native as nat
     from wakeword_trainer_home_amd.config import get_preset
@@ -162,7 +186,7 @@ def main():
             last_done[0] = done
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -186,7 +210,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = nat.prof_collect(dev)
     nat.prof_enable(dev, [])
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -217,10 +241,10 @@ def main():
                          "step_frac_of_hbm_roofline": round(value / world * step_algo_bytes(esz) / (HBM_PEAK_GBS * 1e9), 4)},
             "kernel_ms_per_step_warmup": {k: round(v[0] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (bounded sample, rank 0)
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

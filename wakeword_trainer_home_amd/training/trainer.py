@@ -176,15 +176,15 @@ class Trainer:
     def _allreduce_grads(self):
         if not self._dist:
             return
-        if self.native:
-            flat = self.model.flat_grad
-            self._dist.all_reduce(flat)
-            flat.div_(self.world_size)
-        else:
-            for p in self.model.parameters():
-                if p.grad is not None:
-                    self._dist.all_reduce(p.grad)
-                    p.grad.div_(self.world_size)
+        avg = self._dist.ReduceOp.AVG if self._dist.get_backend() == "nccl" else None   # RCCL averages in-kernel
+        tensors = [self.model.flat_grad] if self.native else [p.grad for p in self.model.parameters()
+                                                              if p.grad is not None]
+        for t in tensors:
+            if avg is not None:
+                self._dist.all_reduce(t, op=avg)
+            else:                                      # gloo (CPU tests) has no AVG
+                self._dist.all_reduce(t)
+                t.div_(self.world_size)
 
     # ------------------------------------------------------------------------------- inner steps
     def _launch_step_index(self) -> int:
