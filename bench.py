@@ -34,6 +34,7 @@ ALGO_BYTES = {
     "pwconv1x1_bwd": 3 * A_ELEMS * 4,
     "dwconv3x3_bwd": 3 * A_ELEMS * 4,
     "conv_stem_bwd": 2 * A_ELEMS * 4,
+    "audio_augment": int(4 * N_SAMPLES * 2.5),      # read x, write out, read a noise segment for half of the clips
 }
 
 
@@ -47,7 +48,7 @@ TRAFFIC_BYTES_B512_BF16 = {"dwconv3x3_bwd": 442.2e6, "pwconv1x1_bwd": 382.8e6, "
 def algo_bytes(kernel, esz):
     """fp32 figures above scale with the activation element size (features stay fp32)."""
     b = ALGO_BYTES.get(kernel, 0)
-    if kernel == "logmel_specaug":
+    if kernel in ("logmel_specaug", "audio_augment"):
         return b
     if kernel == "conv_stem_fwd":
         return 24160 + A_ELEMS * esz
@@ -122,6 +123,10 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=128)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even for one rank (plumbing test on a 1-GPU box)")
+    ap.add_argument("--augment", action="store_true",
+                    help="BASELINE config 4's input stage: on-GPU RIR convolution + background mix ahead of the log-mel "
+                         "(rir_prob 0.25, noise prob 0.5, SNR 5-20 dB: src/config/defaults.py:82-87); not the headline line")
+    ap.add_argument("--rir-len", type=int, default=4000, help="RIR taps for --augment (0.25 s at 16 kHz)")
     args = ap.parse_args()
 
     import torch
@@ -167,6 +172,16 @@ def main():
     # a few distinct synthetic batches, generated on the device, rank-specific seeds (weak scaling)
     pool = [make_synthetic_batch(args.batch, N_SAMPLES, seed=1234 + 97 * rank + i, device=dev) for i in range(4)]
     trainer.model.train()
+    if args.augment:
+        from wakeword_trainer_home_amd.data import AudioAugmentation
+        g = torch.Generator(device=dev).manual_seed(77)
+        decay = torch.exp(-torch.arange(args.rir_len, device=dev) / (args.rir_len / 6.0))
+        rirs = torch.randn(64, args.rir_len, device=dev, generator=g) * decay
+        noises = 0.1 * torch.randn(64, 10 * 16000, device=dev, generator=g)
+        a = cfg.augmentation
+        trainer.audio_augmentation = AudioAugmentation(
+            sample_rate=16000, device=dev, background_noise_prob=a.background_noise_prob,
+            noise_snr_range=(a.noise_snr_min, a.noise_snr_max), rir_prob=a.rir_prob, rirs=rirs, noises=noises, seed=a.seed)
 
     last_done = [None]
 
@@ -227,7 +242,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE config 2: cnn_small + log-mel(40) + SpecAugment, fwd/bwd + clip + AdamW, "
-                                   "16 kHz x 1.5 s clips resident in HBM", "batch_per_gpu": args.batch,
+                                   "16 kHz x 1.5 s clips resident in HBM" + (f" + on-GPU RIR({args.rir_len} taps)/noise-mix augmentation "
+                                   "(config 4's input stage)" if args.augment else ""), "batch_per_gpu": args.batch,
                        "activation_storage": args.dtype, "arithmetic": "f32",
                        "global_batch": args.batch * world, "n_samples": N_SAMPLES,
                        "parallelism": f"dp{world}" if world > 1 else "single",

@@ -92,6 +92,24 @@ int ww_specaug_apply(ww_ctx *ctx, float *x, int B, int F, int T, const ww_specau
                      uint64_t seed, uint64_t step, uint64_t sample_offset, int32_t *mask_idx,
                      ww_stream_t stream);
 
+/* ------------------------------------------------------------------ waveform augmentation
+ * Replaces the RIR / background-noise part of AudioAugmentation.__call__ (src/data/augmentation.py -- ABSENT; ctor
+ * tests/test_training_pipeline.py:230-236, knobs src/config/defaults.py:81-87).  Law: DESIGN.md "Audio augmentation
+ * spec" / oracle/audio_augment.py.  rirs (R,L) f32, L <= 8192; noises (K,Nn) f32, Nn >= N; either bank may be absent
+ * (NULL, 0).  choice_out (nullable): int32 (B,4) = rir index|-1, noise index|-1, noise offset, float bits of snr_db.
+ * wave_out must not alias wave_in.                                                                                   */
+typedef struct {
+    float rir_prob;    /* defaults.py:87 */
+    float noise_prob;  /* background_noise_prob, defaults.py:82 */
+    float snr_min_db;  /* noise_snr_min, :83 */
+    float snr_max_db;  /* noise_snr_max, :84 */
+} ww_audio_aug_cfg;
+size_t ww_audio_augment_scratch_bytes(int B, int N);
+int ww_audio_augment(ww_ctx *ctx, const float *wave_in, float *wave_out, int B, int N, const float *rirs, int R, int L,
+                     const float *noises, int K, int Nn, const ww_audio_aug_cfg *cfg, uint64_t seed, uint64_t step,
+                     uint64_t sample_offset, int32_t *choice_out, void *scratch, size_t scratch_bytes,
+                     ww_stream_t stream);
+
 /* ------------------------------------------------------------------ conv stack layers
  * Replace nn.Conv2d / nn.BatchNorm2d(train) / nn.ReLU as the reference composes them
  * (stem form: src/models/architectures.py:99-102; depthwise-separable blocks are the

@@ -39,6 +39,10 @@ class BN(C.Structure):
                 ("running_var", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float), ("training", C.c_int32)]
 
 
+class AudioAugCfg(C.Structure):
+    _fields_ = [("rir_prob", C.c_float), ("noise_prob", C.c_float), ("snr_min_db", C.c_float), ("snr_max_db", C.c_float)]
+
+
 class StepStats(C.Structure):
     _fields_ = [("loss", C.c_float), ("grad_norm", C.c_float), ("correct", C.c_int32), ("tp", C.c_int32),
                 ("tn", C.c_int32), ("fp", C.c_int32), ("fn", C.c_int32), ("nonfinite", C.c_int32),
@@ -57,6 +61,9 @@ _SIGS = {
     "ww_logmel_fwd": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(FeatCfg), _vp, C.POINTER(SpecAugCfg), _u64, _u64, _u64,
                                 _vp, _vp]),
     "ww_specaug_apply": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(SpecAugCfg), _u64, _u64, _u64, _vp, _vp]),
+    "ww_audio_augment_scratch_bytes": (_sz, [_i, _i]),
+    "ww_audio_augment": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, C.POINTER(AudioAugCfg), _u64, _u64, _u64,
+                                   _vp, _vp, _sz, _vp]),
     "ww_layer_scratch_bytes": (_sz, []),
     "ww_conv_stem_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
     "ww_dwconv3x3_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
@@ -235,6 +242,30 @@ def specaug_apply_(x, specaug: SpecAugCfg, seed=0, step=0, sample_offset=0, want
         _check(load().ww_specaug_apply(ctx(dev), _p(x), B, F, T, C.byref(specaug), seed, step, sample_offset, _p(idx),
                                        _stream(dev)), "ww_specaug_apply")
     return idx
+
+
+def audio_augment(wave, rirs, noises, rir_prob, noise_prob, snr_min_db, snr_max_db, seed=0, step=0, sample_offset=0,
+                  want_choices=False):
+    """wave (B,N) f32 cuda -> augmented copy [, choices int32 (B,4)]; rirs (R,L) / noises (K,Nn) f32 cuda or None."""
+    dev = _dev(wave, rirs, noises)
+    if wave.dim() != 2 or wave.dtype != torch.float32:
+        raise ValueError(f"waveform batch must be float32 (B,N), got {wave.dtype} {tuple(wave.shape)}")
+    for name, t in (("rirs", rirs), ("noises", noises)):
+        if t is not None and (t.dim() != 2 or t.dtype != torch.float32):
+            raise ValueError(f"{name} must be a float32 (count, length) tensor")
+    B, N = wave.shape
+    out = torch.empty_like(wave)
+    R, L = (0, 0) if rirs is None else rirs.shape
+    K, Nn = (0, 0) if noises is None else noises.shape
+    nbytes = load().ww_audio_augment_scratch_bytes(B, N)
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    choices = torch.empty((B, 4), dtype=torch.int32, device=dev) if want_choices else None
+    cfg = AudioAugCfg(rir_prob, noise_prob, snr_min_db, snr_max_db)
+    with torch.cuda.device(dev):
+        _check(load().ww_audio_augment(ctx(dev), _p(wave), _p(out), B, N, _p(rirs), R, L, _p(noises), K, Nn, C.byref(cfg),
+                                       seed, step, sample_offset, _p(choices), _p(scratch), nbytes, _stream(dev)),
+               "ww_audio_augment")
+    return (out, choices) if want_choices else out
 
 
 def layer_scratch(dev):

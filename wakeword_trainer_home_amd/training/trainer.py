@@ -13,7 +13,7 @@ but still counted in the epoch-loss denominator (:177-179, :229).
 
 Replaced (the hot path, :165-203): when the model is HIP-backed the step is
 ``frontend (optional) -> ww_cnn_small_fwd -> ww_ce2_loss_fwd_bwd -> ww_cnn_small_bwd ->
-[all-reduce of the flat gradient bucket] -> ww_grad_norm_clip -> optimizer.step`` with ONE 40-byte
+[all-reduce of the flat gradient bucket] -> ww_grad_norm_clip -> optimizer.step`` with ONE 48-byte
 device->host read per step (loss, accuracy counters, finite flag, grad norm) instead of the
 reference's >= 6 synchronisations, and none of them before ``optimizer.step()``: the "skip this batch" decision
 (non-finite loss, invalid targets, non-finite gradient norm) reaches the fused optimizer as a device flag.  With
@@ -125,6 +125,7 @@ class Trainer:
         self._pending = None
         self._host_bufs, self._buf_i = None, 0
         self._in_stream = None
+        self.audio_augmentation = None     # data.augmentation.AudioAugmentation; applied to (B,N) training batches
         logger.info("Trainer initialized (device=%s, model=%s, native=%s, optimizer=%s, scheduler=%s, loss=%s, "
                     "world=%d)", device, config.model.architecture, self.native, config.optimizer.optimizer,
                     config.optimizer.scheduler, config.loss.loss_function, self.world_size)
@@ -161,12 +162,16 @@ class Trainer:
         wave = inputs.to(self.device, non_blocking=True)
         if wave.dtype not in (torch.float32, torch.int16):
             wave = wave.float()
+        if training and self.audio_augmentation is not None:
+            # RIR + background mix on the device, ahead of the STFT (the reference does this on CPU dataset workers)
+            wave = self.audio_augmentation(wave, step=self._launch_step_index() if step is None else step,
+                                           sample_offset=self.rank * wave.shape[0])
         return nat.logmel_fwd(wave.contiguous(), cfg, sa, seed=a.seed,
                               step=self._launch_step_index() if step is None else step,
                               sample_offset=self.rank * wave.shape[0])
 
     def _read_stats(self, stats: torch.Tensor) -> dict:
-        """The step's single device->host transfer (40 bytes, pinned)."""
+        """The step's single device->host transfer (48 bytes, pinned)."""
         if self._stats_host is None:
             self._stats_host = torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory()
         self._stats_host.copy_(stats, non_blocking=True)
