@@ -105,8 +105,13 @@ typedef struct {
     float snr_max_db;  /* noise_snr_max, :84 */
 } ww_audio_aug_cfg;
 size_t ww_audio_augment_scratch_bytes(int B, int N);
+/* Optional, once per RIR bank: spectra for the FFT (overlap-save, 16384-point) form of the convolution, which
+ * ww_audio_augment uses when `rir_spectra` is non-NULL; NULL selects the direct time-domain form (short RIRs). */
+size_t ww_audio_rir_spectra_bytes(int R);
+int ww_audio_rir_spectra(ww_ctx *ctx, const float *rirs, int R, int L, void *spectra, size_t spectra_bytes,
+                         ww_stream_t stream);
 int ww_audio_augment(ww_ctx *ctx, const float *wave_in, float *wave_out, int B, int N, const float *rirs, int R, int L,
-                     const float *noises, int K, int Nn, const ww_audio_aug_cfg *cfg, uint64_t seed, uint64_t step,
+                     const void *rir_spectra, const float *noises, int K, int Nn, const ww_audio_aug_cfg *cfg, uint64_t seed, uint64_t step,
                      uint64_t sample_offset, int32_t *choice_out, void *scratch, size_t scratch_bytes,
                      ww_stream_t stream);
 

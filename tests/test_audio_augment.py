@@ -52,17 +52,18 @@ def test_oracle_signal_law():
 
 
 # ---------------------------------------------------------------------------------------------------- GPU parity
-def _run_device(x, rirs, noises, **kw):
+def _run_device(x, rirs, noises, fft=False, **kw):
     from wakeword_trainer_home_amd import _native as nat
     dev = torch.device("cuda:0")
     t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
-    out, ch = nat.audio_augment(t(x), t(rirs), t(noises), want_choices=True, **kw)
+    spectra = nat.audio_rir_spectra(t(rirs)) if (fft and rirs is not None) else None
+    out, ch = nat.audio_augment(t(x), t(rirs), t(noises), want_choices=True, rir_spectra=spectra, **kw)
     torch.cuda.synchronize()
     return out.cpu().numpy(), ch.cpu().numpy()
 
 
-def _check(x, rirs, noises, rir_prob, noise_prob, smin, smax, seed=0, step=0, sample_offset=0, atol=1e-4):
-    out, ch = _run_device(x, rirs, noises, rir_prob=rir_prob, noise_prob=noise_prob, snr_min_db=smin, snr_max_db=smax,
+def _check(x, rirs, noises, rir_prob, noise_prob, smin, smax, seed=0, step=0, sample_offset=0, atol=1e-4, fft=False):
+    out, ch = _run_device(x, rirs, noises, fft=fft, rir_prob=rir_prob, noise_prob=noise_prob, snr_min_db=smin, snr_max_db=smax,
                           seed=seed, step=step, sample_offset=sample_offset)
     ref, rch = oa.audio_augment(x, rirs, noises, rir_prob, noise_prob, smin, smax, seed, step, sample_offset)
     assert np.array_equal(ch[:, 0], rch["rir"]) and np.array_equal(ch[:, 1], rch["noise"])
@@ -75,13 +76,36 @@ def _check(x, rirs, noises, rir_prob, noise_prob, smin, smax, seed=0, step=0, sa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,N,L", [(6, 24000, 1200), (3, 2048, 8), (5, 5000, 1), (2, 24000, 8192), (4, 1000, 3001)])
-def test_device_matches_oracle(B, N, L):
+@pytest.mark.parametrize("fft", [False, True], ids=["direct", "fft"])
+@pytest.mark.parametrize("B,N,L", [(6, 24000, 1200), (3, 2048, 8), (5, 5000, 1), (2, 24000, 8192), (4, 1000, 3001),
+                                   (3, 24000, 4000), (2, 40000, 5000)])
+def test_device_matches_oracle(B, N, L, fft):
+    """Both forms of the convolution: direct time-domain, and overlap-save FFT (1, 2 and 3+ segments per clip)."""
     rng = np.random.default_rng(B * 1000 + L)
     rirs, noises = _banks(rng, R=3, L=L, K=2, Nn=N + 777)
     x = (0.2 * rng.standard_normal((B, N))).astype(np.float32)
-    _check(x, rirs, noises, 0.6, 0.6, 5.0, 20.0, seed=5, step=3, sample_offset=17)
-    _check(x, rirs, noises, 1.0, 1.0, 0.0, 0.0, seed=6)
+    _check(x, rirs, noises, 0.6, 0.6, 5.0, 20.0, seed=5, step=3, sample_offset=17, fft=fft)
+    _check(x, rirs, noises, 1.0, 1.0, 0.0, 0.0, seed=6, fft=fft)
+
+
+@pytest.mark.gpu
+def test_fft_and_direct_forms_agree_at_full_batch():
+    """BASELINE-sized batch (512 clips x 24000 samples, 4000-tap RIRs): the two device forms against each other
+    (the float64 oracle covers the small cases above)."""
+    from wakeword_trainer_home_amd import _native as nat
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = 0.2 * torch.randn(512, 24000, device=dev, generator=g)
+    rirs = torch.randn(16, 4000, device=dev, generator=g) * torch.exp(-torch.arange(4000, device=dev) / 700.0)
+    noises = 0.1 * torch.randn(8, 160000, device=dev, generator=g)
+    kw = dict(rir_prob=0.25, noise_prob=0.5, snr_min_db=5.0, snr_max_db=20.0, seed=1, step=9, want_choices=True)
+    a, ca = nat.audio_augment(x, rirs, noises, **kw)
+    b, cb = nat.audio_augment(x, rirs, noises, rir_spectra=nat.audio_rir_spectra(rirs), **kw)
+    assert torch.equal(ca, cb)
+    assert 0.15 < (ca[:, 0] >= 0).float().mean() < 0.35 and 0.4 < (ca[:, 1] >= 0).float().mean() < 0.6
+    assert torch.isfinite(b).all() and (a - b).abs().max().item() <= 1e-4
+    plain = (ca[:, 0] < 0) & (ca[:, 1] < 0)                       # untouched clips are bit-exact copies
+    assert torch.equal(b[plain], x[plain].clamp(-1, 1))
 
 
 @pytest.mark.gpu
@@ -99,8 +123,10 @@ def test_device_edge_cases():
     x[0] = 0
     noises[:] = 0
     _check(x, rirs, noises, 1.0, 1.0, 5.0, 20.0, seed=4)
+    _check(x, rirs, noises, 1.0, 1.0, 5.0, 20.0, seed=4, fft=True)
     # only one of the banks
     _check(x, rirs, None, 1.0, 1.0, 5.0, 20.0, seed=4)
+    _check(x, rirs, None, 1.0, 1.0, 5.0, 20.0, seed=4, fft=True)
     _check(x, None, _banks(rng, K=2, Nn=30000)[1], 1.0, 1.0, 5.0, 20.0, seed=4)
 
 

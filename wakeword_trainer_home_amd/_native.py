@@ -62,8 +62,10 @@ _SIGS = {
                                 _vp, _vp]),
     "ww_specaug_apply": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(SpecAugCfg), _u64, _u64, _u64, _vp, _vp]),
     "ww_audio_augment_scratch_bytes": (_sz, [_i, _i]),
-    "ww_audio_augment": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i, C.POINTER(AudioAugCfg), _u64, _u64, _u64,
-                                   _vp, _vp, _sz, _vp]),
+    "ww_audio_rir_spectra_bytes": (_sz, [_i]),
+    "ww_audio_rir_spectra": (C.c_int, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "ww_audio_augment": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, C.POINTER(AudioAugCfg), _u64, _u64,
+                                   _u64, _vp, _vp, _sz, _vp]),
     "ww_layer_scratch_bytes": (_sz, []),
     "ww_conv_stem_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
     "ww_dwconv3x3_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
@@ -244,9 +246,24 @@ def specaug_apply_(x, specaug: SpecAugCfg, seed=0, step=0, sample_offset=0, want
     return idx
 
 
+def audio_rir_spectra(rirs):
+    """RIR bank (R,L) f32 cuda -> spectra for the FFT form of ww_audio_augment (compute once per bank)."""
+    dev = _dev(rirs)
+    if rirs.dim() != 2 or rirs.dtype != torch.float32:
+        raise ValueError("rirs must be a float32 (count, length) tensor")
+    R, L = rirs.shape
+    nbytes = load().ww_audio_rir_spectra_bytes(R)
+    spectra = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_audio_rir_spectra(ctx(dev), _p(rirs), R, L, _p(spectra), nbytes, _stream(dev)),
+               "ww_audio_rir_spectra")
+    return spectra
+
+
 def audio_augment(wave, rirs, noises, rir_prob, noise_prob, snr_min_db, snr_max_db, seed=0, step=0, sample_offset=0,
-                  want_choices=False):
-    """wave (B,N) f32 cuda -> augmented copy [, choices int32 (B,4)]; rirs (R,L) / noises (K,Nn) f32 cuda or None."""
+                  want_choices=False, rir_spectra=None):
+    """wave (B,N) f32 cuda -> augmented copy [, choices int32 (B,4)]; rirs (R,L) / noises (K,Nn) f32 cuda or None.
+    ``rir_spectra`` (from ``audio_rir_spectra``) selects the FFT convolution; None the direct time-domain form."""
     dev = _dev(wave, rirs, noises)
     if wave.dim() != 2 or wave.dtype != torch.float32:
         raise ValueError(f"waveform batch must be float32 (B,N), got {wave.dtype} {tuple(wave.shape)}")
@@ -262,7 +279,7 @@ def audio_augment(wave, rirs, noises, rir_prob, noise_prob, snr_min_db, snr_max_
     choices = torch.empty((B, 4), dtype=torch.int32, device=dev) if want_choices else None
     cfg = AudioAugCfg(rir_prob, noise_prob, snr_min_db, snr_max_db)
     with torch.cuda.device(dev):
-        _check(load().ww_audio_augment(ctx(dev), _p(wave), _p(out), B, N, _p(rirs), R, L, _p(noises), K, Nn, C.byref(cfg),
+        _check(load().ww_audio_augment(ctx(dev), _p(wave), _p(out), B, N, _p(rirs), R, L, _p(rir_spectra), _p(noises), K, Nn, C.byref(cfg),
                                        seed, step, sample_offset, _p(choices), _p(scratch), nbytes, _stream(dev)),
                "ww_audio_augment")
     return (out, choices) if want_choices else out

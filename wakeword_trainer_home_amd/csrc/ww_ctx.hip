@@ -48,6 +48,7 @@ extern "C" int ww_ctx_create(int device, ww_ctx **out) {
     c->device = device;
     c->tables = nullptr;
     c->prof_mask = 0;
+    c->tw16k = nullptr;
     c->prof_recs = new std::vector<ww_prof_rec>();
     c->prof_free = new std::vector<ww_prof_rec>();
     *out = c;
@@ -72,6 +73,7 @@ static void free_tables(ww_feat_tables *t) {
 extern "C" int ww_ctx_destroy(ww_ctx *ctx) {
     if (!ctx) return WW_OK;
     free_tables(ctx->tables);
+    if (ctx->tw16k) (void)hipFree(ctx->tw16k);
     for (auto *v : {ctx->prof_recs, ctx->prof_free}) {
         for (auto &r : *v) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         delete v;

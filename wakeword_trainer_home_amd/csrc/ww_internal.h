@@ -67,6 +67,7 @@ struct ww_prof_rec { int cls; hipEvent_t a, b; };
 struct ww_ctx {
     int device;
     ww_feat_tables *tables;
+    float2 *tw16k;                         // (1024) exp(-2 pi i m / 16384), ww_audio.hip's FFT convolution; lazy
     uint32_t prof_mask;
     std::vector<ww_prof_rec> *prof_recs;   // recorded, not yet collected
     std::vector<ww_prof_rec> *prof_free;   // event pairs ready for reuse

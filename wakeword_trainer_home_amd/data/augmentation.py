@@ -19,7 +19,7 @@ class AudioAugmentation:
 
     def __init__(self, sample_rate: int = 16000, device="cuda", time_stretch_range=(0.8, 1.2),
                  pitch_shift_range=(-2, 2), background_noise_prob: float = 0.5, noise_snr_range=(5.0, 20.0),
-                 rir_prob: float = 0.25, rirs=None, noises=None, seed: int = 0):
+                 rir_prob: float = 0.25, rirs=None, noises=None, seed: int = 0, fft_min_taps: int = 129):
         for name, p in (("background_noise_prob", background_noise_prob), ("rir_prob", rir_prob)):
             if not 0.0 <= p <= 1.0:
                 raise ValueError(f"{name} must be in [0, 1], got {p}")
@@ -34,6 +34,9 @@ class AudioAugmentation:
         self.step = 0
         self.rirs = self._bank(rirs, "rirs")
         self.noises = self._bank(noises, "noises")
+        # RIRs of fft_min_taps or more go through the overlap-save FFT form; their spectra are computed once, here
+        self.rir_spectra = (nat.audio_rir_spectra(self.rirs)
+                            if self.rirs is not None and self.rirs.shape[1] >= fft_min_taps else None)
         self.last_choices = None      # device int32 (B,4): rir|-1, noise|-1, offset, float bits of snr_db
 
     def _bank(self, bank, name):
@@ -52,7 +55,7 @@ class AudioAugmentation:
         st = self.step if step is None else step
         res = nat.audio_augment(wave.contiguous(), self.rirs, self.noises, self.rir_prob, self.background_noise_prob,
                                 self.noise_snr_range[0], self.noise_snr_range[1], seed=self.seed, step=st,
-                                sample_offset=sample_offset, want_choices=return_choices)
+                                sample_offset=sample_offset, want_choices=return_choices, rir_spectra=self.rir_spectra)
         if step is None:
             self.step += 1
         if return_choices:
