@@ -228,6 +228,23 @@ int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64_t *targets
  * only the norm is computed.  norm_out (nullable) receives the pre-clip L2 norm.          */
 int ww_grad_norm_clip(ww_ctx *ctx, float *flat_grads, size_t n, float max_norm, float *norm_out,
                       ww_step_stats *stats /* nullable: grad_norm and found_inf are updated */, ww_stream_t stream);
+/* Fused clip + optimizer step on flat fp32 buckets.  Replaces, for one step, the reference's
+ * clip_gradients(...) ; optimizer.step()  (src/training/trainer.py:185-193) with torch.optim's own update rules
+ * (create_optimizer, src/training/optimizer_factory.py:165-199: Adam, AdamW, SGD with nesterov=True).
+ * max_norm <= 0: norm only.  exp_avg doubles as SGD's momentum buffer; exp_avg_sq is unused for SGD (may be NULL).
+ * step_state: int64[2] on the device, both 0 initially; call k reads slot[parity] and writes slot[parity^1]
+ * (callers alternate parity 0,1,0,...).  When stats->found_inf != 0 (or the gradient norm is not finite) nothing is
+ * updated and the step count does not advance -- the reference's "skip this batch" (trainer.py:177-179).            */
+enum { WW_OPT_ADAM = 0, WW_OPT_ADAMW = 1, WW_OPT_SGD = 2 };
+typedef struct {
+    int32_t kind;
+    float lr, beta1, beta2, eps, weight_decay, momentum;
+    float max_norm;    /* gradient_clip (src/config/defaults.py:48) */
+} ww_optim_cfg;
+int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *flat_params, float *flat_grads, float *exp_avg,
+                       float *exp_avg_sq, size_t n, int64_t *step_state, int parity, float *norm_out,
+                       ww_step_stats *stats /* nullable */, ww_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement
  * Opt-in timing of kernel classes with hipEvents recorded on the launch stream around the
  * class's main kernel (bench.py's roofline leg; no reference counterpart -- the reference never

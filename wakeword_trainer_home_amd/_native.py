@@ -43,6 +43,14 @@ class AudioAugCfg(C.Structure):
     _fields_ = [("rir_prob", C.c_float), ("noise_prob", C.c_float), ("snr_min_db", C.c_float), ("snr_max_db", C.c_float)]
 
 
+class OptimCfg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("momentum", C.c_float), ("max_norm", C.c_float)]
+
+
+OPT_ADAM, OPT_ADAMW, OPT_SGD = 0, 1, 2
+
+
 class StepStats(C.Structure):
     _fields_ = [("loss", C.c_float), ("grad_norm", C.c_float), ("correct", C.c_int32), ("tp", C.c_int32),
                 ("tn", C.c_int32), ("fp", C.c_int32), ("fn", C.c_int32), ("nonfinite", C.c_int32),
@@ -66,6 +74,7 @@ _SIGS = {
     "ww_audio_rir_spectra": (C.c_int, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "ww_audio_augment": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, C.POINTER(AudioAugCfg), _u64, _u64,
                                    _u64, _vp, _vp, _sz, _vp]),
+    "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp]),
     "ww_layer_scratch_bytes": (_sz, []),
     "ww_conv_stem_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
     "ww_dwconv3x3_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
@@ -283,6 +292,20 @@ def audio_augment(wave, rirs, noises, rir_prob, noise_prob, snr_min_db, snr_max_
                                        seed, step, sample_offset, _p(choices), _p(scratch), nbytes, _stream(dev)),
                "ww_audio_augment")
     return (out, choices) if want_choices else out
+
+
+def clip_optim_step_(cfg: OptimCfg, flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, parity, norm_out=None,
+                     stats=None):
+    """In place: clip flat_grads to cfg.max_norm, then one Adam/AdamW/SGD step on flat_params (skipped on found_inf)."""
+    dev = _dev(flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, norm_out, stats)
+    if flat_params.dtype != torch.float32 or flat_grads.dtype != torch.float32 or flat_params.numel() != flat_grads.numel():
+        raise ValueError("parameter and gradient buckets must be float32 and of equal length")
+    if step_state.dtype != torch.int64 or step_state.numel() != 2:
+        raise ValueError("step_state must be an int64 tensor of two elements")
+    with torch.cuda.device(dev):
+        _check(load().ww_clip_optim_step(ctx(dev), C.byref(cfg), _p(flat_params), _p(flat_grads), _p(exp_avg), _p(exp_avg_sq),
+                                         flat_params.numel(), _p(step_state), parity, _p(norm_out), _p(stats), _stream(dev)),
+               "ww_clip_optim_step")
 
 
 def layer_scratch(dev):

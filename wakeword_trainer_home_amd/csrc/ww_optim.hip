@@ -1,0 +1,175 @@
+// Fused clip + optimizer step on the flat parameter / gradient buckets.
+// Replaces, for a HIP-backed model, the reference's per-step glue  clip_gradients -> optimizer.step()
+// (src/training/trainer.py:185-193, src/training/optimizer_factory.py:165-199,446-452):
+//   norm = ||g||_2 ; g *= min(1, max_norm/(norm+1e-6))           (torch.nn.utils.clip_grad_norm_)
+//   skip everything below when stats->found_inf != 0             (non-finite loss / bad target / non-finite norm)
+//   Adam / AdamW / SGD-Nesterov update, torch.optim's single-tensor formulas in fp32, bias corrections in double.
+// The step counter lives on the device (two slots, read slot[parity], write slot[parity^1]) so that a skipped step does
+// not advance it -- as in the reference, where optimizer.step() is simply not called -- without the host knowing.
+// Small buckets (<= 32 768 floats; cnn_small has 20 546) take ONE single-block launch for norm + clip + update with the
+// gradient held in registers; larger ones use k_grad_norm_clip followed by a grid-wide update.
+#include "ww_internal.h"
+
+namespace {
+
+struct OptimArgs {
+    int kind;
+    float lr, beta1, beta2, eps, wd, momentum, max_norm;
+};
+
+__device__ __forceinline__ void optim_update(const OptimArgs &a, float &p, const float g0, float &m, float &v,
+                                             const float step_size, const float bc2_sqrt) {
+    float g = g0;
+    if (a.kind == WW_OPT_SGD) {                       // torch.optim.SGD, nesterov=True, dampening=0
+        if (a.wd != 0.f) g = fmaf(a.wd, p, g);
+        if (a.momentum != 0.f) {
+            m = fmaf(a.momentum, m, g);               // a zero buffer reproduces torch's "first step: buf = g"
+            g = fmaf(a.momentum, m, g);
+        }
+        p = fmaf(-a.lr, g, p);
+        return;
+    }
+    if (a.kind == WW_OPT_ADAMW) p *= 1.0f - a.lr * a.wd;        // decoupled decay
+    else if (a.wd != 0.f) g = fmaf(a.wd, p, g);                 // Adam: L2 term in the gradient
+    m = m + (1.0f - a.beta1) * (g - m);                         // exp_avg.lerp_(grad, 1 - beta1)
+    v = a.beta2 * v + (1.0f - a.beta2) * g * g;                 // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + a.eps;
+    p = p - step_size * (m / denom);                            // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__device__ __forceinline__ void bias_terms(const OptimArgs &a, long long t, float &step_size, float &bc2_sqrt) {
+    if (a.kind == WW_OPT_SGD) { step_size = a.lr; bc2_sqrt = 1.f; return; }
+    const double bc1 = 1.0 - pow((double)a.beta1, (double)t), bc2 = 1.0 - pow((double)a.beta2, (double)t);
+    step_size = (float)((double)a.lr / bc1);
+    bc2_sqrt = (float)sqrt(bc2);
+}
+
+// single block, the whole gradient bucket held in registers (n <= 32 * 1024): norm -> clip -> found_inf -> update.
+// Loads are issued in unrolled batches so their latencies overlap -- one block has no other way to hide them.
+constexpr int OPT_EPT = 32;
+__global__ __launch_bounds__(1024) void k_clip_optim_small(OptimArgs a, float *__restrict__ p, float *__restrict__ g,
+                                                           float *__restrict__ m, float *__restrict__ v, size_t n,
+                                                           long long *__restrict__ step_state, int parity,
+                                                           float *__restrict__ norm_out, ww_step_stats *__restrict__ stats) {
+    __shared__ double sh[1024];
+    __shared__ float coef_sh, ss_sh, bc_sh;
+    __shared__ int skip_sh;
+    float gr[OPT_EPT];
+#pragma unroll
+    for (int k = 0; k < OPT_EPT; ++k) {
+        const size_t i = threadIdx.x + (size_t)k * 1024;
+        gr[k] = i < n ? g[i] : 0.f;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < OPT_EPT; ++k) acc += (double)gr[k] * (double)gr[k];     // same order as k_grad_norm_clip
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(sh[0]);
+        if (norm_out) *norm_out = norm;
+        bool skip = !isfinite(norm);
+        if (stats) {
+            stats->grad_norm = norm;
+            if (skip) stats->found_inf = 1.0f;
+            skip = stats->found_inf != 0.0f;
+        }
+        float c = 1.0f;
+        if (a.max_norm > 0.f) { c = a.max_norm / (norm + 1e-6f); if (c > 1.0f) c = 1.0f; }
+        coef_sh = c;
+        const long long t0 = step_state[parity];
+        step_state[parity ^ 1] = skip ? t0 : t0 + 1;
+        skip_sh = skip;
+        bias_terms(a, t0 + 1, ss_sh, bc_sh);
+    }
+    __syncthreads();
+    const float c = coef_sh, step_size = ss_sh, bc2_sqrt = bc_sh;
+    const bool skip = skip_sh, clip = a.max_norm > 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < OPT_EPT; k0 += 8) {
+        float pr[8], mr[8], vr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t i = threadIdx.x + (size_t)(k0 + k) * 1024;
+            const bool ok = i < n && !skip;
+            pr[k] = ok ? p[i] : 0.f;
+            mr[k] = (ok && m) ? m[i] : 0.f;
+            vr[k] = (ok && v) ? v[i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const size_t i = threadIdx.x + (size_t)(k0 + k) * 1024;
+            if (i >= n) continue;
+            float gi = gr[k0 + k];
+            if (clip) { gi *= c; g[i] = gi; }
+            if (skip) continue;
+            optim_update(a, pr[k], gi, mr[k], vr[k], step_size, bc2_sqrt);
+            p[i] = pr[k];
+            if (m) m[i] = mr[k];
+            if (v) v[i] = vr[k];
+        }
+    }
+}
+
+// grid-wide update for large buckets (the gradient was clipped by k_grad_norm_clip, which also set found_inf)
+__global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__restrict__ p, const float *__restrict__ g,
+                                                      float *__restrict__ m, float *__restrict__ v, size_t n,
+                                                      long long *__restrict__ step_state, int parity,
+                                                      const ww_step_stats *__restrict__ stats) {
+    const bool skip = stats && stats->found_inf != 0.0f;
+    const long long t0 = step_state[parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) step_state[parity ^ 1] = skip ? t0 : t0 + 1;
+    if (skip) return;
+    float step_size, bc2_sqrt;
+    bias_terms(a, t0 + 1, step_size, bc2_sqrt);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float pi = p[i], mi = m ? m[i] : 0.f, vi = v ? v[i] : 0.f;
+        optim_update(a, pi, g[i], mi, vi, step_size, bc2_sqrt);
+        p[i] = pi;
+        if (m) m[i] = mi;
+        if (v) v[i] = vi;
+    }
+}
+
+}  // namespace
+
+extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *flat_params, float *flat_grads,
+                                  float *exp_avg, float *exp_avg_sq, size_t n, int64_t *step_state, int parity,
+                                  float *norm_out, ww_step_stats *stats, ww_stream_t stream) {
+    WW_REQUIRE(ctx && cfg && flat_params && flat_grads && step_state, WW_E_INVALID, "ww_clip_optim_step: null argument");
+    WW_REQUIRE(cfg->kind == WW_OPT_ADAM || cfg->kind == WW_OPT_ADAMW || cfg->kind == WW_OPT_SGD, WW_E_INVALID,
+               "ww_clip_optim_step: unknown optimizer kind %d", cfg->kind);
+    WW_REQUIRE(parity == 0 || parity == 1, WW_E_INVALID, "ww_clip_optim_step: parity must be 0 or 1");
+    WW_REQUIRE(cfg->lr > 0.f, WW_E_INVALID, "Learning rate must be positive, got %g", (double)cfg->lr);
+    WW_REQUIRE(cfg->weight_decay >= 0.f, WW_E_INVALID, "Weight decay must be non-negative, got %g", (double)cfg->weight_decay);
+    if (cfg->kind == WW_OPT_SGD) {
+        WW_REQUIRE(cfg->momentum >= 0.f && cfg->momentum <= 1.f, WW_E_INVALID, "Momentum must be in [0, 1], got %g",
+                   (double)cfg->momentum);
+        WW_REQUIRE(cfg->momentum == 0.f || exp_avg, WW_E_INVALID, "ww_clip_optim_step: SGD momentum needs the buffer (exp_avg)");
+    } else {
+        WW_REQUIRE(cfg->beta1 >= 0.f && cfg->beta1 <= 1.f && cfg->beta2 >= 0.f && cfg->beta2 <= 1.f, WW_E_INVALID,
+                   "Betas must be in [0, 1], got (%g, %g)", (double)cfg->beta1, (double)cfg->beta2);
+        WW_REQUIRE(exp_avg && exp_avg_sq, WW_E_INVALID, "ww_clip_optim_step: Adam needs exp_avg and exp_avg_sq");
+    }
+    if (n == 0) return WW_OK;
+    OptimArgs a{cfg->kind, cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->momentum, cfg->max_norm};
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= (size_t)OPT_EPT * 1024) {
+        ww_prof_scope ps_(ctx, WW_K_CLIP, st);
+        hipLaunchKernelGGL(k_clip_optim_small, dim3(1), dim3(1024), 0, st, a, flat_params, flat_grads, exp_avg, exp_avg_sq,
+                           n, (long long *)step_state, parity, norm_out, stats);
+        WW_LAUNCH_CHECK();
+        return WW_OK;
+    }
+    int rc = ww_grad_norm_clip(ctx, flat_grads, n, cfg->max_norm, norm_out, stats, stream);
+    if (rc) return rc;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(k_optim_update, dim3(grid), dim3(256), 0, st, a, flat_params, flat_grads, exp_avg, exp_avg_sq, n,
+                       (long long *)step_state, parity, stats);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}

@@ -100,6 +100,7 @@ class CNNSmallWakeword(nn.Module):
         self._pptr = None
         self._gptr = None
         self._flat_grad = None
+        self._flat_param = None
         self._grad_views = None
         self._ws = {}
 
@@ -122,6 +123,18 @@ class CNNSmallWakeword(nn.Module):
         for t in tensors:
             if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
                 raise nat.NativeError("cnn_small parameters must be contiguous float32 on the input's device")
+        # parameters become views of ONE flat fp32 bucket (same order as the gradient bucket): the fused clip+optimizer
+        # kernel walks both buckets linearly; state_dict()/load_state_dict() are unaffected (copy_ goes through views)
+        plist = [t for t in tensors if isinstance(t, nn.Parameter)]
+        flat = torch.empty(sum(t.numel() for t in plist), dtype=torch.float32, device=dev)
+        off = 0
+        for t in plist:
+            view = flat[off:off + t.numel()].view_as(t)
+            view.copy_(t.data)
+            t.data = view
+            off += t.numel()
+        self._flat_param = flat
+        key = tuple(t.data_ptr() for t in tensors)
         self._pkey = key
         self._pptr = nat.ptr_array(tensors)
         self._plist = [t for t in tensors if isinstance(t, nn.Parameter)]
@@ -135,6 +148,18 @@ class CNNSmallWakeword(nn.Module):
             off += n
         self._grad_views = views
         self._gptr = nat.ptr_array([views.get(id(t)) for t in tensors])
+
+    @property
+    def flat_param(self):
+        """The flat fp32 parameter bucket every nn.Parameter of this model is a view of (built on first use)."""
+        if self._flat_param is None:
+            self._prepare(self.classifier.weight.device)
+        return self._flat_param
+
+    def grads_in_bucket(self) -> bool:
+        """True when every .grad is the model's own view of ``flat_grad`` (the normal case after one backward)."""
+        return self._grad_views is not None and all(
+            p.grad is not None and p.grad.data_ptr() == self._grad_views[id(p)].data_ptr() for p in self._plist)
 
     @property
     def flat_grad(self):

@@ -58,6 +58,115 @@ class WarmupScheduler:
             self.base_scheduler.load_state_dict(state["base_scheduler_state"])
 
 
+class FlatFusedOptimizer(optim.Optimizer):
+    """Adam / AdamW / SGD-Nesterov for a HIP-backed model whose parameters and gradients live in flat fp32 buckets
+    (``model.flat_param`` / ``model.flat_grad``): gradient clipping and the update are ONE kernel launch
+    (``ww_clip_optim_step``), the "skip a non-finite batch" decision (trainer.py:177-179) is taken on the device, and the
+    step count lives there too.  Update rules, hyper-parameter names, ``param_groups`` and the ``state_dict()`` layout are
+    torch.optim's (``optimizer_factory.py:165-199``), so LR schedulers and reference checkpoints work unchanged."""
+
+    def __init__(self, model: nn.Module, kind: str, lr: float, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, momentum: float = 0.0):
+        from .. import _native as nat
+        self._nat = nat
+        self._kind = {"adam": nat.OPT_ADAM, "adamw": nat.OPT_ADAMW, "sgd": nat.OPT_SGD}[kind]
+        if self._kind == nat.OPT_SGD:
+            defaults = dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay, nesterov=True, maximize=False,
+                            foreach=None, differentiable=False, fused=None)
+        else:
+            defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                            foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(list(model.parameters()), defaults)
+        self._model = model
+        flat = model.flat_param
+        if not flat.is_cuda:
+            raise nat.NativeError("FlatFusedOptimizer needs the model on an MI355X ('cuda') device")
+        self._flat_ptr = flat.data_ptr()
+        self._m = torch.zeros_like(flat)
+        self._v = torch.zeros_like(flat) if self._kind != nat.OPT_SGD else None
+        self._step_state = torch.zeros(2, dtype=torch.int64, device=flat.device)
+        self._parity = 0
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=flat.device)   # pre-clip norm of the last step
+
+    # ------------------------------------------------------------------ the step
+    def _cfg(self, max_norm):
+        g = self.param_groups[0]
+        b1, b2 = g.get("betas", (0.0, 0.0))
+        return self._nat.OptimCfg(self._kind, g["lr"], b1, b2, g.get("eps", 0.0), g["weight_decay"], g.get("momentum", 0.0),
+                                  max_norm)
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm: float = 0.0, stats=None):
+        """``max_norm > 0`` also clips (clip_grad_norm_ semantics, in place on the bucket); ``stats`` is the step's
+        device ``ww_step_stats`` (found_inf gate, grad_norm output)."""
+        if closure is not None:
+            raise ValueError("FlatFusedOptimizer does not support closures")
+        model = self._model
+        if model.flat_param.data_ptr() != self._flat_ptr:
+            raise self._nat.NativeError("the model's parameter bucket moved after the optimizer was created "
+                                        "(model.to(...) / dtype change): create the optimizer afterwards")
+        if model.flat_grad is None or all(p.grad is None for p in self.param_groups[0]["params"]):
+            return None                                      # nothing to do, like torch's optimizers
+        if not model.grads_in_bucket():                      # gradients were accumulated outside the bucket: gather
+            off = 0
+            for p in self.param_groups[0]["params"]:
+                n = p.numel()
+                model.flat_grad[off:off + n].copy_(p.grad.reshape(-1) if p.grad is not None else torch.zeros(n, device=p.device))
+                off += n
+        self._nat.clip_optim_step_(self._cfg(max_norm), model.flat_param, model.flat_grad, self._m, self._v,
+                                   self._step_state, self._parity, norm_out=self.grad_norm, stats=stats)
+        self._parity ^= 1
+        return None
+
+    def step_count(self) -> int:
+        """Number of applied (not skipped) updates; synchronises."""
+        return int(self._step_state[self._parity].item())
+
+    # ------------------------------------------------------------------ torch-compatible state
+    def _views(self, flat):
+        out, off = [], 0
+        for p in self.param_groups[0]["params"]:
+            out.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return out
+
+    def state_dict(self):
+        t = self.step_count()
+        self.state.clear()
+        if t > 0:
+            params = self.param_groups[0]["params"]
+            if self._kind == self._nat.OPT_SGD:
+                for p, m in zip(params, self._views(self._m)):
+                    self.state[p] = {"momentum_buffer": m.clone()}
+            else:
+                for p, m, v in zip(params, self._views(self._m), self._views(self._v)):
+                    self.state[p] = {"step": torch.tensor(float(t)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        sd = super().state_dict()
+        self.state.clear()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        params = self.param_groups[0]["params"]
+        t = 0
+        self._m.zero_()
+        if self._v is not None:
+            self._v.zero_()
+        for p, m, v in zip(params, self._views(self._m), self._views(self._v) if self._v is not None else [None] * len(params)):
+            st = self.state.get(p)
+            if not st:
+                continue
+            if "momentum_buffer" in st and st["momentum_buffer"] is not None:
+                m.copy_(st["momentum_buffer"])
+                t = max(t, 1)
+            if "exp_avg" in st:
+                m.copy_(st["exp_avg"])
+                v.copy_(st["exp_avg_sq"])
+                t = max(t, int(float(st["step"])))
+        self.state.clear()
+        self._step_state.fill_(t)
+
+
 def create_optimizer(model: nn.Module, optimizer_name: str = "adam", learning_rate: float = 0.001,
                      weight_decay: float = 1e-4, momentum: float = 0.9, betas: Tuple[float, float] = (0.9, 0.999),
                      **kwargs) -> optim.Optimizer:
@@ -71,6 +180,10 @@ def create_optimizer(model: nn.Module, optimizer_name: str = "adam", learning_ra
         raise ValueError(f"Betas must be in [0, 1], got {betas}")
     name = optimizer_name.lower()
     params = list(model.parameters())
+    if (name in ("adam", "adamw", "sgd") and not kwargs and hasattr(model, "flat_param") and params
+            and all(p.is_cuda for p in params)):
+        # HIP-backed model: clip + update in one launch on the flat buckets (same update rules, same state_dict layout)
+        return FlatFusedOptimizer(model, name, learning_rate, betas=betas, weight_decay=weight_decay, momentum=momentum)
     if name in ("adam", "adamw") and "fused" not in kwargs and params and all(p.is_cuda for p in params):
         kwargs["fused"] = True        # one multi-tensor kernel per step instead of ~9 (same update rule)
     if name == "adam":

@@ -39,8 +39,8 @@ from ..config.cuda_utils import enforce_cuda
 from ..models.architectures import CNNSmallWakeword
 from ..models.losses import create_loss_function, _NativeLoss
 from .metrics import MetricMonitor, MetricResults, MetricsTracker
-from .optimizer_factory import (clip_gradients, create_grad_scaler, create_optimizer_and_scheduler,
-                                get_learning_rate)
+from .optimizer_factory import (FlatFusedOptimizer, clip_gradients, create_grad_scaler,
+                                create_optimizer_and_scheduler, get_learning_rate)
 
 logger = logging.getLogger(__name__)
 
@@ -119,7 +119,8 @@ class Trainer:
         # native step pipelining (see _launch_native): the optimizer consumes the device-side found_inf flag, so no
         # host read sits between backward and optimizer.step(); with deferred_metrics a step's 48-byte stats are
         # resolved while the NEXT step is already running (callbacks fire one step late, same order and content).
-        self._skip_on_device = bool(getattr(self.optimizer, "_step_supports_amp_scaling", False))
+        self._fused_optimizer = isinstance(self.optimizer, FlatFusedOptimizer)    # clip + update = one launch
+        self._skip_on_device = self._fused_optimizer or bool(getattr(self.optimizer, "_step_supports_amp_scaling", False))
         self.deferred_metrics = (bool(getattr(config.training, "deferred_metrics", True)) and self.native
                                  and self._native_loss and self._skip_on_device)
         self._pending = None
@@ -252,8 +253,12 @@ class Trainer:
         loss.backward()
         self._allreduce_grads()
         stats = self.criterion.last_stats
-        nat.grad_norm_clip_(self.model.flat_grad, max(float(self.gradient_clip), 0.0), stats=stats)
-        if self._skip_on_device:
+        if self._fused_optimizer:
+            # clip_gradients + "skip a non-finite batch" + optimizer.step() (trainer.py:177-193) in ONE launch
+            self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats)
+        else:
+            nat.grad_norm_clip_(self.model.flat_grad, max(float(self.gradient_clip), 0.0), stats=stats)
+        if self._skip_on_device and not self._fused_optimizer:
             # the reference skips a batch whose loss is not finite (trainer.py:177-179) or whose targets are invalid
             # (losses.py:72) before touching the parameters; here the fused optimizer gets that decision as a
             # device flag (the mechanism GradScaler uses), so nothing on the host waits for the GPU
