@@ -412,7 +412,7 @@ struct DwGeom {
     long items;
 };
 
-constexpr int DW_HS = 10;   // max rows per strip segment (matches ww_conv_fwd.hip)
+constexpr int DW_HS = 20;   // max rows per strip segment (matches ww_conv_fwd.hip)
 
 template <typename T>
 __device__ __forceinline__ void dwb_issue(const T *__restrict__ gimg, const T *__restrict__ yimg, int h, int w0, int H,

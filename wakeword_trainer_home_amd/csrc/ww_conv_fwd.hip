@@ -105,7 +105,7 @@ struct DwGeom {
     long items;
 };
 
-constexpr int DW_HS = 10;   // max rows per strip segment (compile-time so the row loop fully unrolls)
+constexpr int DW_HS = 20;   // max rows per strip segment (compile-time so the row loop fully unrolls)
 
 // raw (pre-BatchNorm) row of 6 pixels around the strip; addresses are clamped so the loads are branch-free
 template <typename T>
