@@ -223,6 +223,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    t_issue = time.perf_counter() - t0                 # host time to enqueue the K steps (diagnostic: host- vs GPU-bound)
     for done in trainer._flush_pending():
         last_done[0] = done
     fence()
@@ -260,6 +261,7 @@ def main():
                          "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": launches,
                          "algorithmic_bytes_per_launch": algo,
                          "step_frac_of_hbm_roofline": round(value / world * step_algo_bytes(esz) / (HBM_PEAK_GBS * 1e9), 4)},
+            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
             "kernel_ms_per_step_warmup": {k: round(v[0] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (bounded sample, rank 0)

@@ -234,7 +234,9 @@ int ww_grad_norm_clip(ww_ctx *ctx, float *flat_grads, size_t n, float max_norm, 
  * max_norm <= 0: norm only.  exp_avg doubles as SGD's momentum buffer; exp_avg_sq is unused for SGD (may be NULL).
  * step_state: int64[2] on the device, both 0 initially; call k reads slot[parity] and writes slot[parity^1]
  * (callers alternate parity 0,1,0,...).  When stats->found_inf != 0 (or the gradient norm is not finite) nothing is
- * updated and the step count does not advance -- the reference's "skip this batch" (trainer.py:177-179).            */
+ * updated and the step count does not advance -- the reference's "skip this batch" (trainer.py:177-179).
+ * stats_host (nullable): PINNED host memory (hipHostMalloc / torch pin_memory) that receives a copy of *stats, written
+ * by the kernel itself -- the step's single device->host record without a copy command in the stream.              */
 enum { WW_OPT_ADAM = 0, WW_OPT_ADAMW = 1, WW_OPT_SGD = 2 };
 typedef struct {
     int32_t kind;
@@ -243,7 +245,8 @@ typedef struct {
 } ww_optim_cfg;
 int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *flat_params, float *flat_grads, float *exp_avg,
                        float *exp_avg_sq, size_t n, int64_t *step_state, int parity, float *norm_out,
-                       ww_step_stats *stats /* nullable */, ww_stream_t stream);
+                       ww_step_stats *stats /* nullable */, ww_step_stats *stats_host /* nullable */,
+                       ww_stream_t stream);
 
 /* ------------------------------------------------------------------ measurement
  * Opt-in timing of kernel classes with hipEvents recorded on the launch stream around the

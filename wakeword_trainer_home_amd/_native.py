@@ -74,7 +74,7 @@ _SIGS = {
     "ww_audio_rir_spectra": (C.c_int, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "ww_audio_augment": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, C.POINTER(AudioAugCfg), _u64, _u64,
                                    _u64, _vp, _vp, _sz, _vp]),
-    "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp]),
+    "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp]),
     "ww_layer_scratch_bytes": (_sz, []),
     "ww_conv_stem_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
     "ww_dwconv3x3_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
@@ -295,16 +295,20 @@ def audio_augment(wave, rirs, noises, rir_prob, noise_prob, snr_min_db, snr_max_
 
 
 def clip_optim_step_(cfg: OptimCfg, flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, parity, norm_out=None,
-                     stats=None):
-    """In place: clip flat_grads to cfg.max_norm, then one Adam/AdamW/SGD step on flat_params (skipped on found_inf)."""
+                     stats=None, stats_host=None):
+    """In place: clip flat_grads to cfg.max_norm, then one Adam/AdamW/SGD step on flat_params (skipped on found_inf).
+    ``stats_host``: pinned uint8[48] host tensor the kernel copies the step's ww_step_stats into."""
     dev = _dev(flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, norm_out, stats)
+    if stats_host is not None and not (stats_host.is_pinned() and stats_host.numel() * stats_host.element_size() >= STEP_STATS_BYTES):
+        raise ValueError("stats_host must be a pinned host tensor of at least 48 bytes")
     if flat_params.dtype != torch.float32 or flat_grads.dtype != torch.float32 or flat_params.numel() != flat_grads.numel():
         raise ValueError("parameter and gradient buckets must be float32 and of equal length")
     if step_state.dtype != torch.int64 or step_state.numel() != 2:
         raise ValueError("step_state must be an int64 tensor of two elements")
     with torch.cuda.device(dev):
         _check(load().ww_clip_optim_step(ctx(dev), C.byref(cfg), _p(flat_params), _p(flat_grads), _p(exp_avg), _p(exp_avg_sq),
-                                         flat_params.numel(), _p(step_state), parity, _p(norm_out), _p(stats), _stream(dev)),
+                                         flat_params.numel(), _p(step_state), parity, _p(norm_out), _p(stats),
+                                         None if stats_host is None else C.c_void_p(stats_host.data_ptr()), _stream(dev)),
                "ww_clip_optim_step")
 
 

@@ -51,7 +51,9 @@ __global__ __launch_bounds__(1024) void k_head_bwd(const float *__restrict__ dlo
             uint32_t rr[4];
             ww_philox(step_lo, step_hi, (uint32_t)(sample_offset + (uint64_t)b), (WW_TAG_DROPOUT << 24) | (uint32_t)(c >> 2),
                       seed_lo, seed_hi, rr);
-            dp = ((uint64_t)rr[c & 3] >= drop_thresh) ? dp * drop_scale : 0.f;
+            const int q = c & 3;   // selected with compares: a dynamically indexed local array would live in scratch
+            const uint32_t rv = q == 0 ? rr[0] : q == 1 ? rr[1] : q == 2 ? rr[2] : rr[3];
+            dp = ((uint64_t)rv >= drop_thresh) ? dp * drop_scale : 0.f;
         }
         dp *= inv_hw;  // d mean / d element
         dpool[(size_t)b * 64 + c] = dp;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(1024) void k_head_bwd(const float *__restrict__ dlo
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             double a = 0.0;
-#pragma unroll
+#pragma unroll 4      // all 96 loads in flight at once spilled; a kernel with scratch pays ~6 us on each side of its dispatch
             for (int q = 0; q < 16; ++q) a += sh[k][64 * q + c];
             t[k] = a;
         }
@@ -458,8 +460,8 @@ template <typename T>
 __device__ __forceinline__ void dwb_row(const typename Act<T>::raw2 (&yc)[4], T *__restrict__ gin_img, int h, int w0,
                                         int W, int cl,
                                         const float2 (&rs0)[6], const float2 (&rs1)[6], const float2 (&rs2)[6],
-                                        const float (&wa)[9], const float (&wb)[9], float2 sc, float2 sf, float2 mu,
-                                        float2 rsd, float (&dwa)[9], float (&dwb)[9], float &s1a, float &s1b, float &s2a,
+                                        const float (&wa)[9], const float (&wb)[9], float2 sc, float2 sf,
+                                        float (&dwa)[9], float (&dwb)[9], float &s1a, float &s1b, float &s2a,
                                         float &s2b) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -482,8 +484,9 @@ __device__ __forceinline__ void dwb_row(const typename Act<T>::raw2 (&yc)[4], T 
             const float g0 = go.x, g1 = go.y;
             Act<T>::st2(gin_img + ((size_t)h * W + w0 + i) * 64 + 2 * cl, go);
             s1a += g0; s1b += g1;
-            s2a = fmaf(g0, (yv.x - mu.x) * rsd.x, s2a);
-            s2b = fmaf(g1, (yv.y - mu.y) * rsd.y, s2b);
+            s2a = fmaf(g0, yv.x, s2a);      // sum g*y; turned into sum g*yhat once, after the loop (4 VGPRs less in it:
+            s2b = fmaf(g1, yv.y, s2b);      // with them the bf16 kernel spilled, and a kernel with scratch pays ~6 us on
+                                            // each side of its dispatch)
         }
     }
 }
@@ -510,8 +513,6 @@ __global__ __launch_bounds__(256, Act<T>::is_f32 ? 2 : 3) void k_dw_bwd(const T 
     const float2 cC = *reinterpret_cast<const float2 *>(coef + 128 + 2 * cl);
     const float2 sc = *reinterpret_cast<const float2 *>(ss_in + 2 * cl);
     const float2 sf = *reinterpret_cast<const float2 *>(ss_in + 64 + 2 * cl);
-    const float2 mu = *reinterpret_cast<const float2 *>(mr_in + 2 * cl);
-    const float2 rsd = *reinterpret_cast<const float2 *>(mr_in + 64 + 2 * cl);
     float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
     const size_t img_stride = (size_t)gm.H * gm.W * 64;
     for (long item = (long)blockIdx.x * 8 + slot; item < gm.items; item += (long)gridDim.x * 8) {
@@ -550,13 +551,19 @@ __global__ __launch_bounds__(256, Act<T>::is_f32 ? 2 : 3) void k_dw_bwd(const T 
                     dwb_issue_centre<T>(yiimg, h + 1, w0, gm.H, gm.W, cl, ayc);
                 }
                 dwb_finish<T>(rg, ry, h + 1, w0, gm.H, gm.W, cA, cB, cC, rows[(ii + 2) % 3]);
-                dwb_row<T>(yc, giimg, h, w0, gm.W, cl, rows[(ii + 2) % 3], rows[(ii + 1) % 3], rows[ii % 3], wa, wb, sc, sf, mu,
-                        rsd, dwa, dwb, s1a, s1b, s2a, s2b);
+                dwb_row<T>(yc, giimg, h, w0, gm.W, cl, rows[(ii + 2) % 3], rows[(ii + 1) % 3], rows[ii % 3], wa, wb, sc, sf,
+                        dwa, dwb, s1a, s1b, s2a, s2b);
             }
           }
         }
     }
-    // statistics partial
+    // statistics partial: sum g*yhat = rstd * (sum g*y - mean * sum g)
+    {
+        const float2 mu = *reinterpret_cast<const float2 *>(mr_in + 2 * cl);
+        const float2 rsd = *reinterpret_cast<const float2 *>(mr_in + 64 + 2 * cl);
+        s2a = rsd.x * (s2a - mu.x * s1a);
+        s2b = rsd.y * (s2b - mu.y * s1b);
+    }
     sh[slot * 128 + 2 * cl] = s1a;       sh[slot * 128 + 2 * cl + 1] = s1b;
     sh[slot * 128 + 64 + 2 * cl] = s2a;  sh[slot * 128 + 64 + 2 * cl + 1] = s2b;
     __syncthreads();

@@ -189,7 +189,7 @@ extern "C" size_t ww_layer_scratch_bytes(void) {
 __device__ inline double ww_col128_sum(const float *__restrict__ partials, int rows, double *sh /*32*128*/) {
     const int c4 = threadIdx.x & 31, part = threadIdx.x >> 5;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 4
+#pragma unroll 16
     for (int r = part; r < rows; r += 32) {
         const float4 v = *reinterpret_cast<const float4 *>(partials + (size_t)r * 128 + 4 * c4);
         a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
@@ -289,7 +289,7 @@ __device__ __forceinline__ void colsum_body(const float *__restrict__ partials, 
     const int col = blk * 64 + 4 * c4;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (col < cols) {
-#pragma unroll 4
+#pragma unroll 8
         for (int r = part; r < rows; r += 64) {
             const float4 v = *reinterpret_cast<const float4 *>(partials + (size_t)r * cols + col);
             a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;

@@ -50,7 +50,8 @@ constexpr int OPT_EPT = 32;
 __global__ __launch_bounds__(1024) void k_clip_optim_small(OptimArgs a, float *__restrict__ p, float *__restrict__ g,
                                                            float *__restrict__ m, float *__restrict__ v, size_t n,
                                                            long long *__restrict__ step_state, int parity,
-                                                           float *__restrict__ norm_out, ww_step_stats *__restrict__ stats) {
+                                                           float *__restrict__ norm_out, ww_step_stats *__restrict__ stats,
+                                                           ww_step_stats *__restrict__ stats_host) {
     __shared__ double sh[1024];
     __shared__ float coef_sh, ss_sh, bc_sh;
     __shared__ int skip_sh;
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(1024) void k_clip_optim_small(OptimArgs a, float *_
             stats->grad_norm = norm;
             if (skip) stats->found_inf = 1.0f;
             skip = stats->found_inf != 0.0f;
+            if (stats_host) *stats_host = *stats;     // the step's one record for the host, written straight to pinned memory
         }
         float c = 1.0f;
         if (a.max_norm > 0.f) { c = a.max_norm / (norm + 1e-6f); if (c > 1.0f) c = 1.0f; }
@@ -119,10 +121,14 @@ __global__ __launch_bounds__(1024) void k_clip_optim_small(OptimArgs a, float *_
 __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__restrict__ p, const float *__restrict__ g,
                                                       float *__restrict__ m, float *__restrict__ v, size_t n,
                                                       long long *__restrict__ step_state, int parity,
-                                                      const ww_step_stats *__restrict__ stats) {
+                                                      const ww_step_stats *__restrict__ stats,
+                                                      ww_step_stats *__restrict__ stats_host) {
     const bool skip = stats && stats->found_inf != 0.0f;
     const long long t0 = step_state[parity];
-    if (blockIdx.x == 0 && threadIdx.x == 0) step_state[parity ^ 1] = skip ? t0 : t0 + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        step_state[parity ^ 1] = skip ? t0 : t0 + 1;
+        if (stats && stats_host) *stats_host = *stats;
+    }
     if (skip) return;
     float step_size, bc2_sqrt;
     bias_terms(a, t0 + 1, step_size, bc2_sqrt);
@@ -139,8 +145,14 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
 
 extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *flat_params, float *flat_grads,
                                   float *exp_avg, float *exp_avg_sq, size_t n, int64_t *step_state, int parity,
-                                  float *norm_out, ww_step_stats *stats, ww_stream_t stream) {
+                                  float *norm_out, ww_step_stats *stats, ww_step_stats *stats_host,
+                                  ww_stream_t stream) {
     WW_REQUIRE(ctx && cfg && flat_params && flat_grads && step_state, WW_E_INVALID, "ww_clip_optim_step: null argument");
+    ww_step_stats *stats_host_dev = nullptr;
+    if (stats_host) {
+        WW_REQUIRE(stats != nullptr, WW_E_INVALID, "ww_clip_optim_step: stats_host needs stats");
+        WW_HIP(hipHostGetDevicePointer((void **)&stats_host_dev, stats_host, 0));   // fails for pageable memory
+    }
     WW_REQUIRE(cfg->kind == WW_OPT_ADAM || cfg->kind == WW_OPT_ADAMW || cfg->kind == WW_OPT_SGD, WW_E_INVALID,
                "ww_clip_optim_step: unknown optimizer kind %d", cfg->kind);
     WW_REQUIRE(parity == 0 || parity == 1, WW_E_INVALID, "ww_clip_optim_step: parity must be 0 or 1");
@@ -161,7 +173,7 @@ extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *f
     if (n <= (size_t)OPT_EPT * 1024) {
         ww_prof_scope ps_(ctx, WW_K_CLIP, st);
         hipLaunchKernelGGL(k_clip_optim_small, dim3(1), dim3(1024), 0, st, a, flat_params, flat_grads, exp_avg, exp_avg_sq,
-                           n, (long long *)step_state, parity, norm_out, stats);
+                           n, (long long *)step_state, parity, norm_out, stats, stats_host_dev);
         WW_LAUNCH_CHECK();
         return WW_OK;
     }
@@ -169,7 +181,7 @@ extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *f
     if (rc) return rc;
     const int grid = (int)std::min<size_t>((n + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(k_optim_update, dim3(grid), dim3(256), 0, st, a, flat_params, flat_grads, exp_avg, exp_avg_sq, n,
-                       (long long *)step_state, parity, stats);
+                       (long long *)step_state, parity, stats, stats_host_dev);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

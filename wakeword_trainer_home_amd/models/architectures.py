@@ -233,6 +233,21 @@ class CNNSmallWakeword(nn.Module):
             else:
                 p.grad.add_(views[id(p)])
 
+    def train_step_native(self, x: torch.Tensor, targets: torch.Tensor, criterion):
+        """forward -> native loss -> backward as three C-ABI calls, without the autograd engine (what Trainer's native step
+        uses: the loss kernel already returns dL/dlogits, so nothing needs recording).  Gradients land in the flat bucket
+        exactly as after ``criterion(model(x), targets).backward()``; returns the device ``ww_step_stats`` tensor."""
+        x = self._check_input(x)
+        if not self.training:
+            raise RuntimeError("train_step_native() needs model.train()")
+        if any(p.grad is not None for p in self._plist or ()):
+            raise RuntimeError("train_step_native() writes fresh gradients: call optimizer.zero_grad(set_to_none=True) first")
+        self._prepare(x.device)
+        logits, slot, step = self._launch_forward(x, training=True)
+        stats, dlogits = criterion.native_fwd_bwd(logits, targets)
+        self._launch_backward(x, dlogits, slot, step)
+        return stats
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self._check_input(x)
         if self.training and torch.is_grad_enabled():

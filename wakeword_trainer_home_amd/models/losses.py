@@ -47,6 +47,16 @@ class _NativeLoss(nn.Module):
             self._stats[dev] = torch.zeros(nat.STEP_STATS_BYTES, dtype=torch.uint8, device=dev)
         return self._stats[dev]
 
+    def native_fwd_bwd(self, logits: torch.Tensor, target: torch.Tensor):
+        """Loss kernel without autograd: -> (device ww_step_stats, dL/dlogits).  Target range errors are reported through
+        ``stats.bad_target`` (the caller reads the stats once per step)."""
+        if logits.dim() != 2 or logits.size(1) != 2 or target.dim() != 1 or logits.size(0) != target.size(0):
+            raise ValueError(f"expected logits (B,2) and targets (B,), got {tuple(logits.shape)} and {tuple(target.shape)}")
+        _, dl, stats = nat.ce2_loss_fwd_bwd(logits.contiguous(), target.long().contiguous(), self._kind, self._eps,
+                                            self._alpha, self._gamma, stats=self._stats_for(logits.device))
+        self.last_stats = stats
+        return stats, dl
+
     def forward(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         if pred.dim() != 2:
             raise ValueError(f"Predictions must be 2D (batch, num_classes), got shape {pred.shape}")

@@ -96,9 +96,10 @@ class FlatFusedOptimizer(optim.Optimizer):
                                   max_norm)
 
     @torch.no_grad()
-    def step(self, closure=None, max_norm: float = 0.0, stats=None):
+    def step(self, closure=None, max_norm: float = 0.0, stats=None, stats_host=None):
         """``max_norm > 0`` also clips (clip_grad_norm_ semantics, in place on the bucket); ``stats`` is the step's
-        device ``ww_step_stats`` (found_inf gate, grad_norm output)."""
+        device ``ww_step_stats`` (found_inf gate, grad_norm output); ``stats_host`` a pinned 48-byte tensor the kernel
+        copies it to."""
         if closure is not None:
             raise ValueError("FlatFusedOptimizer does not support closures")
         model = self._model
@@ -114,7 +115,8 @@ class FlatFusedOptimizer(optim.Optimizer):
                 model.flat_grad[off:off + n].copy_(p.grad.reshape(-1) if p.grad is not None else torch.zeros(n, device=p.device))
                 off += n
         self._nat.clip_optim_step_(self._cfg(max_norm), model.flat_param, model.flat_grad, self._m, self._v,
-                                   self._step_state, self._parity, norm_out=self.grad_norm, stats=stats)
+                                   self._step_state, self._parity, norm_out=self.grad_norm, stats=stats,
+                                   stats_host=stats_host)
         self._parity ^= 1
         return None
 

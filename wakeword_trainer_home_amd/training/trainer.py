@@ -248,14 +248,16 @@ class Trainer:
         targets.record_stream(main)
         self.model.sample_offset = self.rank * inputs.shape[0]
         self.optimizer.zero_grad(set_to_none=True)
-        outputs = self.model(inputs)
-        loss = self.criterion(outputs, targets)
-        loss.backward()
+        stats = self.model.train_step_native(inputs, targets, self.criterion)     # fwd, loss, bwd: three C-ABI calls
         self._allreduce_grads()
-        stats = self.criterion.last_stats
+        if self._host_bufs is None:
+            self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        buf = self._host_bufs[self._buf_i]
+        self._buf_i ^= 1
         if self._fused_optimizer:
-            # clip_gradients + "skip a non-finite batch" + optimizer.step() (trainer.py:177-193) in ONE launch
-            self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats)
+            # clip_gradients + "skip a non-finite batch" + optimizer.step() (trainer.py:177-193) in ONE launch, which also
+            # writes the step's 48-byte record into pinned host memory
+            self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats, stats_host=buf)
         else:
             nat.grad_norm_clip_(self.model.flat_grad, max(float(self.gradient_clip), 0.0), stats=stats)
         if self._skip_on_device and not self._fused_optimizer:
@@ -268,11 +270,8 @@ class Trainer:
                 self.optimizer.step()
             finally:
                 del self.optimizer.grad_scale, self.optimizer.found_inf
-        if self._host_bufs is None:
-            self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
-        buf = self._host_bufs[self._buf_i]
-        self._buf_i ^= 1
-        buf.copy_(stats, non_blocking=True)
+        if not self._fused_optimizer:
+            buf.copy_(stats, non_blocking=True)
         event = torch.cuda.Event()
         event.record()
         launched = (batch_idx, buf, event)
