@@ -228,6 +228,28 @@ int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64_t *targets
  * only the norm is computed.  norm_out (nullable) receives the pre-clip L2 norm.          */
 int ww_grad_norm_clip(ww_ctx *ctx, float *flat_grads, size_t n, float max_norm, float *norm_out,
                       ww_step_stats *stats /* nullable: grad_norm and found_inf are updated */, ww_stream_t stream);
+/* ------------------------------------------------------------------ dense layers on the matrix cores (K8)
+ * nn.Linear (+ Hardswish + Dropout) forward/backward: the classifier the reference puts on MobileNetV3,
+ *   Sequential(Linear(576,1024), Hardswish(), Dropout(p), Linear(1024,num_classes))   (src/models/architectures.py:105-111).
+ * x (M,K), w (N,K) = nn.Linear.weight, bias (N) nullable, y/pre/dy (M,N), dx (M,K), dw (N,K), db (N); all fp32, row-major.
+ * mode WW_ACT_F32: fp32 MFMA (v_mfma_f32_32x32x2_f32), parity mode; WW_ACT_BF16: operands rounded to bf16, fp32
+ * accumulation (v_mfma_f32_32x32x16_bf16).  epi (nullable): activation, then dropout drawn from the Philox stream
+ * ctr = (step, sample_offset + row, TAG_DROPOUT<<24 | col>>2), lane col&3 (dropout_p = 0 in eval).  `pre` receives the
+ * pre-activation the backward of the activation needs.                                                              */
+#define WW_LIN_NONE 0
+#define WW_LIN_HARDSWISH 1
+typedef struct {
+    int32_t act;
+    float dropout_p;
+    uint64_t seed, step, sample_offset;
+} ww_linear_epi;
+int ww_linear_mfma_fwd(ww_ctx *ctx, int mode, const float *x, const float *w, const float *bias, int M, int K, int N,
+                       const ww_linear_epi *epi, float *pre /* nullable */, float *y, ww_stream_t stream);
+size_t ww_linear_mfma_bwd_scratch_bytes(int M, int K, int N);
+int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const float *w, const float *pre /* nullable if no act */,
+                       const float *dy, int M, int K, int N, const ww_linear_epi *epi, float *dx /* nullable */, float *dw,
+                       float *db /* nullable */, void *scratch, size_t scratch_bytes, ww_stream_t stream);
+
 /* Fused clip + optimizer step on flat fp32 buckets.  Replaces, for one step, the reference's
  * clip_gradients(...) ; optimizer.step()  (src/training/trainer.py:185-193) with torch.optim's own update rules
  * (create_optimizer, src/training/optimizer_factory.py:165-199: Adam, AdamW, SGD with nesterov=True).

@@ -43,6 +43,14 @@ class AudioAugCfg(C.Structure):
     _fields_ = [("rir_prob", C.c_float), ("noise_prob", C.c_float), ("snr_min_db", C.c_float), ("snr_max_db", C.c_float)]
 
 
+class LinearEpi(C.Structure):
+    _fields_ = [("act", C.c_int32), ("dropout_p", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
+                ("sample_offset", C.c_uint64)]
+
+
+LIN_NONE, LIN_HARDSWISH = 0, 1
+
+
 class OptimCfg(C.Structure):
     _fields_ = [("kind", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("weight_decay", C.c_float), ("momentum", C.c_float), ("max_norm", C.c_float)]
@@ -74,6 +82,10 @@ _SIGS = {
     "ww_audio_rir_spectra": (C.c_int, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "ww_audio_augment": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, C.POINTER(AudioAugCfg), _u64, _u64,
                                    _u64, _vp, _vp, _sz, _vp]),
+    "ww_linear_mfma_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, C.POINTER(LinearEpi), _vp, _vp, _vp]),
+    "ww_linear_mfma_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
+    "ww_linear_mfma_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(LinearEpi), _vp, _vp, _vp, _vp, _sz,
+                                     _vp]),
     "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp]),
     "ww_layer_scratch_bytes": (_sz, []),
     "ww_conv_stem_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
@@ -292,6 +304,51 @@ def audio_augment(wave, rirs, noises, rir_prob, noise_prob, snr_min_db, snr_max_
                                        seed, step, sample_offset, _p(choices), _p(scratch), nbytes, _stream(dev)),
                "ww_audio_augment")
     return (out, choices) if want_choices else out
+
+
+def _lin_check(x, w, bias):
+    if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1] or x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise ValueError(f"linear: need float32 x (M,K) and weight (N,K), got {tuple(x.shape)} and {tuple(w.shape)}")
+    if bias is not None and (bias.dim() != 1 or bias.shape[0] != w.shape[0] or bias.dtype != torch.float32):
+        raise ValueError("linear: bias must be float32 (N,)")
+
+
+def linear_mfma_fwd(x, w, bias=None, act=LIN_NONE, dropout_p=0.0, seed=0, step=0, sample_offset=0, mode=torch.float32,
+                    want_pre=False):
+    """y = dropout(act(x @ w.T + bias)) on the matrix cores -> y [, pre]."""
+    dev = _dev(x, w, bias)
+    _lin_check(x, w, bias)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=dev)
+    pre = torch.empty((M, N), dtype=torch.float32, device=dev) if want_pre else None
+    epi = LinearEpi(act, dropout_p, seed, step, sample_offset)
+    with torch.cuda.device(dev):
+        _check(load().ww_linear_mfma_fwd(ctx(dev), act_code(mode), _p(x.contiguous()), _p(w.contiguous()), _p(bias), M, K, N,
+                                         C.byref(epi), _p(pre), _p(y), _stream(dev)), "ww_linear_mfma_fwd")
+    return (y, pre) if want_pre else y
+
+
+def linear_mfma_bwd(x, w, pre, dy, act=LIN_NONE, dropout_p=0.0, seed=0, step=0, sample_offset=0, mode=torch.float32,
+                    need_dx=True, need_db=True):
+    """-> (dx | None, dw, db | None)."""
+    dev = _dev(x, w, pre, dy)
+    _lin_check(x, w, None)
+    M, K = x.shape
+    N = w.shape[0]
+    if tuple(dy.shape) != (M, N) or dy.dtype != torch.float32:
+        raise ValueError(f"linear backward: dy must be float32 {(M, N)}, got {tuple(dy.shape)}")
+    dx = torch.empty((M, K), dtype=torch.float32, device=dev) if need_dx else None
+    dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty(N, dtype=torch.float32, device=dev) if need_db else None
+    nbytes = load().ww_linear_mfma_bwd_scratch_bytes(M, K, N)
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    epi = LinearEpi(act, dropout_p, seed, step, sample_offset)
+    with torch.cuda.device(dev):
+        _check(load().ww_linear_mfma_bwd(ctx(dev), act_code(mode), _p(x.contiguous()), _p(w.contiguous()), _p(pre),
+                                         _p(dy.contiguous()), M, K, N, C.byref(epi), _p(dx), _p(dw), _p(db), _p(scratch), nbytes,
+                                         _stream(dev)), "ww_linear_mfma_bwd")
+    return dx, dw, db
 
 
 def clip_optim_step_(cfg: OptimCfg, flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, parity, norm_out=None,

@@ -61,7 +61,7 @@ struct ww_feat_tables {
 // ---- opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
 enum {
     WW_K_LOGMEL = 0, WW_K_STEM_FWD, WW_K_DW_FWD, WW_K_PW_FWD, WW_K_GAP_FWD, WW_K_HEAD_LOSS, WW_K_PW_BWD, WW_K_DW_BWD,
-    WW_K_STEM_BWD, WW_K_FINALIZE, WW_K_CLIP, WW_K_AUDIO_AUG, WW_K_NCLASS
+    WW_K_STEM_BWD, WW_K_FINALIZE, WW_K_CLIP, WW_K_AUDIO_AUG, WW_K_LINEAR, WW_K_NCLASS
 };
 struct ww_prof_rec { int cls; hipEvent_t a, b; };
 struct ww_ctx {

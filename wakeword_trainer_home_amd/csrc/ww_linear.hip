@@ -1,0 +1,332 @@
+// Dense layers on the matrix cores (ww_linear_mfma_{fwd,bwd}; K8 = the 576 -> 1024 -> num_classes head
+// the reference puts on MobileNetV3, src/models/architectures.py:105-111: Linear, Hardswish, Dropout, Linear).
+//   fwd : pre = x W^T + b ;  y = dropout(act(pre))
+//   bwd : dpre = dy * dropout * act'(pre) ;  dx = dpre W ;  dW = dpre^T x ;  db = colsum(dpre)
+// One tiled GEMM kernel serves all three products: C[i][j] = sum_k A(i,k) B(j,k) with either operand read K-contiguous
+// (nn.Linear's own layouts for the forward) or transposed on the way into LDS (dx, dW).  64x64 block tile, 4 wavefronts x
+// one 32x32 MFMA tile, K staged 32 at a time.  mode WW_ACT_F32: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
+// accumulation: the parity mode); WW_ACT_BF16: operands rounded to bf16 at LDS-fill time, v_mfma_f32_32x32x16_bf16
+// (what fp16/bf16 autocast does to nn.Linear; 16x the fp32 matrix rate).  All tensors are fp32 in HBM.
+// Dropout after the activation draws from the same Philox stream as the cnn_small classifier dropout (TAG_DROPOUT,
+// 4 features per draw, global sample index), so the oracle reproduces the mask exactly.
+#include "ww_internal.h"
+#include "ww_act.h"
+#include <algorithm>
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int GT = 64;      // block tile (rows and columns)
+constexpr int GK = 32;      // K per LDS stage
+
+struct GemmOperand {
+    const float *p;
+    long s_row, s_k;    // element (i,k) = p[i*s_row + k*s_k]
+    int rows;           // valid rows
+};
+struct Epilogue {
+    const float *bias;          // per column j (nullable)
+    float *pre;                 // pre-activation out (nullable)
+    int act;                    // WW_LIN_*
+    int use_dropout;
+    float drop_scale;
+    uint64_t drop_thresh;
+    uint32_t seed_lo, seed_hi, step_lo, step_hi;
+    uint64_t sample_offset;
+};
+
+__device__ __forceinline__ float hardswish(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
+__device__ __forceinline__ float hardswish_grad(float x) { return x < -3.f ? 0.f : (x <= 3.f ? x * (1.f / 3.f) + 0.5f : 1.f); }
+__device__ __forceinline__ bool drop_keep(const Epilogue &e, long row, int col) {
+    uint32_t rr[4];
+    ww_philox(e.step_lo, e.step_hi, (uint32_t)(e.sample_offset + (uint64_t)row), (WW_TAG_DROPOUT << 24) | (uint32_t)(col >> 2),
+              e.seed_lo, e.seed_hi, rr);
+    const int q = col & 3;
+    const uint32_t rv = q == 0 ? rr[0] : q == 1 ? rr[1] : q == 2 ? rr[2] : rr[3];
+    return (uint64_t)rv >= e.drop_thresh;
+}
+
+// ---- operand staging.  A tile is 64 rows x 32 k.  It is kept in LDS in the operand's own memory orientation, so both the
+// global reads (float4) and the LDS writes are contiguous:  KC (k contiguous in memory): [row][k];  otherwise: [k][row].
+// Each thread moves 2 float4 per tile; the next tile's float4s are fetched before the MFMAs of the current one.
+template <bool KC>
+__device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k0, int K, bool vec_ok, float4 (&v)[2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = tid + 256 * j;                 // float4 index within the tile (512 per tile)
+        long row; int k;
+        if (KC) { row = r0 + (q >> 3); k = k0 + 4 * (q & 7); }         // 8 float4 per row of 32 k
+        else { k = k0 + (q >> 4); row = r0 + 4 * (q & 15); }           // 16 float4 per k-line of 64 rows
+        const long lim_c = KC ? K : op.rows, c = KC ? k : row;         // the contiguous coordinate and its bound
+        const bool other_ok = KC ? row < op.rows : k < K;
+        const float *src = op.p + row * op.s_row + (long)k * op.s_k;
+        if (other_ok && vec_ok && c + 3 < lim_c) {
+            v[j] = *reinterpret_cast<const float4 *>(src);
+        } else {
+            const long st = KC ? op.s_k : op.s_row;
+            v[j].x = (other_ok && c < lim_c) ? src[0] : 0.f;
+            v[j].y = (other_ok && c + 1 < lim_c) ? src[st] : 0.f;
+            v[j].z = (other_ok && c + 2 < lim_c) ? src[2 * st] : 0.f;
+            v[j].w = (other_ok && c + 3 < lim_c) ? src[3 * st] : 0.f;
+        }
+    }
+}
+constexpr int LDF_KC = 36, LDF_T = 68;   // fp32 strides: [row][k] and [k][row]
+constexpr int LDH_KC = 40, LDH_T = 72;   // bf16 strides
+template <bool BF16, bool KC>
+__device__ __forceinline__ void stage_tile(void *lds, const float4 (&v)[2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = tid + 256 * j;
+        const int off = KC ? (q >> 3) * (BF16 ? LDH_KC : LDF_KC) + 4 * (q & 7) : (q >> 4) * (BF16 ? LDH_T : LDF_T) + 4 * (q & 15);
+        if (BF16) {
+            typedef Act<ww_bf16> A16;
+            *reinterpret_cast<uint2 *>(reinterpret_cast<ww_bf16 *>(lds) + off) =
+                make_uint2(A16::pack2(v[j].x, v[j].y), A16::pack2(v[j].z, v[j].w));
+        } else {
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(lds) + off) = v[j];
+        }
+    }
+}
+typedef short short4v __attribute__((ext_vector_type(4)));
+// bf16 MFMA operand (rows row0 + lane&31, k = 16t + 8*(lane>>5) .. +7) from a [k][row] tile: transposing LDS reads
+__device__ __forceinline__ bf16x8 tr_frag(const ww_bf16 *tile, int k0, int row0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+    const ww_bf16 *base = tile + (k0 + 8 * (g >> 1) + q) * LDH_T + row0 + 16 * (g & 1) + 4 * pp;
+    typedef short4v __attribute__((address_space(3))) * lds_p;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * LDH_T));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// grid: x = column tiles, y = row tiles, z = K splits (partial products go to C + z*split_stride)
+template <bool BF16, bool KCA, bool KCB, bool EPI>
+__global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int K, int k_per_split, float *__restrict__ C,
+                                              long ldc, long split_stride, int vecA, int vecB, Epilogue e) {
+    __shared__ __align__(16) unsigned char lds[2 * 64 * 40 * 4];      // two tiles, the larger of all layouts (fp32 [k][row]: 32*68*4)
+    void *As = lds, *Bs = lds + 64 * 40 * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5, rh = wv >> 1, nh = wv & 1;
+    const long m0 = (long)blockIdx.y * GT, n0 = (long)blockIdx.x * GT;
+    const int kb = blockIdx.z * k_per_split, ke = min(K, kb + k_per_split);
+    floatx16 acc = {0.f};
+    float4 va[2], vb[2];
+    if (kb < ke) {
+        fetch_tile<KCA>(A, m0, kb, ke, vecA, va);
+        fetch_tile<KCB>(B, n0, kb, ke, vecB, vb);
+    }
+    for (int k0 = kb; k0 < ke; k0 += GK) {
+        __syncthreads();
+        stage_tile<BF16, KCA>(As, va);
+        stage_tile<BF16, KCB>(Bs, vb);
+        __syncthreads();
+        if (k0 + GK < ke) {                        // next tile in flight under the MFMAs
+            fetch_tile<KCA>(A, m0, k0 + GK, ke, vecA, va);
+            fetch_tile<KCB>(B, n0, k0 + GK, ke, vecB, vb);
+        }
+        if (BF16) {
+            const ww_bf16 *a = reinterpret_cast<const ww_bf16 *>(As), *b = reinterpret_cast<const ww_bf16 *>(Bs);
+#pragma unroll
+            for (int t = 0; t < GK / 16; ++t) {
+                const bf16x8 fa = KCA ? *reinterpret_cast<const bf16x8 *>(a + (32 * rh + r) * LDH_KC + 16 * t + 8 * h)
+                                      : tr_frag(a, 16 * t, 32 * rh, lane);
+                const bf16x8 fb = KCB ? *reinterpret_cast<const bf16x8 *>(b + (32 * nh + r) * LDH_KC + 16 * t + 8 * h)
+                                      : tr_frag(b, 16 * t, 32 * nh, lane);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+            }
+        } else {
+            const float *a = reinterpret_cast<const float *>(As), *b = reinterpret_cast<const float *>(Bs);
+#pragma unroll
+            for (int t = 0; t < GK / 2; ++t) {
+                const float fa = KCA ? a[(32 * rh + r) * LDF_KC + 2 * t + h] : a[(2 * t + h) * LDF_T + 32 * rh + r];
+                const float fb = KCB ? b[(32 * nh + r) * LDF_KC + 2 * t + h] : b[(2 * t + h) * LDF_T + 32 * nh + r];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+            }
+        }
+    }
+    const long col = n0 + 32 * nh + r;
+    if (col >= B.rows) return;
+    C += (long)blockIdx.z * split_stride;
+    const float bias = (EPI && e.bias) ? e.bias[col] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const long row = m0 + 32 * rh + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (row >= A.rows) continue;
+        float v = acc[reg];
+        if (EPI) {
+            v += bias;
+            if (e.pre) e.pre[row * ldc + col] = v;
+            if (e.act == WW_LIN_HARDSWISH) v = hardswish(v);
+            if (e.use_dropout) v = drop_keep(e, row, (int)col) ? v * e.drop_scale : 0.f;
+        }
+        C[row * ldc + col] = v;
+    }
+}
+
+// C[i] = sum_z P[z][i] in fixed order (split-K partial products)
+__global__ __launch_bounds__(256) void k_splitk_sum(const float *__restrict__ P, long n, int splits, float *__restrict__ C) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            float4 s = *reinterpret_cast<const float4 *>(P + i);
+            for (int z = 1; z < splits; ++z) {
+                const float4 t = *reinterpret_cast<const float4 *>(P + (long)z * n + i);
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            *reinterpret_cast<float4 *>(C + i) = s;
+        } else {
+            for (long j = i; j < n; ++j) {
+                float s = P[j];
+                for (int z = 1; z < splits; ++z) s += P[(long)z * n + j];
+                C[j] = s;
+            }
+        }
+    }
+}
+
+// dpre = dy * dropout * act'(pre)
+__global__ __launch_bounds__(256) void k_linear_dpre(const float *__restrict__ dy, const float *__restrict__ pre, long M, int N,
+                                                     Epilogue e, float *__restrict__ dpre) {
+    const long n = M * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long row = i / N;
+        const int col = (int)(i - row * N);
+        float g = dy[i];
+        if (e.use_dropout) g = drop_keep(e, row, col) ? g * e.drop_scale : 0.f;
+        if (e.act == WW_LIN_HARDSWISH) g *= hardswish_grad(pre[i]);
+        dpre[i] = g;
+    }
+}
+
+// db[j] = sum_i dpre[i][j], any N; fixed summation order (16 row parts, then parts in order), fp64
+__global__ __launch_bounds__(1024) void k_colsum_any(const float *__restrict__ a, int rows, int cols, float *__restrict__ out) {
+    __shared__ double sh[16][64];
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
+    double acc = 0.0;
+    if (col < cols) {
+#pragma unroll 8
+        for (int r = part; r < rows; r += 16) acc += (double)a[(size_t)r * cols + col];
+    }
+    sh[part][c] = acc;
+    __syncthreads();
+    if (part == 0 && col < cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += sh[p][c];
+        out[col] = (float)t;
+    }
+}
+
+int make_epilogue(const ww_linear_epi *epi, const float *bias, float *pre, Epilogue *out) {
+    Epilogue e = {};
+    e.bias = bias;
+    e.pre = pre;
+    if (epi) {
+        WW_REQUIRE(epi->act == WW_LIN_NONE || epi->act == WW_LIN_HARDSWISH, WW_E_INVALID, "ww_linear_mfma: unknown activation %d", epi->act);
+        WW_REQUIRE(epi->dropout_p >= 0.f && epi->dropout_p < 1.f, WW_E_INVALID, "ww_linear_mfma: dropout_p=%f not in [0,1)",
+                   (double)epi->dropout_p);
+        e.act = epi->act;
+        e.use_dropout = epi->dropout_p > 0.f;
+        e.drop_scale = (float)(1.0 / (1.0 - (double)epi->dropout_p));
+        e.drop_thresh = ww_prob_threshold((double)epi->dropout_p);
+        e.seed_lo = (uint32_t)epi->seed; e.seed_hi = (uint32_t)(epi->seed >> 32);
+        e.step_lo = (uint32_t)epi->step; e.step_hi = (uint32_t)(epi->step >> 32);
+        e.sample_offset = epi->sample_offset;
+    }
+    *out = e;
+    return WW_OK;
+}
+
+// splits > 1: partial products into `part` (splits x rows x cols), then summed in fixed order into C
+template <bool KCA, bool KCB, bool EPI>
+int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, float *C, long ldc, const Epilogue &e,
+                hipStream_t st, int splits = 1, float *part = nullptr) {
+    auto aligned = [](const GemmOperand &o, bool kc) {
+        const long ld = kc ? o.s_row : o.s_k;
+        return (int)(((uintptr_t)o.p & 15) == 0 && (ld & 3) == 0);
+    };
+    const int vecA = aligned(A, KCA), vecB = aligned(B, KCB);
+    int kps = K;
+    if (splits > 1) kps = ((K + splits - 1) / splits + GK - 1) / GK * GK;
+    const int nz = (K + kps - 1) / kps;
+    dim3 grid((B.rows + GT - 1) / GT, (A.rows + GT - 1) / GT, nz);
+    float *dst = nz > 1 ? part : C;
+    const long sstride = (long)A.rows * ldc;
+    if (mode == WW_ACT_BF16)
+        hipLaunchKernelGGL((k_gemm<true, KCA, KCB, EPI>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
+    else
+        hipLaunchKernelGGL((k_gemm<false, KCA, KCB, EPI>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
+    WW_LAUNCH_CHECK();
+    if (nz > 1) {
+        const long n = sstride;
+        const int g = (int)std::min<long>((n / 4 + 255) / 256 + 1, 2048);
+        hipLaunchKernelGGL(k_splitk_sum, dim3(g), dim3(256), 0, st, part, n, nz, C);
+        WW_LAUNCH_CHECK();
+    }
+    return WW_OK;
+}
+
+int check_dims(const char *who, int mode, int M, int K, int N) {
+    WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16, WW_E_INVALID, "%s: unknown mode %d", who, mode);
+    WW_REQUIRE(M >= 1 && K >= 1 && N >= 1, WW_E_INVALID, "%s: bad shape M=%d K=%d N=%d", who, M, K, N);
+    return WW_OK;
+}
+
+}  // namespace
+
+extern "C" int ww_linear_mfma_fwd(ww_ctx *ctx, int mode, const float *x, const float *w, const float *bias, int M, int K,
+                                  int N, const ww_linear_epi *epi, float *pre, float *y, ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && w && y, WW_E_INVALID, "ww_linear_mfma_fwd: null argument");
+    int rc = check_dims("ww_linear_mfma_fwd", mode, M, K, N);
+    if (rc) return rc;
+    Epilogue e;
+    if ((rc = make_epilogue(epi, bias, pre, &e))) return rc;
+    const GemmOperand A{x, K, 1, M}, B{w, K, 1, N};
+    ww_prof_scope ps_(ctx, WW_K_LINEAR, (hipStream_t)stream);
+    return launch_gemm<true, true, true>(mode, A, B, K, y, N, e, (hipStream_t)stream);
+}
+
+constexpr int DW_SPLITS = 4;     // K splits of the weight-gradient product (its contraction runs over the batch)
+extern "C" size_t ww_linear_mfma_bwd_scratch_bytes(int M, int K, int N) {
+    if (M < 1 || K < 1 || N < 1) return 0;
+    return ((size_t)M * N + (size_t)DW_SPLITS * N * K) * sizeof(float);      // dpre + split-K partial products of dW
+}
+
+extern "C" int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const float *w, const float *pre, const float *dy,
+                                  int M, int K, int N, const ww_linear_epi *epi, float *dx, float *dw, float *db,
+                                  void *scratch, size_t scratch_bytes, ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && w && dy && dw && scratch, WW_E_INVALID, "ww_linear_mfma_bwd: null argument");
+    int rc = check_dims("ww_linear_mfma_bwd", mode, M, K, N);
+    if (rc) return rc;
+    WW_REQUIRE(scratch_bytes >= ww_linear_mfma_bwd_scratch_bytes(M, K, N), WW_E_WORKSPACE, "ww_linear_mfma_bwd: scratch too small");
+    Epilogue e;
+    if ((rc = make_epilogue(epi, nullptr, nullptr, &e))) return rc;
+    WW_REQUIRE(e.act == WW_LIN_NONE || pre, WW_E_INVALID, "ww_linear_mfma_bwd: the activation's backward needs `pre`");
+    hipStream_t st = (hipStream_t)stream;
+    ww_prof_scope ps_(ctx, WW_K_LINEAR, st);
+    const float *dpre = dy;
+    if (e.act != WW_LIN_NONE || e.use_dropout) {
+        const long n = (long)M * N;
+        const int grid = (int)std::min<long>((n + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(k_linear_dpre, dim3(grid), dim3(256), 0, st, dy, pre, (long)M, N, e, (float *)scratch);
+        WW_LAUNCH_CHECK();
+        dpre = (const float *)scratch;
+    }
+    const Epilogue none = {};
+    if (dx) {   // dx[m][k] = sum_n dpre[m][n] w[n][k] : A = dpre (n contiguous), B(k, n) = w[n][k] (row index contiguous)
+        const GemmOperand A{dpre, N, 1, M}, B{w, 1, K, K};
+        if ((rc = launch_gemm<true, false, false>(mode, A, B, N, dx, K, none, st))) return rc;
+    }
+    {           // dw[n][k] = sum_m dpre[m][n] x[m][k] : A(n, m) = dpre[m][n], B(k, m) = x[m][k]
+        const GemmOperand A{dpre, 1, N, N}, B{x, 1, K, K};
+        float *part = (float *)scratch + (size_t)M * N;
+        if ((rc = launch_gemm<false, false, false>(mode, A, B, M, dw, K, none, st, M >= 1024 ? DW_SPLITS : 1, part))) return rc;
+    }
+    if (db) {
+        hipLaunchKernelGGL(k_colsum_any, dim3((N + 63) / 64), dim3(1024), 0, st, dpre, M, N, db);
+        WW_LAUNCH_CHECK();
+    }
+    return WW_OK;
+}
