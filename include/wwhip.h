@@ -250,6 +250,22 @@ int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const float *w, co
                        const float *dy, int M, int K, int N, const ww_linear_epi *epi, float *dx /* nullable */, float *dw,
                        float *db /* nullable */, void *scratch, size_t scratch_bytes, ww_stream_t stream);
 
+/* ------------------------------------------------------------------ GRU layer, one direction
+ * torch.nn.GRU's cell and parameter layout (gate order r|z|n; w_ih (3H,I), w_hh (3H,H), b_ih, b_hh (3H)) -- what the
+ * reference's GRUWakeword wraps (src/models/architectures.py:228-235).  batch_first: x (B,T,I) with row stride ldx
+ * between consecutive (b,t) rows, y (B,T,H) with row stride ldy (a bidirectional layer's two directions write the two
+ * halves of one (B,T,2H) buffer: ldy = 2H, y offset by H for the reverse direction).  reverse != 0 runs t = T-1..0.
+ * h0 nullable (zeros).  H = 128 only.  ws (ww_gru_workspace_bytes, 256-byte aligned) keeps the projections and the
+ * gates between ww_gru_fwd and the ww_gru_bwd of the same (layer, direction).  ww_gru_bwd: dy (nullable) is the
+ * gradient of y, dh_n (nullable) of the final hidden state; dx is written, or added to when accumulate_dx != 0.     */
+size_t ww_gru_workspace_bytes(int B, int T, int I, int H);
+int ww_gru_fwd(ww_ctx *ctx, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *b_ih,
+               const float *b_hh, const float *h0, int B, int T, int I, int H, int reverse, float *y, long ldy, float *h_n,
+               void *ws, size_t ws_bytes, ww_stream_t stream);
+int ww_gru_bwd(ww_ctx *ctx, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *dy, long ldy,
+               const float *dh_n, int B, int T, int I, int H, int reverse, void *ws, size_t ws_bytes, float *dx, long lddx,
+               int accumulate_dx, float *dw_ih, float *dw_hh, float *db_ih, float *db_hh, float *dh0, ww_stream_t stream);
+
 /* Fused clip + optimizer step on flat fp32 buckets.  Replaces, for one step, the reference's
  * clip_gradients(...) ; optimizer.step()  (src/training/trainer.py:185-193) with torch.optim's own update rules
  * (create_optimizer, src/training/optimizer_factory.py:165-199: Adam, AdamW, SGD with nesterov=True).

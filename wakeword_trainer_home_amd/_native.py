@@ -86,6 +86,10 @@ _SIGS = {
     "ww_linear_mfma_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
     "ww_linear_mfma_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(LinearEpi), _vp, _vp, _vp, _vp, _sz,
                                      _vp]),
+    "ww_gru_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "ww_gru_fwd": (C.c_int, [_vp, _vp, C.c_long, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_long, _vp, _vp, _sz, _vp]),
+    "ww_gru_bwd": (C.c_int, [_vp, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, C.c_long, _i,
+                             _vp, _vp, _vp, _vp, _vp, _vp]),
     "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp]),
     "ww_layer_scratch_bytes": (_sz, []),
     "ww_conv_stem_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
@@ -172,6 +176,21 @@ def _dev(*tensors):
         d = t.device if d is None else d
         if t.device != d:
             raise ValueError("tensors on different devices")
+    return d
+
+
+def _dev_rows(*tensors):
+    """Device check for (B,T,F) row-strided views (validated separately by _bt_rows); no contiguity requirement."""
+    d = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NativeError("the HIP hot path needs tensors on an MI355X ('cuda') device; got a CPU tensor "
+                              "(there is no CPU fallback)")
+        d = t.device if d is None else d
+        if t.device != d:
+            raise ValueError("tensors on different devices passed to the native path")
     return d
 
 
@@ -349,6 +368,57 @@ def linear_mfma_bwd(x, w, pre, dy, act=LIN_NONE, dropout_p=0.0, seed=0, step=0, 
                                          _p(dy.contiguous()), M, K, N, C.byref(epi), _p(dx), _p(dw), _p(db), _p(scratch), nbytes,
                                          _stream(dev)), "ww_linear_mfma_bwd")
     return dx, dw, db
+
+
+def _bt_rows(t, name):
+    """(B,T,F) tensor (possibly a column slice of a wider buffer) -> row stride, checking the (b,t) rows are equidistant."""
+    if t.dim() != 3 or t.dtype != torch.float32 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+        raise ValueError(f"{name} must be float32 (B,T,F) with contiguous features and equidistant (b,t) rows")
+    return t.stride(1)
+
+
+def gru_workspace(B, T, I, H, dev):
+    n = load().ww_gru_workspace_bytes(B, T, I, H)
+    if n == 0:
+        raise NativeError(f"GRU shape B={B} T={T} I={I} H={H} is not implemented (hidden size 128 only)")
+    return torch.empty(n // 4, dtype=torch.float32, device=dev)
+
+
+def gru_fwd(x, w_ih, w_hh, b_ih, b_hh, y, ws, h0=None, reverse=False):
+    """One GRU direction: x (B,T,I) -> writes y (B,T,H) (may be a column slice of a (B,T,2H) buffer); returns h_n (B,H)."""
+    dev = _dev(w_ih, w_hh, b_ih, b_hh, ws, h0)
+    _dev_rows(x, y)
+    B, T, I = x.shape
+    H = w_hh.shape[1]
+    ldx, ldy = _bt_rows(x, "x"), _bt_rows(y, "y")
+    if tuple(w_ih.shape) != (3 * H, I) or tuple(w_hh.shape) != (3 * H, H) or tuple(y.shape) != (B, T, H):
+        raise ValueError("GRU parameter / output shapes do not match (w_ih (3H,I), w_hh (3H,H), y (B,T,H))")
+    h_n = torch.empty((B, H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_gru_fwd(ctx(dev), _p(x), ldx, _p(w_ih.contiguous()), _p(w_hh.contiguous()), _p(b_ih), _p(b_hh), _p(h0),
+                                 B, T, I, H, int(reverse), _p(y), ldy, _p(h_n), _p(ws), ws.numel() * 4, _stream(dev)),
+               "ww_gru_fwd")
+    return h_n
+
+
+def gru_bwd(x, w_ih, w_hh, dy, dh_n, ws, reverse=False, dx=None, accumulate_dx=False, want_dh0=False):
+    """Backward of the gru_fwd that filled ``ws``: -> (dw_ih, dw_hh, db_ih, db_hh, dh0 | None); dx written/accumulated in place."""
+    dev = _dev(w_ih, w_hh, dh_n, ws)
+    _dev_rows(x, dy, dx)
+    B, T, I = x.shape
+    H = w_hh.shape[1]
+    ldx = _bt_rows(x, "x")
+    ldy = _bt_rows(dy, "dy") if dy is not None else H
+    lddx = _bt_rows(dx, "dx") if dx is not None else I
+    dw_ih, dw_hh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+    db_ih = torch.empty(3 * H, dtype=torch.float32, device=dev)
+    db_hh = torch.empty(3 * H, dtype=torch.float32, device=dev)
+    dh0 = torch.empty((B, H), dtype=torch.float32, device=dev) if want_dh0 else None
+    with torch.cuda.device(dev):
+        _check(load().ww_gru_bwd(ctx(dev), _p(x), ldx, _p(w_ih.contiguous()), _p(w_hh.contiguous()), _p(dy), ldy, _p(dh_n),
+                                 B, T, I, H, int(reverse), _p(ws), ws.numel() * 4, _p(dx), lddx, int(accumulate_dx),
+                                 _p(dw_ih), _p(dw_hh), _p(db_ih), _p(db_hh), _p(dh0), _stream(dev)), "ww_gru_bwd")
+    return dw_ih, dw_hh, db_ih, db_hh, dh0
 
 
 def clip_optim_step_(cfg: OptimCfg, flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, parity, norm_out=None,

@@ -1,0 +1,227 @@
+// GRU layer (one direction) forward / backward -- the recurrent half of SURVEY.md §8f rank 3 (CRNN); cell maths and
+// parameter layout are torch.nn.GRU's, which is what the reference's GRUWakeword wraps
+// (src/models/architectures.py:228-235: nn.GRU(input, 128, num_layers=2, batch_first=True, bidirectional=True)):
+//   r = s(W_ir x + b_ir + W_hr h + b_hr)   z = s(W_iz x + b_iz + W_hz h + b_hz)
+//   n = tanh(W_in x + b_in + r * (W_hn h + b_hn))          h' = (1 - z) * n + z * h          gate order r|z|n
+// MI355X shape of the computation:
+//   * the input projection of ALL time steps is one GEMM  Gi = X W_ih^T + b_ih  (ww_gemm, matrix cores);
+//   * the recurrence is ONE persistent kernel per direction: a block owns 16 batch rows for all T steps, keeps h in LDS,
+//     and every wavefront keeps ITS slice of W_hh (16 hidden units x 3 gates x 128 = 96 VGPRs) in registers for the whole
+//     sequence -- the per-step product h W_hh^T is 96 v_mfma_f32_16x16x4_f32 per wave with no weight traffic at all;
+//   * backward mirrors it (dh carried in LDS, W_hh slice by output unit in registers, dGh W_hh per step), and the weight
+//     gradients are three large GEMMs over all (batch, time) rows afterwards, split over K with fixed-order sums.
+// fp32 throughout (exact-fp32 MFMA): this is the parity mode; hidden size 128 only.
+#include "ww_internal.h"
+#include <algorithm>
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int GH = 128;          // hidden size
+constexpr int GBT = 16;          // batch rows per block (one 16-row MFMA tile)
+constexpr int HS_LD = GH + 4;    // LDS row strides: lane (row i, k) -> bank 4i + k, conflict-free fragment reads
+constexpr int DG_LD = 3 * GH + 4;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+struct GruSaved { float *r, *z, *n, *hn, *hp; };    // (B*T, 128) each: gates, W_hn h + b_hn, h_{t-1}
+
+// grid ceil(B/16), block 512 = 8 waves; wave w owns hidden units [16w, 16w+16)
+__global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, const float *__restrict__ w_hh,
+                                                 const float *__restrict__ b_hh, const float *__restrict__ h0, int B, int T,
+                                                 int reverse, float *__restrict__ y, long ldy, long bsy,
+                                                 float *__restrict__ hn_out, GruSaved sv) {
+    __shared__ float hs[2][GBT][HS_LD];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
+    const int b0 = blockIdx.x * GBT, u = 16 * w + j;
+    float wreg[3][32];      // B operand of k-step kk, gate g: W_hh[g*128 + u][4kk + kq]
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) wreg[g][kk] = w_hh[(size_t)(g * GH + u) * GH + 4 * kk + kq];
+    const float bhr = b_hh[u], bhz = b_hh[GH + u], bhn = b_hh[2 * GH + u];
+    for (int e = tid; e < GBT * GH; e += 512) {
+        const int row = e >> 7, c = e & 127;
+        hs[0][row][c] = (h0 && b0 + row < B) ? h0[(size_t)(b0 + row) * GH + c] : 0.f;
+    }
+    __syncthreads();
+    for (int it = 0; it < T; ++it) {
+        const int t = reverse ? T - 1 - it : it, cur = it & 1;
+        floatx4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const float a = hs[cur][j][4 * kk + kq];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[g][kk], acc[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {     // D[row = 4kq + reg][unit u]
+            const int row = 4 * kq + reg, b = b0 + row;
+            if (b < B) {
+                const size_t m = (size_t)b * T + t;
+                const float *g3 = gi + m * (3 * GH);
+                const float hnv = acc[2][reg] + bhn;
+                const float r = sigmoidf_(g3[u] + acc[0][reg] + bhr);
+                const float z = sigmoidf_(g3[GH + u] + acc[1][reg] + bhz);
+                const float n = tanhf(g3[2 * GH + u] + r * hnv);
+                const float hp = hs[cur][row][u];
+                const float h = (1.0f - z) * n + z * hp;
+                hs[cur ^ 1][row][u] = h;
+                sv.r[m * GH + u] = r; sv.z[m * GH + u] = z; sv.n[m * GH + u] = n; sv.hn[m * GH + u] = hnv; sv.hp[m * GH + u] = hp;
+                y[(size_t)b * bsy + (size_t)t * ldy + u] = h;
+            }
+        }
+        __syncthreads();
+    }
+    if (hn_out)
+        for (int e = tid; e < GBT * GH; e += 512) {
+            const int row = e >> 7, c = e & 127;
+            if (b0 + row < B) hn_out[(size_t)(b0 + row) * GH + c] = hs[T & 1][row][c];
+        }
+}
+
+// same decomposition; wave w owns OUTPUT units [16w,16w+16) of dh_{t-1} = dh*z + dGh W_hh
+__global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh, const float *__restrict__ dy, long ldy,
+                                                 long bsy, const float *__restrict__ dhn, int B, int T, int reverse,
+                                                 GruSaved sv, float *__restrict__ dgi, float *__restrict__ dgh,
+                                                 float *__restrict__ dh0) {
+    __shared__ float dhs[GBT][HS_LD];
+    __shared__ float dg[GBT][DG_LD];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
+    const int b0 = blockIdx.x * GBT, u = 16 * w + j;
+    float wreg[96];         // B operand of k-step cc: W_hh[4cc + kq][u]  (contraction over the 384 gate rows)
+#pragma unroll
+    for (int cc = 0; cc < 96; ++cc) wreg[cc] = w_hh[(size_t)(4 * cc + kq) * GH + u];
+    for (int e = tid; e < GBT * GH; e += 512) {
+        const int row = e >> 7, c = e & 127;
+        dhs[row][c] = (dhn && b0 + row < B) ? dhn[(size_t)(b0 + row) * GH + c] : 0.f;
+    }
+    __syncthreads();
+    for (int it = 0; it < T; ++it) {
+        const int t = reverse ? it : T - 1 - it;        // the forward pass's time order, backwards
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                   // elementwise part: 16 x 128 cells over 512 threads
+            const int e = tid + 512 * q, row = e >> 7, c = e & 127, b = b0 + row;
+            float dar = 0.f, daz = 0.f, dan = 0.f, dhn_ = 0.f, keep = 0.f;
+            if (b < B) {
+                const size_t m = (size_t)b * T + t, i = m * GH + c;
+                float dh = dhs[row][c];
+                if (dy) dh += dy[(size_t)b * bsy + (size_t)t * ldy + c];
+                const float r = sv.r[i], z = sv.z[i], n = sv.n[i], hnv = sv.hn[i], hp = sv.hp[i];
+                const float dn = dh * (1.0f - z), dz = dh * (hp - n);
+                dan = dn * (1.0f - n * n);
+                dar = dan * hnv * r * (1.0f - r);
+                daz = dz * z * (1.0f - z);
+                dhn_ = dan * r;
+                keep = dh * z;
+                float *o = dgi + m * (3 * GH);
+                o[c] = dar; o[GH + c] = daz; o[2 * GH + c] = dan;
+                float *p = dgh + m * (3 * GH);
+                p[c] = dar; p[GH + c] = daz; p[2 * GH + c] = dhn_;
+            }
+            dg[row][c] = dar; dg[row][GH + c] = daz; dg[row][2 * GH + c] = dhn_;
+            dhs[row][c] = keep;                          // read and written by this thread only
+        }
+        __syncthreads();
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < 96; ++cc)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dg[j][4 * cc + kq], wreg[cc], acc, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) dhs[4 * kq + reg][u] += acc[reg];
+        __syncthreads();
+    }
+    if (dh0)
+        for (int e = tid; e < GBT * GH; e += 512) {
+            const int row = e >> 7, c = e & 127;
+            if (b0 + row < B) dh0[(size_t)(b0 + row) * GH + c] = dhs[row][c];
+        }
+}
+
+struct WsLayout { size_t gi, dgh, r, z, n, hn, hp, part, total; };
+constexpr int GRU_SPLITS = 32, GRU_CHUNKS = 64;
+WsLayout ws_layout(long B, long T, int I) {
+    WsLayout L;
+    size_t o = 0;
+    auto take = [&](size_t nfloat) { size_t r = o; o += (nfloat * sizeof(float) + 255) & ~(size_t)255; return r; };
+    const size_t M = (size_t)B * T;
+    L.gi = take(M * 3 * GH);        // projections, overwritten by dGi in the backward pass
+    L.dgh = take(M * 3 * GH);
+    L.r = take(M * GH); L.z = take(M * GH); L.n = take(M * GH); L.hn = take(M * GH); L.hp = take(M * GH);
+    L.part = take((size_t)GRU_SPLITS * 3 * GH * std::max(I, GH) + (size_t)GRU_CHUNKS * 3 * GH);
+    L.total = o;
+    return L;
+}
+int check_gru(const char *who, ww_ctx *ctx, int B, int T, int I, int H, const void *ws, size_t ws_bytes) {
+    WW_REQUIRE(ctx && ws, WW_E_INVALID, "%s: null argument", who);
+    WW_REQUIRE(B >= 1 && T >= 1 && I >= 1, WW_E_INVALID, "%s: bad shape B=%d T=%d I=%d", who, B, T, I);
+    WW_REQUIRE(H == GH, WW_E_UNSUPPORTED, "%s: hidden size %d not implemented (128 only)", who, H);
+    WW_REQUIRE(ws_bytes >= ws_layout(B, T, I).total, WW_E_WORKSPACE, "%s: workspace too small", who);
+    WW_REQUIRE(((uintptr_t)ws & 255) == 0, WW_E_INVALID, "%s: workspace must be 256-byte aligned", who);
+    return WW_OK;
+}
+GruSaved saved(char *w, const WsLayout &L) {
+    return GruSaved{(float *)(w + L.r), (float *)(w + L.z), (float *)(w + L.n), (float *)(w + L.hn), (float *)(w + L.hp)};
+}
+
+}  // namespace
+
+extern "C" size_t ww_gru_workspace_bytes(int B, int T, int I, int H) {
+    if (B < 1 || T < 1 || I < 1 || H != GH) return 0;
+    return ws_layout(B, T, I).total;
+}
+
+extern "C" int ww_gru_fwd(ww_ctx *ctx, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *b_ih,
+                          const float *b_hh, const float *h0, int B, int T, int I, int H, int reverse, float *y, long ldy,
+                          float *h_n, void *ws, size_t ws_bytes, ww_stream_t stream) {
+    int rc = check_gru("ww_gru_fwd", ctx, B, T, I, H, ws, ws_bytes);
+    if (rc) return rc;
+    WW_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && y, WW_E_INVALID, "ww_gru_fwd: null argument");
+    WW_REQUIRE(ldx >= I && ldy >= H, WW_E_INVALID, "ww_gru_fwd: row strides smaller than the feature sizes");
+    const WsLayout L = ws_layout(B, T, I);
+    char *w = (char *)ws;
+    hipStream_t st = (hipStream_t)stream;
+    ww_prof_scope ps_(ctx, WW_K_GRU, st);
+    // Gi[(b,t)][3H] = x[(b,t)][:] W_ih^T + b_ih for all time steps at once
+    rc = ww_gemm(WW_ACT_F32, x, ldx, 1, B * T, w_ih, I, 1, 3 * GH, I, (float *)(w + L.gi), 3 * GH, b_ih, 0, 1, nullptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gru_fwd, dim3((B + GBT - 1) / GBT), dim3(512), 0, st, (const float *)(w + L.gi), w_hh, b_hh, h0, B, T,
+                       reverse, y, ldy, (long)T * ldy, h_n, saved(w, L));
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+
+extern "C" int ww_gru_bwd(ww_ctx *ctx, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *dy,
+                          long ldy, const float *dh_n, int B, int T, int I, int H, int reverse, void *ws, size_t ws_bytes,
+                          float *dx, long lddx, int accumulate_dx, float *dw_ih, float *dw_hh, float *db_ih, float *db_hh,
+                          float *dh0, ww_stream_t stream) {
+    int rc = check_gru("ww_gru_bwd", ctx, B, T, I, H, ws, ws_bytes);
+    if (rc) return rc;
+    WW_REQUIRE(x && w_ih && w_hh && dw_ih && dw_hh && db_ih && db_hh, WW_E_INVALID, "ww_gru_bwd: null argument");
+    WW_REQUIRE(dy || dh_n, WW_E_INVALID, "ww_gru_bwd: need dy and/or dh_n");
+    const WsLayout L = ws_layout(B, T, I);
+    char *w = (char *)ws;
+    hipStream_t st = (hipStream_t)stream;
+    ww_prof_scope ps_(ctx, WW_K_GRU, st);
+    float *dgi = (float *)(w + L.gi), *dgh = (float *)(w + L.dgh), *part = (float *)(w + L.part);
+    const GruSaved sv = saved(w, L);
+    hipLaunchKernelGGL(k_gru_bwd, dim3((B + GBT - 1) / GBT), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse,
+                       sv, dgi, dgh, dh0);
+    WW_LAUNCH_CHECK();
+    const int M = B * T;
+    const int splits = M >= 4096 ? GRU_SPLITS : 1;
+    // dW_hh[c][k] = sum_m dGh[m][c] h_prev[m][k]   ;   dW_ih[c][i] = sum_m dGi[m][c] x[m][i]
+    if ((rc = ww_gemm(WW_ACT_F32, dgh, 1, 3 * GH, 3 * GH, sv.hp, 1, GH, GH, M, dw_hh, GH, nullptr, 0, splits, part, st))) return rc;
+    if ((rc = ww_gemm(WW_ACT_F32, dgi, 1, 3 * GH, 3 * GH, x, 1, ldx, I, M, dw_ih, I, nullptr, 0, splits, part, st))) return rc;
+    float *cpart = part + (size_t)GRU_SPLITS * 3 * GH * std::max(I, GH);
+    const int chunks = std::max(1, std::min(GRU_CHUNKS, M / 64));
+    if ((rc = ww_colsum_rows(dgi, M, 3 * GH, db_ih, cpart, chunks, st))) return rc;
+    if ((rc = ww_colsum_rows(dgh, M, 3 * GH, db_hh, cpart, chunks, st))) return rc;
+    // dx[m][i] (+)= sum_c dGi[m][c] W_ih[c][i]
+    if (dx) {
+        WW_REQUIRE(lddx >= I, WW_E_INVALID, "ww_gru_bwd: dx row stride smaller than the input size");
+        if ((rc = ww_gemm(WW_ACT_F32, dgi, 3 * GH, 1, M, w_ih, 1, I, I, 3 * GH, dx, lddx, nullptr, accumulate_dx, 1, nullptr, st)))
+            return rc;
+    }
+    return WW_OK;
+}

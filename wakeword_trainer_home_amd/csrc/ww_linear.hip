@@ -35,6 +35,7 @@ struct Epilogue {
     uint64_t drop_thresh;
     uint32_t seed_lo, seed_hi, step_lo, step_hi;
     uint64_t sample_offset;
+    int accumulate;             // C += result (second direction of a bidirectional layer adds into dX)
 };
 
 __device__ __forceinline__ float hardswish(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
@@ -162,12 +163,14 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
             if (e.act == WW_LIN_HARDSWISH) v = hardswish(v);
             if (e.use_dropout) v = drop_keep(e, row, (int)col) ? v * e.drop_scale : 0.f;
         }
+        if (e.accumulate && gridDim.z == 1) v += C[row * ldc + col];
         C[row * ldc + col] = v;
     }
 }
 
 // C[i] = sum_z P[z][i] in fixed order (split-K partial products)
-__global__ __launch_bounds__(256) void k_splitk_sum(const float *__restrict__ P, long n, int splits, float *__restrict__ C) {
+__global__ __launch_bounds__(256) void k_splitk_sum(const float *__restrict__ P, long n, int splits, float *__restrict__ C,
+                                                    int accumulate) {
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
         if (i + 3 < n) {
             float4 s = *reinterpret_cast<const float4 *>(P + i);
@@ -175,12 +178,16 @@ __global__ __launch_bounds__(256) void k_splitk_sum(const float *__restrict__ P,
                 const float4 t = *reinterpret_cast<const float4 *>(P + (long)z * n + i);
                 s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
             }
+            if (accumulate) {
+                const float4 c = *reinterpret_cast<const float4 *>(C + i);
+                s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+            }
             *reinterpret_cast<float4 *>(C + i) = s;
         } else {
             for (long j = i; j < n; ++j) {
                 float s = P[j];
                 for (int z = 1; z < splits; ++z) s += P[(long)z * n + j];
-                C[j] = s;
+                C[j] = accumulate ? C[j] + s : s;
             }
         }
     }
@@ -216,6 +223,27 @@ __global__ __launch_bounds__(1024) void k_colsum_any(const float *__restrict__ a
 #pragma unroll
         for (int p = 0; p < 16; ++p) t += sh[p][c];
         out[col] = (float)t;
+    }
+}
+
+// partial column sums of a row chunk: grid (column groups of 64, chunks); part[chunk][cols]
+__global__ __launch_bounds__(1024) void k_colsum_chunk(const float *__restrict__ a, long rows, int cols, long rows_per_chunk,
+                                                       float *__restrict__ part) {
+    __shared__ double sh[16][64];
+    const int c = threadIdx.x & 63, p = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
+    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    double acc = 0.0;
+    if (col < cols) {
+#pragma unroll 8
+        for (long r = r0 + p; r < r1; r += 16) acc += (double)a[r * cols + col];
+    }
+    sh[p][c] = acc;
+    __syncthreads();
+    if (p == 0 && col < cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sh[q][c];
+        part[(long)blockIdx.y * cols + col] = (float)t;
     }
 }
 
@@ -262,7 +290,7 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
     if (nz > 1) {
         const long n = sstride;
         const int g = (int)std::min<long>((n / 4 + 255) / 256 + 1, 2048);
-        hipLaunchKernelGGL(k_splitk_sum, dim3(g), dim3(256), 0, st, part, n, nz, C);
+        hipLaunchKernelGGL(k_splitk_sum, dim3(g), dim3(256), 0, st, part, n, nz, C, e.accumulate);
         WW_LAUNCH_CHECK();
     }
     return WW_OK;
@@ -275,6 +303,29 @@ int check_dims(const char *who, int mode, int M, int K, int N) {
 }
 
 }  // namespace
+
+// internal entry points for the recurrent layers (ww_gru.hip)
+int ww_gemm(int mode, const float *A, long a_srow, long a_sk, int a_rows, const float *B, long b_srow, long b_sk, int b_rows,
+            int K, float *C, long ldc, const float *bias, int accumulate, int splits, float *part, hipStream_t st) {
+    Epilogue e = {};
+    e.bias = bias;
+    e.accumulate = accumulate;
+    const GemmOperand a{A, a_srow, a_sk, a_rows}, b{B, b_srow, b_sk, b_rows};
+    const bool kca = a_sk == 1, kcb = b_sk == 1;
+    if (kca && kcb) return launch_gemm<true, true, true>(mode, a, b, K, C, ldc, e, st, splits, part);
+    if (kca && !kcb) return launch_gemm<true, false, true>(mode, a, b, K, C, ldc, e, st, splits, part);
+    if (!kca && kcb) return launch_gemm<false, true, true>(mode, a, b, K, C, ldc, e, st, splits, part);
+    return launch_gemm<false, false, true>(mode, a, b, K, C, ldc, e, st, splits, part);
+}
+// out[j] = sum_i a[i][j] for tall matrices: chunked partial sums (part: chunks x cols floats), then a fixed-order sum
+int ww_colsum_rows(const float *a, long rows, int cols, float *out, float *part, int chunks, hipStream_t st) {
+    const long rpc = (rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(k_colsum_chunk, dim3((cols + 63) / 64, chunks), dim3(1024), 0, st, a, rows, cols, rpc, part);
+    WW_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_colsum_any, dim3((cols + 63) / 64), dim3(1024), 0, st, part, chunks, cols, out);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
 
 extern "C" int ww_linear_mfma_fwd(ww_ctx *ctx, int mode, const float *x, const float *w, const float *bias, int M, int K,
                                   int N, const ww_linear_epi *epi, float *pre, float *y, ww_stream_t stream) {
