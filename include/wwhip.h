@@ -259,6 +259,11 @@ int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const float *w, co
  * gates between ww_gru_fwd and the ww_gru_bwd of the same (layer, direction).  ww_gru_bwd: dy (nullable) is the
  * gradient of y, dh_n (nullable) of the final hidden state; dx is written, or added to when accumulate_dx != 0.     */
 size_t ww_gru_workspace_bytes(int B, int T, int I, int H);
+/* Dropout on a (B,T,C) tensor of row-strided rows (nn.GRU's inter-layer dropout, the Dropout in front of GRUWakeword.fc,
+ * architectures.py:232,239): out = keep ? x/(1-p) : 0 with keep from Philox ctr = (step, sample_offset + b,
+ * TAG_DROPOUT<<24 | stream_id<<20 | t<<8 | c>>2), lane c&3.  Applying it to the gradient is its backward.          */
+int ww_dropout_bt(ww_ctx *ctx, const float *x, long ldx, int B, int T, int C, float p, uint64_t seed, uint64_t step,
+                  uint64_t sample_offset, int stream_id, float *out, long ldo, ww_stream_t stream);
 int ww_gru_fwd(ww_ctx *ctx, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *b_ih,
                const float *b_hh, const float *h0, int B, int T, int I, int H, int reverse, float *y, long ldy, float *h_n,
                void *ws, size_t ws_bytes, ww_stream_t stream);

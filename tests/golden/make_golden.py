@@ -232,7 +232,43 @@ def g4_sched():
     print("G4 written")
 
 
+# ----------------------------------------------------------------------------- G7
+def g7_gru():
+    """The reference's own GRUWakeword (src/models/architectures.py:198-267).  Its module imports torchvision at the top;
+    torchvision is not installed here, so an empty stand-in module satisfies that import -- GRUWakeword itself only uses
+    torch.nn.  eval-mode logits (dropout off -> deterministic) and train-mode gradients with dropout=0."""
+    import types
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tv.models = types.ModuleType("torchvision.models")
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.models"] = tv.models
+    from src.models.architectures import create_model as ref_create_model       # noqa: E402  (reference)
+    torch.manual_seed(77)
+    model = ref_create_model("gru", num_classes=2, input_size=40, hidden_size=128, num_layers=2, bidirectional=True,
+                             dropout=0.0)
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(6, 31, 40, generator=g)
+    y = torch.tensor([0, 1, 1, 0, 1, 0])
+    model.eval()
+    with torch.no_grad():
+        logits_eval = model(x)
+    model.train()
+    out = model(x)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    sd = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+    grads = {"grad." + k: p.grad.numpy() for k, p in model.named_parameters()}
+    np.savez_compressed(HERE / "g7_gru.npz", x=x.numpy(), y=y.numpy(), logits_eval=logits_eval.numpy(),
+                        logits_train=out.detach().numpy(), loss=np.float64(loss.item()), **{"sd." + k: v for k, v in sd.items()},
+                        **grads)
+    print("g7_gru.npz:", list(sd.keys()), "loss", loss.item())
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":
+        g7_gru()
+        sys.exit(0)
     g1_loss()
     g3_metrics()
     g4_sched()

@@ -73,3 +73,79 @@ def test_gru_argument_checks():
         nat.gru_fwd(x, w_ih, w_hh, b, b, torch.zeros(4, 5, 128, device=DEV), ws[:100])       # workspace too small
     with pytest.raises(ValueError):
         nat.gru_fwd(x.transpose(0, 1), w_ih, w_hh, b, b, torch.zeros(5, 4, 128, device=DEV), ws)
+
+
+# ------------------------------------------------------------------------------------------ model level
+def _golden():
+    from pathlib import Path
+    return np.load(Path(__file__).parent / "golden" / "g7_gru.npz")
+
+
+def _sd_from_golden(g):
+    return {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+
+
+def test_gruwakeword_matches_reference_fixture():
+    """tests/golden/g7_gru.npz was produced by the reference's own GRUWakeword (make_golden.py g7): same state_dict keys,
+    eval logits, training loss and every parameter gradient."""
+    from wakeword_trainer_home_amd.models import create_model
+    g = _golden()
+    sd = _sd_from_golden(g)
+    model = create_model("gru", num_classes=2, input_size=40, hidden_size=128, num_layers=2, bidirectional=True, dropout=0.0)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd)
+    model.to(DEV)
+    x, y = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        ev = model(x)
+    assert (ev.cpu() - torch.from_numpy(g["logits_eval"])).abs().max().item() <= 2e-5
+    model.train()
+    out = model(x)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5
+    for n, p in model.named_parameters():
+        ref = torch.from_numpy(g["grad." + n])
+        assert _rel(p.grad.cpu(), ref) <= 5e-4, n
+    # (B,1,F,T) feature batches, as the Trainer produces them, give the same logits
+    with torch.no_grad():
+        model.eval()
+        ev4 = model(x.transpose(1, 2)[:, None].contiguous())
+    assert torch.equal(ev4, ev)
+
+
+@pytest.mark.parametrize("layers,bidir", [(2, True), (1, True), (2, False)])
+def test_gruwakeword_with_dropout_matches_oracle(layers, bidir):
+    from wakeword_trainer_home_amd.models import create_model
+    from oracle.gru import GRUWakewordOracle
+    torch.manual_seed(layers * 3 + int(bidir))
+    model = create_model("gru", input_size=40, num_layers=layers, bidirectional=bidir, dropout=0.3, dropout_seed=21).to(DEV)
+    oracle = GRUWakewordOracle(40, 128, layers, 2, bidir, dropout=0.3, seed=21)
+    oracle.load_reference_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    B, T = 9, 23
+    x = torch.randn(B, T, 40)
+    y = torch.randint(0, 2, (B,))
+    model.train()
+    model.sample_offset = 5
+    for step in range(2):
+        xd = x.to(DEV).requires_grad_(True)
+        out = model(xd)
+        loss = torch.nn.functional.cross_entropy(out, y.to(DEV))
+        model.zero_grad()
+        loss.backward()
+        xo = x.double().requires_grad_(True)
+        ref = oracle(xo, step=step, sample_offset=5, training=True)
+        lo = torch.nn.functional.cross_entropy(ref, y)
+        oracle.zero_grad()
+        lo.backward()
+        assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 5e-5, step
+        assert _rel(xd.grad.cpu().double(), xo.grad) <= 5e-4
+        nd = 2 if bidir else 1
+        for k in range(layers):
+            for sfx in ("", "_reverse")[:nd]:
+                for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                    gd = getattr(model.gru, f"{name}_l{k}{sfx}").grad.cpu().double()
+                    go = getattr(oracle.layers[k], f"{name}_l0{sfx}").grad
+                    assert _rel(gd, go) <= 5e-4, (step, name, k, sfx)
+        assert _rel(model.fc[1].weight.grad.cpu().double(), oracle.fc.weight.grad) <= 5e-4

@@ -176,3 +176,32 @@ def test_step_oracle_reproduces_reference_trainer_trace(golden_dir, tag):
         assert abs(r["loss"] - tr["step_loss"][i]) < 1e-6, (i, r["loss"], tr["step_loss"][i])
         assert abs(r["acc"] - tr["step_acc"][i]) < 1e-6
         assert abs(r["grad_norm"] - tr["grad_norm"][i]) < 1e-3 * max(1.0, tr["grad_norm"][i])
+
+
+def test_gru_oracle_matches_reference_fixture(golden_dir):
+    """oracle/gru.py (unrolled single-layer nn.GRU modules + explicit dropout masks) == the reference's GRUWakeword on the
+    fixture written by importing it (tests/golden/make_golden.py g7): pins the oracle the device GRU is checked against."""
+    import numpy as np
+    import torch
+    from oracle.gru import GRUWakewordOracle, dropout_bt_mask
+    g = np.load(golden_dir / "g7_gru.npz")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    oracle = GRUWakewordOracle(40, 128, 2, 2, True, dropout=0.0)
+    oracle.load_reference_state_dict(sd)
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    ev = oracle(x, training=False)
+    assert (ev.detach() - torch.from_numpy(g["logits_eval"]).double()).abs().max().item() <= 1e-6
+    out = oracle(x, training=True)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6
+    for k, layer in enumerate(oracle.layers):
+        for sfx in ("", "_reverse"):
+            for name in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                ref = torch.from_numpy(g[f"grad.gru.{name}_l{k}{sfx}"]).double()
+                got = getattr(layer, f"{name}_l0{sfx}").grad
+                assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-9
+    # the dropout mask law: keep-rate and determinism
+    m = dropout_bt_mask(64, 20, 256, 0.3, seed=3, step=4, sample_offset=10, stream_id=2)
+    assert abs(m.mean() - 0.7) < 0.01 and np.array_equal(m, dropout_bt_mask(64, 20, 256, 0.3, 3, 4, 10, 2))
+    assert not np.array_equal(m, dropout_bt_mask(64, 20, 256, 0.3, 3, 4, 10, 3))

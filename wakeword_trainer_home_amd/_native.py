@@ -86,6 +86,7 @@ _SIGS = {
     "ww_linear_mfma_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
     "ww_linear_mfma_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(LinearEpi), _vp, _vp, _vp, _vp, _sz,
                                      _vp]),
+    "ww_dropout_bt": (C.c_int, [_vp, _vp, C.c_long, _i, _i, _i, _f, _u64, _u64, _u64, _i, _vp, C.c_long, _vp]),
     "ww_gru_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ww_gru_fwd": (C.c_int, [_vp, _vp, C.c_long, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_long, _vp, _vp, _sz, _vp]),
     "ww_gru_bwd": (C.c_int, [_vp, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, C.c_long, _i,
@@ -375,6 +376,19 @@ def _bt_rows(t, name):
     if t.dim() != 3 or t.dtype != torch.float32 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
         raise ValueError(f"{name} must be float32 (B,T,F) with contiguous features and equidistant (b,t) rows")
     return t.stride(1)
+
+
+def dropout_bt(x, p, seed=0, step=0, sample_offset=0, stream_id=0, out=None):
+    """Philox dropout of a (B,T,C) tensor (rows may be strided); also its own backward when applied to the gradient."""
+    dev = _dev_rows(x, out)
+    ldx = _bt_rows(x, "x")
+    B, T, Cc = x.shape
+    if out is None:
+        out = torch.empty((B, T, Cc), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_dropout_bt(ctx(dev), _p(x), ldx, B, T, Cc, p, seed, step, sample_offset, stream_id, _p(out),
+                                    _bt_rows(out, "out"), _stream(dev)), "ww_dropout_bt")
+    return out
 
 
 def gru_workspace(B, T, I, H, dev):

@@ -138,6 +138,30 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
         }
 }
 
+// Philox dropout on a (B,T,C) tensor with row-strided rows: out = keep ? x * scale : 0.  Counter field (24 bits):
+// stream_id (4) | t (12) | c>>2 (8); lane c&3; sample = global batch index.  Its own backward (apply to the gradient).
+__global__ __launch_bounds__(256) void k_dropout_bt(const float *__restrict__ x, long ldx, int B, int T, int C, float scale,
+                                                    uint64_t thresh, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
+                                                    uint32_t step_hi, uint64_t sample_offset, uint32_t stream_id,
+                                                    float *__restrict__ out, long ldo) {
+    const int cq = (C + 3) / 4;
+    const long n = (long)B * T * cq;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % cq);
+        const long m = i / cq;
+        const int t = (int)(m % T), b = (int)(m / T);
+        uint32_t rr[4];
+        ww_philox(step_lo, step_hi, (uint32_t)(sample_offset + (uint64_t)b),
+                  (WW_TAG_DROPOUT << 24) | (stream_id << 20) | ((uint32_t)t << 8) | (uint32_t)q, seed_lo, seed_hi, rr);
+        const float *src = x + m * ldx + 4 * q;
+        float *dst = out + m * ldo + 4 * q;
+        if (4 * q < C) dst[0] = (uint64_t)rr[0] >= thresh ? src[0] * scale : 0.f;
+        if (4 * q + 1 < C) dst[1] = (uint64_t)rr[1] >= thresh ? src[1] * scale : 0.f;
+        if (4 * q + 2 < C) dst[2] = (uint64_t)rr[2] >= thresh ? src[2] * scale : 0.f;
+        if (4 * q + 3 < C) dst[3] = (uint64_t)rr[3] >= thresh ? src[3] * scale : 0.f;
+    }
+}
+
 struct WsLayout { size_t gi, dgh, r, z, n, hn, hp, part, total; };
 constexpr int GRU_SPLITS = 32, GRU_CHUNKS = 64;
 WsLayout ws_layout(long B, long T, int I) {
@@ -165,6 +189,23 @@ GruSaved saved(char *w, const WsLayout &L) {
 }
 
 }  // namespace
+
+extern "C" int ww_dropout_bt(ww_ctx *ctx, const float *x, long ldx, int B, int T, int C, float p, uint64_t seed,
+                             uint64_t step, uint64_t sample_offset, int stream_id, float *out, long ldo,
+                             ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && out, WW_E_INVALID, "ww_dropout_bt: null argument");
+    WW_REQUIRE(B >= 1 && T >= 1 && C >= 1 && ldx >= C && ldo >= C, WW_E_INVALID, "ww_dropout_bt: bad shape");
+    WW_REQUIRE(T <= 4096 && C <= 1024 && stream_id >= 0 && stream_id < 16, WW_E_UNSUPPORTED,
+               "ww_dropout_bt: T <= 4096, C <= 1024, stream_id < 16");
+    WW_REQUIRE(p >= 0.f && p < 1.f, WW_E_INVALID, "ww_dropout_bt: p=%f not in [0,1)", (double)p);
+    const long n = (long)B * T * ((C + 3) / 4);
+    const int grid = (int)std::min<long>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_dropout_bt, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, B, T, C,
+                       (float)(1.0 / (1.0 - (double)p)), ww_prob_threshold((double)p), (uint32_t)seed, (uint32_t)(seed >> 32),
+                       (uint32_t)step, (uint32_t)(step >> 32), sample_offset, (uint32_t)stream_id, out, ldo);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
 
 extern "C" size_t ww_gru_workspace_bytes(int B, int T, int I, int H) {
     if (B < 1 || T < 1 || I < 1 || H != GH) return 0;

@@ -15,8 +15,8 @@ import torch.nn as nn
 
 from .. import _native as nat
 
-_SUPPORTED = "cnn_small"
-_REFERENCE_ONLY = ("resnet18", "mobilenetv3", "lstm", "gru", "tcn")
+_SUPPORTED = "cnn_small, gru"
+_REFERENCE_ONLY = ("resnet18", "mobilenetv3", "lstm", "tcn")
 
 
 class _DSBlock(nn.Module):
@@ -264,6 +264,12 @@ def create_model(architecture: str, num_classes: int = 2, pretrained: bool = Fal
         return CNNSmallWakeword(num_classes=num_classes, pretrained=pretrained, dropout=kwargs.get("dropout", 0.3),
                                 input_channels=kwargs.get("input_channels", 1),
                                 dropout_seed=kwargs.get("dropout_seed", 0), act_dtype=kwargs.get("act_dtype", "fp32"))
+    if name == "gru":                                   # same kwargs as the reference factory (architectures.py:490-498)
+        from .recurrent import GRUWakeword
+        return GRUWakeword(input_size=kwargs.get("input_size", 40), hidden_size=kwargs.get("hidden_size", 128),
+                           num_layers=kwargs.get("num_layers", 2), num_classes=num_classes,
+                           bidirectional=kwargs.get("bidirectional", True), dropout=kwargs.get("dropout", 0.3),
+                           dropout_seed=kwargs.get("dropout_seed", 0))
     if name in _REFERENCE_ONLY:
         raise ValueError(f"Architecture '{architecture}' exists in the reference but is outside this build's "
                          f"HIP hot path (DESIGN.md 'Out of scope'). Supported: {_SUPPORTED}")

@@ -1,0 +1,167 @@
+"""``GRUWakeword`` with the constructor, ``forward`` contract and ``state_dict`` keys of the reference class
+(``src/models/architectures.py:198-267``: ``gru.weight_ih_l0`` ... ``gru.bias_hh_l1_reverse``, ``fc.1.weight``, ``fc.1.bias``),
+running on ``ww_gru_fwd/bwd`` (one persistent MFMA kernel per layer and direction), ``ww_dropout_bt`` and the MFMA
+``fc``.  It also accepts the (B,1,F,T) feature batches the Trainer produces (the reference class takes (B,T,F) only and
+cannot be driven by its own Trainer -- SURVEY.md Q3).  Hidden size 128 (the reference default) is the implemented size."""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _native as nat
+from .heads import MFMALinear
+
+
+class _GRUStackFn(torch.autograd.Function):
+    """All layers and directions of the stack; parameters arrive flat in nn.GRU's ``_flat_weights`` order."""
+
+    @staticmethod
+    def forward(ctx, x, mod, step, *params):
+        L, nd, H = mod.num_layers, mod.num_directions, mod.hidden_size
+        B, T, _ = x.shape
+        dev = x.device
+        p = mod.dropout if (mod.training and L > 1) else 0.0
+        inputs, workspaces, h_last = [x], [], []
+        cur = x
+        for k in range(L):
+            out = torch.empty((B, T, nd * H), dtype=torch.float32, device=dev)
+            ws_k = []
+            for d in range(nd):
+                w_ih, w_hh, b_ih, b_hh = params[4 * (k * nd + d):4 * (k * nd + d) + 4]
+                ws = nat.gru_workspace(B, T, cur.shape[2], H, dev)
+                h_n = nat.gru_fwd(cur, w_ih, w_hh, b_ih, b_hh, out[:, :, d * H:(d + 1) * H], ws, reverse=(d == 1))
+                ws_k.append(ws)
+                if k == L - 1:
+                    h_last.append(h_n)
+            workspaces.append(ws_k)
+            if p > 0 and k + 1 < L:
+                out = nat.dropout_bt(out, p, seed=mod.dropout_seed, step=step, sample_offset=mod.sample_offset, stream_id=1 + k)
+            cur = out
+            if k + 1 < L:
+                inputs.append(cur)
+        ctx.mod, ctx.step, ctx.p = mod, step, p
+        ctx.inputs, ctx.workspaces = inputs, workspaces
+        ctx.save_for_backward(*params)
+        return torch.cat(h_last, dim=1) if nd == 2 else h_last[0]
+
+    @staticmethod
+    def backward(ctx, dh):
+        mod, params = ctx.mod, ctx.saved_tensors
+        L, nd, H = mod.num_layers, mod.num_directions, mod.hidden_size
+        grads = [None] * len(params)
+        dh = dh.contiguous()
+        dy = None                                  # gradient of layer k's (dropped-out) output, (B,T,nd*H)
+        for k in reversed(range(L)):
+            xin = ctx.inputs[k]
+            need_dx = k > 0 or ctx.needs_input_grad[0]
+            dx = torch.empty_like(xin) if need_dx else None
+            for d in range(nd):
+                w_ih, w_hh = params[4 * (k * nd + d)], params[4 * (k * nd + d) + 1]
+                dyd = dy[:, :, d * H:(d + 1) * H] if dy is not None else None
+                dhn = dh[:, d * H:(d + 1) * H].contiguous() if k == L - 1 else None
+                g = nat.gru_bwd(xin, w_ih, w_hh, dyd, dhn, ctx.workspaces[k][d], reverse=(d == 1), dx=dx,
+                                accumulate_dx=(d > 0))
+                grads[4 * (k * nd + d):4 * (k * nd + d) + 4] = g[:4]
+            if k > 0:
+                dy = dx
+                if ctx.p > 0:                      # backward of the inter-layer dropout: the same mask on the gradient
+                    dy = nat.dropout_bt(dy, ctx.p, seed=mod.dropout_seed, step=ctx.step, sample_offset=mod.sample_offset,
+                                        stream_id=k)
+            else:
+                dy = dx
+        ctx.workspaces = ctx.inputs = None
+        return (dy if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
+
+
+class NativeGRU(nn.Module):
+    """Parameter container with nn.GRU's names/initialisation; ``forward(x (B,T,I)) -> h_n of the last layer (B, nd*H)``."""
+
+    def __init__(self, input_size, hidden_size=128, num_layers=2, bidirectional=True, dropout=0.0, dropout_seed=0):
+        super().__init__()
+        if hidden_size != 128:
+            raise nat.NativeError(f"the HIP GRU kernels implement hidden_size == 128 (the reference default), got {hidden_size}")
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.num_directions = 2 if bidirectional else 1
+        self.dropout, self.dropout_seed = float(dropout), dropout_seed
+        self.dropout_step, self.sample_offset = 0, 0
+        k = 1.0 / math.sqrt(hidden_size)
+        self._names = []
+        for layer in range(num_layers):
+            for d in range(self.num_directions):
+                sfx = "_reverse" if d == 1 else ""
+                isz = input_size if layer == 0 else hidden_size * self.num_directions
+                for name, shape in ((f"weight_ih_l{layer}{sfx}", (3 * hidden_size, isz)),
+                                    (f"weight_hh_l{layer}{sfx}", (3 * hidden_size, hidden_size)),
+                                    (f"bias_ih_l{layer}{sfx}", (3 * hidden_size,)), (f"bias_hh_l{layer}{sfx}", (3 * hidden_size,))):
+                    self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))     # nn.GRU.reset_parameters
+                    self._names.append(name)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise nat.NativeError("the GRU runs on hand-written HIP kernels only: the input is on "
+                                  f"'{x.device}', need an MI355X ('cuda') device -- there is no CPU fallback")
+        if x.dim() != 3 or x.shape[2] != self.input_size:
+            raise ValueError(f"expected input (B,T,{self.input_size}), got {tuple(x.shape)}")
+        step = self.dropout_step
+        if self.training and self.dropout > 0 and self.num_layers > 1:
+            self.dropout_step += 1
+        return _GRUStackFn.apply(x.float().contiguous(), self, step, *[getattr(self, n) for n in self._names])
+
+
+class _HiddenDropout(nn.Module):
+    """The ``nn.Dropout`` in front of ``fc`` (architectures.py:239), drawn from the Philox stream (stream 15)."""
+
+    def __init__(self, p, owner):
+        super().__init__()
+        self.p = float(p)
+        self._owner = [owner]          # not a submodule: only read for seed / step / sample offset
+
+    def forward(self, h):
+        gru = self._owner[0]
+        if not self.training or self.p <= 0:
+            return h
+        return _DropFn.apply(h, self.p, gru.dropout_seed, gru.fc_step, gru.sample_offset)
+
+
+class _DropFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, p, seed, step, offset):
+        ctx.args = (p, seed, step, offset)
+        return nat.dropout_bt(h.contiguous()[:, None, :], p, seed=seed, step=step, sample_offset=offset, stream_id=15)[:, 0]
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed, step, offset = ctx.args
+        dg = nat.dropout_bt(g.contiguous()[:, None, :], p, seed=seed, step=step, sample_offset=offset, stream_id=15)[:, 0]
+        return dg, None, None, None, None
+
+
+class GRUWakeword(nn.Module):
+    def __init__(self, input_size: int = 40, hidden_size: int = 128, num_layers: int = 2, num_classes: int = 2,
+                 bidirectional: bool = True, dropout: float = 0.3, dropout_seed: int = 0):
+        super().__init__()
+        self.hidden_size, self.num_layers, self.bidirectional = hidden_size, num_layers, bidirectional
+        self.gru = NativeGRU(input_size, hidden_size, num_layers, bidirectional, dropout if num_layers > 1 else 0.0,
+                             dropout_seed)
+        self.gru.fc_step = 0
+        out = hidden_size * 2 if bidirectional else hidden_size
+        self.fc = nn.Sequential(_HiddenDropout(dropout, self.gru), MFMALinear(out, num_classes))
+
+    @property
+    def sample_offset(self):
+        return self.gru.sample_offset
+
+    @sample_offset.setter
+    def sample_offset(self, v):
+        self.gru.sample_offset = v
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() == 4:                                    # (B,1,F,T) feature batch -> (B,T,F)
+            if x.shape[1] != 1:
+                raise ValueError(f"expected (B,1,F,T) features or (B,T,F) sequences, got {tuple(x.shape)}")
+            x = x[:, 0].transpose(1, 2)
+        self.gru.fc_step = self.gru.dropout_step            # one Philox step per training forward, shared by all masks
+        h = self.gru(x.contiguous())
+        if self.training and self.gru.dropout == 0 and self.fc[0].p > 0:
+            self.gru.dropout_step += 1                      # single-layer stacks: the fc dropout alone advances the stream
+        return self.fc(h)
