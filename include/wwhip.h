@@ -250,6 +250,17 @@ int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const float *w, co
                        const float *dy, int M, int K, int N, const ww_linear_epi *epi, float *dx /* nullable */, float *dw,
                        float *db /* nullable */, void *scratch, size_t scratch_bytes, ww_stream_t stream);
 
+/* ------------------------------------------------------------------ conv front-end of the CRNN
+ * cnn_small's conv stack (stem + 4 depthwise-separable blocks) without GAP / classifier, followed by the mean over the
+ * frequency axis of the last layer's activations: x (B,1,F,T) -> seq (B, ceil(T/2), 64) fp32, the input sequence of the
+ * recurrent layers.  Same parameter / gradient pointer tables and workspace as ww_cnn_small_fwd/bwd (entries 45, 46 --
+ * the classifier -- are not read and may be NULL).  The reference has no CRNN: the topology is this
+ * build's, assembled from the reference's conv idiom and its GRUWakeword.                                          */
+int ww_cnn_front_fwd(ww_ctx *ctx, int act_dtype, void *const *params, const float *x, int B, int F, int T, int training,
+                     float bn_momentum, float bn_eps, void *ws, size_t ws_bytes, float *seq, ww_stream_t stream);
+int ww_cnn_front_bwd(ww_ctx *ctx, int act_dtype, void *const *params, void *const *grads, const float *x, const float *dseq,
+                     int B, int F, int T, void *ws, size_t ws_bytes, ww_stream_t stream);
+
 /* ------------------------------------------------------------------ GRU layer, one direction
  * torch.nn.GRU's cell and parameter layout (gate order r|z|n; w_ih (3H,I), w_hh (3H,H), b_ih, b_hh (3H)) -- what the
  * reference's GRUWakeword wraps (src/models/architectures.py:228-235).  batch_first: x (B,T,I) with row stride ldx

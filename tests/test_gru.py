@@ -149,3 +149,49 @@ def test_gruwakeword_with_dropout_matches_oracle(layers, bidir):
                     go = getattr(oracle.layers[k], f"{name}_l0{sfx}").grad
                     assert _rel(gd, go) <= 5e-4, (step, name, k, sfx)
         assert _rel(model.fc[1].weight.grad.cpu().double(), oracle.fc.weight.grad) <= 5e-4
+
+
+@pytest.mark.parametrize("act", ["fp32", "bf16"])
+def test_crnn_matches_oracle(act):
+    """conv front-end + frequency pooling + GRU against oracle/crnn.py (torch.nn conv stack + nn.GRU, float64)."""
+    from wakeword_trainer_home_amd.models import create_model
+    from oracle.crnn import CRNNOracle
+    from tests.golden_util import make_inputs
+    torch.manual_seed(3)
+    model = create_model("crnn", dropout=0.3, dropout_seed=4, act_dtype=act).to(DEV)
+    keys = list(model.state_dict().keys())
+    assert keys[0] == "front.stem.conv.weight" and "rnn.gru.weight_hh_l1_reverse" in keys and keys[-1] == "rnn.fc.1.bias"
+    assert not any("classifier" in k for k in keys)
+    oracle = CRNNOracle(dropout=0.3, seed=4)
+    oracle.load_device_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    x, y = make_inputs(5, 12)
+    model.train()
+    oracle.train()
+    xd = x.to(DEV)
+    out = model(xd)
+    assert out.shape == (12, 2)
+    loss = torch.nn.functional.cross_entropy(out, y.to(DEV))
+    loss.backward()
+    ref = oracle(x, step=0, training=True)
+    lo = torch.nn.functional.cross_entropy(ref, y)
+    lo.backward()
+    tol = 2e-4 if act == "fp32" else 3e-2
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= tol
+    assert abs(loss.item() - lo.item()) <= tol
+    gd = torch.cat([p.grad.flatten().cpu().double() for n, p in model.named_parameters() if n.startswith("rnn.")])
+    go = torch.cat([p.grad.flatten() for p in oracle.rnn.parameters()])
+    assert len(gd) == len(go)
+    # whole-vector bounds: at B=12 a single fp32 ReLU decision within round-off of zero moves individual conv gradients
+    assert ((gd - go).norm() / go.norm()).item() <= (2e-3 if act == "fp32" else 8e-2)
+    fd = torch.cat([p.grad.flatten().cpu().double() for n, p in model.named_parameters() if n.startswith("front.")])
+    fo = torch.cat([p.grad.flatten() for n, p in oracle.front.named_parameters() if not n.startswith("classifier")])
+    if act == "fp32":
+        assert ((fd - fo).norm() / fo.norm()).item() <= 2e-2
+    else:      # bf16 storage of 9 activation / 9 gradient tensors at B=12: direction of the conv-stack gradient (cf. test_bf16_mode.py)
+        assert (fd @ fo / (fd.norm() * fo.norm())).item() > 0.97
+    model.eval()                      # running statistics were updated by ONE training forward on both sides
+    oracle.eval()
+    with torch.no_grad():
+        ev = model(xd)
+        ev_ref = oracle(x, training=False)
+    assert (ev.cpu().double() - ev_ref).abs().max().item() <= (5e-4 if act == "fp32" else 5e-2)

@@ -106,6 +106,8 @@ _SIGS = {
     "ww_cnn_small_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ww_cnn_small_fwd": (C.c_int, [_vp, _i, C.POINTER(_vp), _vp, _i, _i, _i, _i, _f, _f, _f, _u64, _u64, _u64, _vp, _sz,
                                    _vp, _vp]),
+    "ww_cnn_front_fwd": (C.c_int, [_vp, _i, C.POINTER(_vp), _vp, _i, _i, _i, _i, _f, _f, _vp, _sz, _vp, _vp]),
+    "ww_cnn_front_bwd": (C.c_int, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "ww_cnn_small_bwd": (C.c_int, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i, _i, _i, _f, _u64, _u64, _u64,
                                    _vp, _sz, _vp]),
     "ww_ce2_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
@@ -596,6 +598,22 @@ def cnn_small_bwd(params, grads, x, dlogits, ws, dropout_p=0.0, seed=0, step=0, 
         _check(load().ww_cnn_small_bwd(ctx(dev), act, params, grads, _p(x), _p(dlogits), B, F, T, dropout_p, seed, step,
                                        sample_offset, _p(ws), ws.numel() * ws.element_size(), _stream(dev)),
                "ww_cnn_small_bwd")
+
+
+def cnn_front_fwd(params, x, ws, seq, training, bn_momentum=0.1, bn_eps=1e-5, act=ACT_F32):
+    dev = _dev(x, ws, seq)
+    B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
+    with torch.cuda.device(dev):
+        _check(load().ww_cnn_front_fwd(ctx(dev), act, params, _p(x), B, F, T, int(training), bn_momentum, bn_eps, _p(ws),
+                                       ws.numel() * ws.element_size(), _p(seq), _stream(dev)), "ww_cnn_front_fwd")
+
+
+def cnn_front_bwd(params, grads, x, dseq, ws, act=ACT_F32):
+    dev = _dev(x, ws, dseq)
+    B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
+    with torch.cuda.device(dev):
+        _check(load().ww_cnn_front_bwd(ctx(dev), act, params, grads, _p(x), _p(dseq), B, F, T, _p(ws),
+                                       ws.numel() * ws.element_size(), _stream(dev)), "ww_cnn_front_bwd")
 
 
 def ce2_loss_fwd_bwd(logits, targets, kind=LOSS_CE, label_smoothing=0.0, focal_alpha=0.25, focal_gamma=2.0,

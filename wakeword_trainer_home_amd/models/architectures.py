@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import _native as nat
 
-_SUPPORTED = "cnn_small, gru"
+_SUPPORTED = "cnn_small, gru, crnn"
 _REFERENCE_ONLY = ("resnet18", "mobilenetv3", "lstm", "tcn")
 
 
@@ -48,6 +48,23 @@ class _CNNSmallFn(torch.autograd.Function):
         return (None, None) + (None,) * len(ctx.mod._plist)
 
 
+class _CNNFrontFn(torch.autograd.Function):
+    """seq = mean over frequency of the conv stack's last activations (the CRNN front-end)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, *params):
+        seq, ws = mod._launch_front_forward(x, training=True)
+        ctx.mod, ctx.ws = mod, ws
+        ctx.save_for_backward(x)
+        return seq
+
+    @staticmethod
+    def backward(ctx, dseq):
+        (x,) = ctx.saved_tensors
+        ctx.mod._launch_front_backward(x, dseq, ctx.ws)
+        return (None, None) + (None,) * len(ctx.mod._plist)
+
+
 class CNNSmallWakeword(nn.Module):
     """stem Conv2d(1,64,3,s2,p1)+BN+ReLU -> 4 x [DW3x3+BN+ReLU, PW1x1+BN+ReLU] -> GAP -> dropout -> Linear(64,2).
 
@@ -58,8 +75,9 @@ class CNNSmallWakeword(nn.Module):
     N_BLOCKS = 4
 
     def __init__(self, num_classes: int = 2, pretrained: bool = False, dropout: float = 0.3,
-                 input_channels: int = 1, dropout_seed: int = 0, act_dtype: str = "fp32"):
+                 input_channels: int = 1, dropout_seed: int = 0, act_dtype: str = "fp32", features_only: bool = False):
         super().__init__()
+        self.features_only = bool(features_only)      # conv stack + frequency pooling only (the CRNN's front-end)
         self.act = nat.act_code(act_dtype)   # storage of the conv-stack activations: fp32 (parity) | bf16
         if num_classes != 2:
             raise ValueError(f"cnn_small: the HIP classifier/loss kernels implement num_classes == 2, got {num_classes}")
@@ -72,7 +90,8 @@ class CNNSmallWakeword(nn.Module):
         self.stem = nn.Sequential(OrderedDict(conv=nn.Conv2d(1, self.CH, 3, stride=2, padding=1, bias=False),
                                               bn=nn.BatchNorm2d(self.CH)))
         self.blocks = nn.ModuleList([_DSBlock(self.CH) for _ in range(self.N_BLOCKS)])
-        self.classifier = nn.Linear(self.CH, num_classes)
+        if not self.features_only:
+            self.classifier = nn.Linear(self.CH, num_classes)
         self.p = float(dropout)
         self.dropout_seed = int(dropout_seed)
         self.dropout_step = 0        # advanced once per training-mode forward (counter of the Philox stream)
@@ -92,7 +111,7 @@ class CNNSmallWakeword(nn.Module):
         for blk in self.blocks:
             out += [blk.dw.weight, blk.dw_bn.weight, blk.dw_bn.bias, blk.dw_bn.running_mean, blk.dw_bn.running_var,
                     blk.pw.weight, blk.pw_bn.weight, blk.pw_bn.bias, blk.pw_bn.running_mean, blk.pw_bn.running_var]
-        return out + [self.classifier.weight, self.classifier.bias]
+        return out + ([None, None] if self.features_only else [self.classifier.weight, self.classifier.bias])
 
     def _reset_caches(self):
         self._plist = None
@@ -117,10 +136,12 @@ class CNNSmallWakeword(nn.Module):
 
     def _prepare(self, dev):
         tensors = self._ordered()
-        key = tuple(t.data_ptr() for t in tensors)
+        key = tuple(0 if t is None else t.data_ptr() for t in tensors)
         if self._pptr is not None and self._pkey == key:
             return
         for t in tensors:
+            if t is None:
+                continue
             if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev:
                 raise nat.NativeError("cnn_small parameters must be contiguous float32 on the input's device")
         # parameters become views of ONE flat fp32 bucket (same order as the gradient bucket): the fused clip+optimizer
@@ -134,7 +155,7 @@ class CNNSmallWakeword(nn.Module):
             t.data = view
             off += t.numel()
         self._flat_param = flat
-        key = tuple(t.data_ptr() for t in tensors)
+        key = tuple(0 if t is None else t.data_ptr() for t in tensors)
         self._pkey = key
         self._pptr = nat.ptr_array(tensors)
         self._plist = [t for t in tensors if isinstance(t, nn.Parameter)]
@@ -147,7 +168,7 @@ class CNNSmallWakeword(nn.Module):
             views[id(t)] = self._flat_grad[off:off + t.numel()].view_as(t)
             off += n
         self._grad_views = views
-        self._gptr = nat.ptr_array([views.get(id(t)) for t in tensors])
+        self._gptr = nat.ptr_array([None if t is None else views.get(id(t)) for t in tensors])
 
     @property
     def flat_param(self):
@@ -221,9 +242,44 @@ class CNNSmallWakeword(nn.Module):
             for t in self._plist:
                 views[id(t)] = tmp[off:off + t.numel()].view_as(t)
                 off += t.numel()
-            gptr = nat.ptr_array([views.get(id(t)) for t in tens])
+            gptr = nat.ptr_array([None if t is None else views.get(id(t)) for t in tens])
         nat.cnn_small_bwd(self._pptr, gptr, x, dlogits.contiguous(), slot["buf"], dropout_p=self.p,
                           seed=self.dropout_seed, step=step, sample_offset=self.sample_offset, act=self.act)
+        slot["busy"] = False
+        for p in self._plist:
+            if fresh:
+                p.grad = self._grad_views[id(p)]
+            elif p.grad is None:
+                p.grad = views[id(p)].clone()
+            else:
+                p.grad.add_(views[id(p)])
+
+    # ------------------------------------------------------------------ CRNN front-end (features_only)
+    def _launch_front_forward(self, x, training):
+        dev = x.device
+        self._prepare(dev)
+        B, _, F, T = x.shape
+        slot = self._workspace(B, F, T, dev, hold=training and torch.is_grad_enabled())
+        seq = torch.empty((B, (T + 1) // 2, self.CH), dtype=torch.float32, device=dev)
+        bn0 = self.stem.bn
+        nat.cnn_front_fwd(self._pptr, x, slot["buf"], seq, training=training,
+                          bn_momentum=bn0.momentum if bn0.momentum is not None else 0.1, bn_eps=bn0.eps, act=self.act)
+        if training:
+            self._pending_tracked += 1
+        return seq, slot
+
+    def _launch_front_backward(self, x, dseq, slot):
+        fresh = all(p.grad is None for p in self._plist)
+        if fresh:
+            gptr, views = self._gptr, None
+        else:
+            tmp = torch.zeros_like(self._flat_grad)
+            views, off, tens = {}, 0, self._ordered()
+            for t in self._plist:
+                views[id(t)] = tmp[off:off + t.numel()].view_as(t)
+                off += t.numel()
+            gptr = nat.ptr_array([None if t is None else views.get(id(t)) for t in tens])
+        nat.cnn_front_bwd(self._pptr, gptr, x, dseq.contiguous(), slot["buf"], act=self.act)
         slot["busy"] = False
         for p in self._plist:
             if fresh:
@@ -250,6 +306,11 @@ class CNNSmallWakeword(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self._check_input(x)
+        if self.features_only:                     # -> (B, ceil(T/2), 64) sequence
+            if self.training and torch.is_grad_enabled():
+                self._prepare(x.device)
+                return _CNNFrontFn.apply(x, self, *self._plist)
+            return self._launch_front_forward(x, training=self.training)[0]
         if self.training and torch.is_grad_enabled():
             self._prepare(x.device)
             return _CNNSmallFn.apply(x, self, *self._plist)
@@ -264,6 +325,12 @@ def create_model(architecture: str, num_classes: int = 2, pretrained: bool = Fal
         return CNNSmallWakeword(num_classes=num_classes, pretrained=pretrained, dropout=kwargs.get("dropout", 0.3),
                                 input_channels=kwargs.get("input_channels", 1),
                                 dropout_seed=kwargs.get("dropout_seed", 0), act_dtype=kwargs.get("act_dtype", "fp32"))
+    if name == "crnn":                                  # not in the reference factory: BASELINE config 5's model
+        from .recurrent import CRNNWakeword
+        return CRNNWakeword(num_classes=num_classes, hidden_size=kwargs.get("hidden_size", 128),
+                            num_layers=kwargs.get("num_layers", 2), bidirectional=kwargs.get("bidirectional", True),
+                            dropout=kwargs.get("dropout", 0.3), dropout_seed=kwargs.get("dropout_seed", 0),
+                            act_dtype=kwargs.get("act_dtype", "fp32"))
     if name == "gru":                                   # same kwargs as the reference factory (architectures.py:490-498)
         from .recurrent import GRUWakeword
         return GRUWakeword(input_size=kwargs.get("input_size", 40), hidden_size=kwargs.get("hidden_size", 128),

@@ -136,6 +136,33 @@ class _DropFn(torch.autograd.Function):
         return dg, None, None, None, None
 
 
+class CRNNWakeword(nn.Module):
+    """Conv front-end + GRU (BASELINE config 5's model; the reference has no CRNN -- SURVEY.md F4 -- so the topology is this
+    build's, made of the reference's own parts): cnn_small's conv stack (stem + 4 depthwise-separable blocks, 64 channels)
+    -> BN+ReLU -> mean over the frequency axis -> (B, T/2, 64) -> GRUWakeword's recurrent part (2-layer bidirectional GRU,
+    final hidden states concatenated -> Dropout -> Linear).  ``forward((B,1,F,T)) -> (B, num_classes)``."""
+
+    def __init__(self, num_classes: int = 2, hidden_size: int = 128, num_layers: int = 2, bidirectional: bool = True,
+                 dropout: float = 0.3, dropout_seed: int = 0, act_dtype: str = "fp32"):
+        super().__init__()
+        from .architectures import CNNSmallWakeword
+        self.front = CNNSmallWakeword(num_classes=2, dropout=0.0, act_dtype=act_dtype, features_only=True)
+        self.rnn = GRUWakeword(input_size=CNNSmallWakeword.CH, hidden_size=hidden_size, num_layers=num_layers,
+                               num_classes=num_classes, bidirectional=bidirectional, dropout=dropout, dropout_seed=dropout_seed)
+
+    @property
+    def sample_offset(self):
+        return self.rnn.sample_offset
+
+    @sample_offset.setter
+    def sample_offset(self, v):
+        self.rnn.sample_offset = v
+        self.front.sample_offset = v
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.rnn(self.front(x))
+
+
 class GRUWakeword(nn.Module):
     def __init__(self, input_size: int = 40, hidden_size: int = 128, num_layers: int = 2, num_classes: int = 2,
                  bidirectional: bool = True, dropout: float = 0.3, dropout_seed: int = 0):
