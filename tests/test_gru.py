@@ -195,3 +195,49 @@ def test_crnn_matches_oracle(act):
         ev = model(xd)
         ev_ref = oracle(x, training=False)
     assert (ev.cpu().double() - ev_ref).abs().max().item() <= (5e-4 if act == "fp32" else 5e-2)
+
+
+@pytest.mark.parametrize("arch", ["crnn", "gru"])
+def test_trainer_drives_recurrent_models(tmp_path, arch):
+    """Trainer.train_epoch / validate_epoch on waveform batches with the recurrent models (generic autograd path: native
+    front end -> model -> native loss -> torch AdamW); first-step loss == the oracle pipeline's."""
+    from wakeword_trainer_home_amd.config import get_preset
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    from wakeword_trainer_home_amd.data import make_synthetic_batch
+    from oracle.train_step import frontend
+    from oracle.crnn import CRNNOracle
+    from oracle.gru import GRUWakewordOracle
+    cfg = get_preset("cnn_small_logmel40")
+    cfg.training.epochs, cfg.optimizer.warmup_epochs, cfg.training.batch_size = 1, 0, 8
+    cfg.loss.label_smoothing = 0.0
+    torch.manual_seed(9)
+    model = create_model(arch, dropout=0.0)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    wave, y = make_synthetic_batch(24, 24000, seed=5)
+    y[::3] = 1
+    batches = [(wave[i:i + 8], y[i:i + 8], [{"path": "s"}] * 8) for i in range(0, 24, 8)]
+    t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=tmp_path, device=DEV)
+    losses = []
+
+    class Rec:
+        def on_batch_end(self, batch_idx, loss, acc):
+            losses.append(loss)
+    t.add_callback(Rec())
+    t.train_epoch(0)
+    assert len(losses) == 3 and all(np.isfinite(losses))
+    a = cfg.augmentation
+    spec = dict(freq_mask_param=a.freq_mask_param, time_mask_param=a.time_mask_param, n_freq_masks=a.n_freq_masks,
+                n_time_masks=a.n_time_masks, freq_mask_prob=a.freq_mask_prob, time_mask_prob=a.time_mask_prob)
+    x0, _ = frontend(batches[0][0].numpy(), spec, seed=a.seed, step=0)
+    if arch == "crnn":
+        oracle = CRNNOracle(dropout=0.0)
+        oracle.load_device_state_dict(sd)
+    else:
+        oracle = GRUWakewordOracle(40, dropout=0.0)
+        oracle.load_reference_state_dict(sd)
+    oracle.train()
+    ref = torch.nn.functional.cross_entropy(oracle(torch.as_tensor(x0), training=True), batches[0][1]).item()
+    assert abs(losses[0] - ref) < 1e-3, (losses[0], ref)
+    loss, m = t.validate_epoch(0)
+    assert m.total_samples == 8 and np.isfinite(loss)

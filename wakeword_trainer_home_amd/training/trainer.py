@@ -289,9 +289,18 @@ class Trainer:
         self._pending = launched
         return done
 
+    def _to_model_input(self, inputs, training):
+        """(B,N) waveforms go through the native front end (log-mel/MFCC [+SpecAugment, audio augmentation]); feature
+        batches are moved as the reference does (channels_last, trainer.py:160)."""
+        if inputs.dim() == 2 and torch.device(self.device).type == "cuda":
+            return self._features(inputs, training=training)
+        return inputs.to(self.device, non_blocking=True, memory_format=torch.channels_last)
+
     def _step_generic(self, inputs, targets, batch_idx):
-        inputs = inputs.to(self.device, non_blocking=True, memory_format=torch.channels_last)
+        inputs = self._to_model_input(inputs, training=True)
         targets = targets.to(self.device, non_blocking=True)
+        if hasattr(self.model, "sample_offset"):
+            self.model.sample_offset = self.rank * inputs.shape[0]
         self.optimizer.zero_grad(set_to_none=True)
         dev_type = torch.device(self.device).type
         with torch.autocast(dev_type, enabled=self.use_mixed_precision and dev_type == "cuda"):
@@ -328,7 +337,7 @@ class Trainer:
                 return None
             self.val_metrics_tracker.update_counts(s["tp"], s["tn"], s["fp"], s["fn"])
             return s["loss"]
-        inputs = inputs.to(self.device, non_blocking=True, memory_format=torch.channels_last)
+        inputs = self._to_model_input(inputs, training=False)
         targets = targets.to(self.device, non_blocking=True)
         dev_type = torch.device(self.device).type
         with torch.autocast(dev_type, enabled=self.use_mixed_precision and dev_type == "cuda"):
