@@ -275,10 +275,10 @@ size_t ww_gru_workspace_bytes(int B, int T, int I, int H);
  * TAG_DROPOUT<<24 | stream_id<<20 | t<<8 | c>>2), lane c&3.  Applying it to the gradient is its backward.          */
 int ww_dropout_bt(ww_ctx *ctx, const float *x, long ldx, int B, int T, int C, float p, uint64_t seed, uint64_t step,
                   uint64_t sample_offset, int stream_id, float *out, long ldo, ww_stream_t stream);
-int ww_gru_fwd(ww_ctx *ctx, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *b_ih,
+int ww_gru_fwd(ww_ctx *ctx, int mode /* WW_ACT_F32 | WW_ACT_BF16: matrix type of the projection GEMMs */, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *b_ih,
                const float *b_hh, const float *h0, int B, int T, int I, int H, int reverse, float *y, long ldy, float *h_n,
                void *ws, size_t ws_bytes, ww_stream_t stream);
-int ww_gru_bwd(ww_ctx *ctx, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *dy, long ldy,
+int ww_gru_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *dy, long ldy,
                const float *dh_n, int B, int T, int I, int H, int reverse, void *ws, size_t ws_bytes, float *dx, long lddx,
                int accumulate_dx, float *dw_ih, float *dw_hh, float *db_ih, float *db_hh, float *dh0, ww_stream_t stream);
 

@@ -241,3 +241,25 @@ def test_trainer_drives_recurrent_models(tmp_path, arch):
     assert abs(losses[0] - ref) < 1e-3, (losses[0], ref)
     loss, m = t.validate_epoch(0)
     assert m.total_samples == 8 and np.isfinite(loss)
+
+
+def test_gruwakeword_bf16_matrix_mode():
+    """mode='bf16': the projection / weight-gradient GEMMs take bf16 operands (fp32 accumulation), the recurrence stays fp32.
+    Against the float64 oracle: logits within 2e-2, gradient direction cos > 0.999."""
+    from wakeword_trainer_home_amd.models import create_model
+    from oracle.gru import GRUWakewordOracle
+    torch.manual_seed(1)
+    model = create_model("gru", input_size=40, dropout=0.0, mode="bf16").to(DEV)
+    oracle = GRUWakewordOracle(40, dropout=0.0)
+    oracle.load_reference_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    x = torch.randn(33, 50, 40)
+    y = torch.randint(0, 2, (33,))
+    model.train()
+    out = model(x.to(DEV))
+    torch.nn.functional.cross_entropy(out, y.to(DEV)).backward()
+    ref = oracle(x, training=True)
+    torch.nn.functional.cross_entropy(ref, y).backward()
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 2e-2
+    gd = torch.cat([p.grad.flatten().cpu().double() for p in model.parameters()])
+    go = torch.cat([p.grad.flatten() for p in oracle.parameters()])
+    assert (gd @ go / (gd.norm() * go.norm())).item() > 0.999

@@ -1,0 +1,53 @@
+"""BASELINE config 5's model on one GPU: CRNN (conv front-end + 2-layer bidirectional GRU) training step -- log-mel front end,
+forward, native loss, backward, clip, AdamW -- at batch 4096 (and 512), inputs resident in HBM.  Secondary measurement:
+bench.py's headline line stays BASELINE config 2."""
+import contextlib
+import json
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+from wakeword_trainer_home_amd import _native as nat
+from wakeword_trainer_home_amd.config import get_preset
+from wakeword_trainer_home_amd.data import make_synthetic_batch
+from wakeword_trainer_home_amd.models import create_model
+from wakeword_trainer_home_amd.training import Trainer
+
+dev = "cuda:0"
+for arch, B, act in (("crnn", 512, "bf16"), ("crnn", 4096, "bf16"), ("gru", 4096, "fp32")):
+    cfg = get_preset("cnn_small_logmel40")
+    cfg.training.batch_size = B
+    torch.manual_seed(0)
+    kw = {"act_dtype": act} if arch == "crnn" else {}
+    model = create_model(arch, dropout=0.3, **kw)
+    with contextlib.redirect_stdout(sys.stderr):
+        tr = Trainer(model, [], [], cfg, checkpoint_dir=Path(tempfile.mkdtemp()), device=dev)
+    tr.model.train()
+    pool = [make_synthetic_batch(B, 24000, seed=i, device=dev) for i in range(2)]
+    classes = ["logmel_specaug", "conv_stem_fwd", "dwconv3x3_fwd", "pwconv1x1_fwd", "pwconv1x1_bwd", "dwconv3x3_bwd", "conv_stem_bwd",
+               "finalize", "gru", "linear_mfma"]
+
+    def step(i):
+        tr._step_generic(*pool[i % 2], i)
+
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    n = 8
+    t0 = time.perf_counter()
+    for i in range(n):
+        step(3 + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    nat.prof_enable(dev, classes)
+    step(100)
+    torch.cuda.synchronize()
+    prof = {k: round(v[0], 3) for k, v in nat.prof_collect(dev).items()}
+    nat.prof_enable(dev, [])
+    print(json.dumps({"model": arch, "batch": B, "conv_storage": act if arch == "crnn" else None, "ms_per_step": round(dt * 1e3, 3),
+                      "samples_per_s": round(B / dt, 1), "class_ms_one_step": prof}))
+    del tr, model, pool
+    torch.cuda.empty_cache()

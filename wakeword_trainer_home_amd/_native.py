@@ -88,8 +88,8 @@ _SIGS = {
                                      _vp]),
     "ww_dropout_bt": (C.c_int, [_vp, _vp, C.c_long, _i, _i, _i, _f, _u64, _u64, _u64, _i, _vp, C.c_long, _vp]),
     "ww_gru_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "ww_gru_fwd": (C.c_int, [_vp, _vp, C.c_long, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_long, _vp, _vp, _sz, _vp]),
-    "ww_gru_bwd": (C.c_int, [_vp, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, C.c_long, _i,
+    "ww_gru_fwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_long, _vp, _vp, _sz, _vp]),
+    "ww_gru_bwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, C.c_long, _i,
                              _vp, _vp, _vp, _vp, _vp, _vp]),
     "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp]),
     "ww_layer_scratch_bytes": (_sz, []),
@@ -400,7 +400,7 @@ def gru_workspace(B, T, I, H, dev):
     return torch.empty(n // 4, dtype=torch.float32, device=dev)
 
 
-def gru_fwd(x, w_ih, w_hh, b_ih, b_hh, y, ws, h0=None, reverse=False):
+def gru_fwd(x, w_ih, w_hh, b_ih, b_hh, y, ws, h0=None, reverse=False, mode=torch.float32):
     """One GRU direction: x (B,T,I) -> writes y (B,T,H) (may be a column slice of a (B,T,2H) buffer); returns h_n (B,H)."""
     dev = _dev(w_ih, w_hh, b_ih, b_hh, ws, h0)
     _dev_rows(x, y)
@@ -411,13 +411,13 @@ def gru_fwd(x, w_ih, w_hh, b_ih, b_hh, y, ws, h0=None, reverse=False):
         raise ValueError("GRU parameter / output shapes do not match (w_ih (3H,I), w_hh (3H,H), y (B,T,H))")
     h_n = torch.empty((B, H), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _check(load().ww_gru_fwd(ctx(dev), _p(x), ldx, _p(w_ih.contiguous()), _p(w_hh.contiguous()), _p(b_ih), _p(b_hh), _p(h0),
+        _check(load().ww_gru_fwd(ctx(dev), act_code(mode), _p(x), ldx, _p(w_ih.contiguous()), _p(w_hh.contiguous()), _p(b_ih), _p(b_hh), _p(h0),
                                  B, T, I, H, int(reverse), _p(y), ldy, _p(h_n), _p(ws), ws.numel() * 4, _stream(dev)),
                "ww_gru_fwd")
     return h_n
 
 
-def gru_bwd(x, w_ih, w_hh, dy, dh_n, ws, reverse=False, dx=None, accumulate_dx=False, want_dh0=False):
+def gru_bwd(x, w_ih, w_hh, dy, dh_n, ws, reverse=False, dx=None, accumulate_dx=False, want_dh0=False, mode=torch.float32):
     """Backward of the gru_fwd that filled ``ws``: -> (dw_ih, dw_hh, db_ih, db_hh, dh0 | None); dx written/accumulated in place."""
     dev = _dev(w_ih, w_hh, dh_n, ws)
     _dev_rows(x, dy, dx)
@@ -431,7 +431,7 @@ def gru_bwd(x, w_ih, w_hh, dy, dh_n, ws, reverse=False, dx=None, accumulate_dx=F
     db_hh = torch.empty(3 * H, dtype=torch.float32, device=dev)
     dh0 = torch.empty((B, H), dtype=torch.float32, device=dev) if want_dh0 else None
     with torch.cuda.device(dev):
-        _check(load().ww_gru_bwd(ctx(dev), _p(x), ldx, _p(w_ih.contiguous()), _p(w_hh.contiguous()), _p(dy), ldy, _p(dh_n),
+        _check(load().ww_gru_bwd(ctx(dev), act_code(mode), _p(x), ldx, _p(w_ih.contiguous()), _p(w_hh.contiguous()), _p(dy), ldy, _p(dh_n),
                                  B, T, I, H, int(reverse), _p(ws), ws.numel() * 4, _p(dx), lddx, int(accumulate_dx),
                                  _p(dw_ih), _p(dw_hh), _p(db_ih), _p(db_hh), _p(dh0), _stream(dev)), "ww_gru_bwd")
     return dw_ih, dw_hh, db_ih, db_hh, dh0

@@ -10,7 +10,9 @@
 //     sequence -- the per-step product h W_hh^T is 96 v_mfma_f32_16x16x4_f32 per wave with no weight traffic at all;
 //   * backward mirrors it (dh carried in LDS, W_hh slice by output unit in registers, dGh W_hh per step), and the weight
 //     gradients are three large GEMMs over all (batch, time) rows afterwards, split over K with fixed-order sums.
-// fp32 throughout (exact-fp32 MFMA): this is the parity mode; hidden size 128 only.
+// The recurrence is fp32 (exact-fp32 MFMA) in both modes; `mode` selects the matrix type of the big GEMMs (input projection,
+// dX, dW_ih, dW_hh): WW_ACT_F32 = fp32 MFMA (parity mode), WW_ACT_BF16 = operands rounded to bf16, fp32 accumulation
+// (what autocast does to them).  Hidden size 128 only.
 #include "ww_internal.h"
 #include <algorithm>
 
@@ -212,11 +214,12 @@ extern "C" size_t ww_gru_workspace_bytes(int B, int T, int I, int H) {
     return ws_layout(B, T, I).total;
 }
 
-extern "C" int ww_gru_fwd(ww_ctx *ctx, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *b_ih,
+extern "C" int ww_gru_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *b_ih,
                           const float *b_hh, const float *h0, int B, int T, int I, int H, int reverse, float *y, long ldy,
                           float *h_n, void *ws, size_t ws_bytes, ww_stream_t stream) {
     int rc = check_gru("ww_gru_fwd", ctx, B, T, I, H, ws, ws_bytes);
     if (rc) return rc;
+    WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16, WW_E_INVALID, "ww_gru_fwd: unknown mode %d", mode);
     WW_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && y, WW_E_INVALID, "ww_gru_fwd: null argument");
     WW_REQUIRE(ldx >= I && ldy >= H, WW_E_INVALID, "ww_gru_fwd: row strides smaller than the feature sizes");
     const WsLayout L = ws_layout(B, T, I);
@@ -224,7 +227,7 @@ extern "C" int ww_gru_fwd(ww_ctx *ctx, const float *x, long ldx, const float *w_
     hipStream_t st = (hipStream_t)stream;
     ww_prof_scope ps_(ctx, WW_K_GRU, st);
     // Gi[(b,t)][3H] = x[(b,t)][:] W_ih^T + b_ih for all time steps at once
-    rc = ww_gemm(WW_ACT_F32, x, ldx, 1, B * T, w_ih, I, 1, 3 * GH, I, (float *)(w + L.gi), 3 * GH, b_ih, 0, 1, nullptr, st);
+    rc = ww_gemm(mode, x, ldx, 1, B * T, w_ih, I, 1, 3 * GH, I, (float *)(w + L.gi), 3 * GH, b_ih, 0, 1, nullptr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gru_fwd, dim3((B + GBT - 1) / GBT), dim3(512), 0, st, (const float *)(w + L.gi), w_hh, b_hh, h0, B, T,
                        reverse, y, ldy, (long)T * ldy, h_n, saved(w, L));
@@ -232,12 +235,13 @@ extern "C" int ww_gru_fwd(ww_ctx *ctx, const float *x, long ldx, const float *w_
     return WW_OK;
 }
 
-extern "C" int ww_gru_bwd(ww_ctx *ctx, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *dy,
+extern "C" int ww_gru_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *dy,
                           long ldy, const float *dh_n, int B, int T, int I, int H, int reverse, void *ws, size_t ws_bytes,
                           float *dx, long lddx, int accumulate_dx, float *dw_ih, float *dw_hh, float *db_ih, float *db_hh,
                           float *dh0, ww_stream_t stream) {
     int rc = check_gru("ww_gru_bwd", ctx, B, T, I, H, ws, ws_bytes);
     if (rc) return rc;
+    WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16, WW_E_INVALID, "ww_gru_bwd: unknown mode %d", mode);
     WW_REQUIRE(x && w_ih && w_hh && dw_ih && dw_hh && db_ih && db_hh, WW_E_INVALID, "ww_gru_bwd: null argument");
     WW_REQUIRE(dy || dh_n, WW_E_INVALID, "ww_gru_bwd: need dy and/or dh_n");
     const WsLayout L = ws_layout(B, T, I);
@@ -252,8 +256,8 @@ extern "C" int ww_gru_bwd(ww_ctx *ctx, const float *x, long ldx, const float *w_
     const int M = B * T;
     const int splits = M >= 4096 ? GRU_SPLITS : 1;
     // dW_hh[c][k] = sum_m dGh[m][c] h_prev[m][k]   ;   dW_ih[c][i] = sum_m dGi[m][c] x[m][i]
-    if ((rc = ww_gemm(WW_ACT_F32, dgh, 1, 3 * GH, 3 * GH, sv.hp, 1, GH, GH, M, dw_hh, GH, nullptr, 0, splits, part, st))) return rc;
-    if ((rc = ww_gemm(WW_ACT_F32, dgi, 1, 3 * GH, 3 * GH, x, 1, ldx, I, M, dw_ih, I, nullptr, 0, splits, part, st))) return rc;
+    if ((rc = ww_gemm(mode, dgh, 1, 3 * GH, 3 * GH, sv.hp, 1, GH, GH, M, dw_hh, GH, nullptr, 0, splits, part, st))) return rc;
+    if ((rc = ww_gemm(mode, dgi, 1, 3 * GH, 3 * GH, x, 1, ldx, I, M, dw_ih, I, nullptr, 0, splits, part, st))) return rc;
     float *cpart = part + (size_t)GRU_SPLITS * 3 * GH * std::max(I, GH);
     const int chunks = std::max(1, std::min(GRU_CHUNKS, M / 64));
     if ((rc = ww_colsum_rows(dgi, M, 3 * GH, db_ih, cpart, chunks, st))) return rc;
@@ -261,7 +265,7 @@ extern "C" int ww_gru_bwd(ww_ctx *ctx, const float *x, long ldx, const float *w_
     // dx[m][i] (+)= sum_c dGi[m][c] W_ih[c][i]
     if (dx) {
         WW_REQUIRE(lddx >= I, WW_E_INVALID, "ww_gru_bwd: dx row stride smaller than the input size");
-        if ((rc = ww_gemm(WW_ACT_F32, dgi, 3 * GH, 1, M, w_ih, 1, I, I, 3 * GH, dx, lddx, nullptr, accumulate_dx, 1, nullptr, st)))
+        if ((rc = ww_gemm(mode, dgi, 3 * GH, 1, M, w_ih, 1, I, I, 3 * GH, dx, lddx, nullptr, accumulate_dx, 1, nullptr, st)))
             return rc;
     }
     return WW_OK;

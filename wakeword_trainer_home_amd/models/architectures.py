@@ -336,7 +336,7 @@ def create_model(architecture: str, num_classes: int = 2, pretrained: bool = Fal
         return GRUWakeword(input_size=kwargs.get("input_size", 40), hidden_size=kwargs.get("hidden_size", 128),
                            num_layers=kwargs.get("num_layers", 2), num_classes=num_classes,
                            bidirectional=kwargs.get("bidirectional", True), dropout=kwargs.get("dropout", 0.3),
-                           dropout_seed=kwargs.get("dropout_seed", 0))
+                           dropout_seed=kwargs.get("dropout_seed", 0), mode=kwargs.get("mode", "fp32"))
     if name in _REFERENCE_ONLY:
         raise ValueError(f"Architecture '{architecture}' exists in the reference but is outside this build's "
                          f"HIP hot path (DESIGN.md 'Out of scope'). Supported: {_SUPPORTED}")

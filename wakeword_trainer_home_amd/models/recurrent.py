@@ -29,7 +29,8 @@ class _GRUStackFn(torch.autograd.Function):
             for d in range(nd):
                 w_ih, w_hh, b_ih, b_hh = params[4 * (k * nd + d):4 * (k * nd + d) + 4]
                 ws = nat.gru_workspace(B, T, cur.shape[2], H, dev)
-                h_n = nat.gru_fwd(cur, w_ih, w_hh, b_ih, b_hh, out[:, :, d * H:(d + 1) * H], ws, reverse=(d == 1))
+                h_n = nat.gru_fwd(cur, w_ih, w_hh, b_ih, b_hh, out[:, :, d * H:(d + 1) * H], ws, reverse=(d == 1),
+                                  mode=mod.mode)
                 ws_k.append(ws)
                 if k == L - 1:
                     h_last.append(h_n)
@@ -60,7 +61,7 @@ class _GRUStackFn(torch.autograd.Function):
                 dyd = dy[:, :, d * H:(d + 1) * H] if dy is not None else None
                 dhn = dh[:, d * H:(d + 1) * H].contiguous() if k == L - 1 else None
                 g = nat.gru_bwd(xin, w_ih, w_hh, dyd, dhn, ctx.workspaces[k][d], reverse=(d == 1), dx=dx,
-                                accumulate_dx=(d > 0))
+                                accumulate_dx=(d > 0), mode=mod.mode)
                 grads[4 * (k * nd + d):4 * (k * nd + d) + 4] = g[:4]
             if k > 0:
                 dy = dx
@@ -76,8 +77,11 @@ class _GRUStackFn(torch.autograd.Function):
 class NativeGRU(nn.Module):
     """Parameter container with nn.GRU's names/initialisation; ``forward(x (B,T,I)) -> h_n of the last layer (B, nd*H)``."""
 
-    def __init__(self, input_size, hidden_size=128, num_layers=2, bidirectional=True, dropout=0.0, dropout_seed=0):
+    def __init__(self, input_size, hidden_size=128, num_layers=2, bidirectional=True, dropout=0.0, dropout_seed=0,
+                 mode="fp32"):
         super().__init__()
+        self.mode = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(mode, mode)   # matrix type of the projection GEMMs
+        nat.act_code(self.mode)
         if hidden_size != 128:
             raise nat.NativeError(f"the HIP GRU kernels implement hidden_size == 128 (the reference default), got {hidden_size}")
         self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
@@ -148,7 +152,8 @@ class CRNNWakeword(nn.Module):
         from .architectures import CNNSmallWakeword
         self.front = CNNSmallWakeword(num_classes=2, dropout=0.0, act_dtype=act_dtype, features_only=True)
         self.rnn = GRUWakeword(input_size=CNNSmallWakeword.CH, hidden_size=hidden_size, num_layers=num_layers,
-                               num_classes=num_classes, bidirectional=bidirectional, dropout=dropout, dropout_seed=dropout_seed)
+                               num_classes=num_classes, bidirectional=bidirectional, dropout=dropout, dropout_seed=dropout_seed,
+                               mode="bf16" if nat.act_code(act_dtype) == nat.ACT_BF16 else "fp32")
 
     @property
     def sample_offset(self):
@@ -165,14 +170,14 @@ class CRNNWakeword(nn.Module):
 
 class GRUWakeword(nn.Module):
     def __init__(self, input_size: int = 40, hidden_size: int = 128, num_layers: int = 2, num_classes: int = 2,
-                 bidirectional: bool = True, dropout: float = 0.3, dropout_seed: int = 0):
+                 bidirectional: bool = True, dropout: float = 0.3, dropout_seed: int = 0, mode: str = "fp32"):
         super().__init__()
         self.hidden_size, self.num_layers, self.bidirectional = hidden_size, num_layers, bidirectional
         self.gru = NativeGRU(input_size, hidden_size, num_layers, bidirectional, dropout if num_layers > 1 else 0.0,
-                             dropout_seed)
+                             dropout_seed, mode=mode)
         self.gru.fc_step = 0
         out = hidden_size * 2 if bidirectional else hidden_size
-        self.fc = nn.Sequential(_HiddenDropout(dropout, self.gru), MFMALinear(out, num_classes))
+        self.fc = nn.Sequential(_HiddenDropout(dropout, self.gru), MFMALinear(out, num_classes, mode=mode))
 
     @property
     def sample_offset(self):
