@@ -17,7 +17,10 @@ from wakeword_trainer_home_amd.models import create_model
 from wakeword_trainer_home_amd.training import Trainer
 
 dev = "cuda:0"
-for arch, B, act in (("crnn", 512, "bf16"), ("crnn", 4096, "bf16"), ("gru", 4096, "fp32")):
+CONFIGS = (("crnn", 512, "bf16"), ("crnn", 4096, "bf16"), ("gru", 4096, "fp32"))
+if len(sys.argv) > 1:                         # e.g.  bench_crnn.py crnn 4096 bf16
+    CONFIGS = ((sys.argv[1], int(sys.argv[2]), sys.argv[3]),)
+for arch, B, act in CONFIGS:
     cfg = get_preset("cnn_small_logmel40")
     cfg.training.batch_size = B
     torch.manual_seed(0)
