@@ -49,6 +49,13 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
     __syncthreads();
     for (int it = 0; it < T; ++it) {
         const int t = reverse ? T - 1 - it : it, cur = it & 1;
+        float gir[4], giz[4], gin[4];          // this step's projections: in flight under the MFMAs below
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int b = min(b0 + 4 * kq + reg, B - 1);
+            const float *g3 = gi + ((size_t)b * T + t) * (3 * GH);
+            gir[reg] = g3[u]; giz[reg] = g3[GH + u]; gin[reg] = g3[2 * GH + u];
+        }
         floatx4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int kk = 0; kk < 32; ++kk) {
@@ -61,11 +68,10 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
             const int row = 4 * kq + reg, b = b0 + row;
             if (b < B) {
                 const size_t m = (size_t)b * T + t;
-                const float *g3 = gi + m * (3 * GH);
                 const float hnv = acc[2][reg] + bhn;
-                const float r = sigmoidf_(g3[u] + acc[0][reg] + bhr);
-                const float z = sigmoidf_(g3[GH + u] + acc[1][reg] + bhz);
-                const float n = tanhf(g3[2 * GH + u] + r * hnv);
+                const float r = sigmoidf_(gir[reg] + acc[0][reg] + bhr);
+                const float z = sigmoidf_(giz[reg] + acc[1][reg] + bhz);
+                const float n = tanhf(gin[reg] + r * hnv);
                 const float hp = hs[cur][row][u];
                 const float h = (1.0f - z) * n + z * hp;
                 hs[cur ^ 1][row][u] = h;
@@ -99,6 +105,17 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
         dhs[row][c] = (dhn && b0 + row < B) ? dhn[(size_t)(b0 + row) * GH + c] : 0.f;
     }
     __syncthreads();
+    float pr[4], pz[4], pn[4], phn[4], php[4], pdy[4];      // saved values of the step about to be processed
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 512 * q, row = e >> 7, c = e & 127, b = min(b0 + row, B - 1);
+            const size_t i = ((size_t)b * T + t) * GH + c;
+            pr[q] = sv.r[i]; pz[q] = sv.z[i]; pn[q] = sv.n[i]; phn[q] = sv.hn[i]; php[q] = sv.hp[i];
+            pdy[q] = dy ? dy[(size_t)b * bsy + (size_t)t * ldy + c] : 0.f;
+        }
+    };
+    prefetch(reverse ? 0 : T - 1);
     for (int it = 0; it < T; ++it) {
         const int t = reverse ? it : T - 1 - it;        // the forward pass's time order, backwards
 #pragma unroll
@@ -106,10 +123,9 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
             const int e = tid + 512 * q, row = e >> 7, c = e & 127, b = b0 + row;
             float dar = 0.f, daz = 0.f, dan = 0.f, dhn_ = 0.f, keep = 0.f;
             if (b < B) {
-                const size_t m = (size_t)b * T + t, i = m * GH + c;
-                float dh = dhs[row][c];
-                if (dy) dh += dy[(size_t)b * bsy + (size_t)t * ldy + c];
-                const float r = sv.r[i], z = sv.z[i], n = sv.n[i], hnv = sv.hn[i], hp = sv.hp[i];
+                const size_t m = (size_t)b * T + t;
+                const float dh = dhs[row][c] + pdy[q];
+                const float r = pr[q], z = pz[q], n = pn[q], hnv = phn[q], hp = php[q];
                 const float dn = dh * (1.0f - z), dz = dh * (hp - n);
                 dan = dn * (1.0f - n * n);
                 dar = dan * hnv * r * (1.0f - r);
@@ -125,6 +141,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
             dhs[row][c] = keep;                          // read and written by this thread only
         }
         __syncthreads();
+        if (it + 1 < T) prefetch(reverse ? it + 1 : T - 2 - it);      // in flight under the MFMAs
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int cc = 0; cc < 96; ++cc)
