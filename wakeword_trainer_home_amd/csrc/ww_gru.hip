@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
 __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh, const float *__restrict__ dy, long ldy,
                                                  long bsy, const float *__restrict__ dhn, int B, int T, int reverse,
                                                  GruSaved sv, float *__restrict__ dgi, float *__restrict__ dgh,
-                                                 float *__restrict__ dh0) {
+                                                 float *__restrict__ dh0, float *__restrict__ bias_part) {
     __shared__ float dhs[GBT][HS_LD];
     __shared__ float dg[GBT][DG_LD];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
         }
     };
     prefetch(reverse ? 0 : T - 1);
+    float sar = 0.f, saz = 0.f, san = 0.f, shn = 0.f;      // bias-gradient partials of column c = tid & 127 (rows: 4 per thread)
     for (int it = 0; it < T; ++it) {
         const int t = reverse ? it : T - 1 - it;        // the forward pass's time order, backwards
 #pragma unroll
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
                 o[c] = dar; o[GH + c] = daz; o[2 * GH + c] = dan;
                 float *p = dgh + m * (3 * GH);
                 p[c] = dar; p[GH + c] = daz; p[2 * GH + c] = dhn_;
+                sar += dar; saz += daz; san += dan; shn += dhn_;
             }
             dg[row][c] = dar; dg[row][GH + c] = daz; dg[row][2 * GH + c] = dhn_;
             dhs[row][c] = keep;                          // read and written by this thread only
@@ -155,6 +157,22 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
             const int row = e >> 7, c = e & 127;
             if (b0 + row < B) dh0[(size_t)(b0 + row) * GH + c] = dhs[row][c];
         }
+    // bias gradients: this block's column sums over its rows and all time steps -> bias_part[block][db_ih(384) | db_hh(384)]
+    __syncthreads();
+    {
+        const int c = tid & 127, part = tid >> 7;
+        dg[part][c] = sar; dg[part][GH + c] = saz; dg[part][2 * GH + c] = san; dg[4 + part][c] = shn;
+        __syncthreads();
+        if (tid < 128) {
+            const float ar = dg[0][c] + dg[1][c] + dg[2][c] + dg[3][c];
+            const float az = dg[0][GH + c] + dg[1][GH + c] + dg[2][GH + c] + dg[3][GH + c];
+            const float an = dg[0][2 * GH + c] + dg[1][2 * GH + c] + dg[2][2 * GH + c] + dg[3][2 * GH + c];
+            const float hn = dg[4][c] + dg[5][c] + dg[6][c] + dg[7][c];
+            float *o = bias_part + (size_t)blockIdx.x * (6 * GH);
+            o[c] = ar; o[GH + c] = az; o[2 * GH + c] = an;
+            o[3 * GH + c] = ar; o[4 * GH + c] = az; o[5 * GH + c] = hn;
+        }
+    }
 }
 
 // Philox dropout on a (B,T,C) tensor with row-strided rows: out = keep ? x * scale : 0.  Counter field (24 bits):
@@ -182,7 +200,7 @@ __global__ __launch_bounds__(256) void k_dropout_bt(const float *__restrict__ x,
 }
 
 struct WsLayout { size_t gi, dgh, r, z, n, hn, hp, part, total; };
-constexpr int GRU_SPLITS = 32, GRU_CHUNKS = 64;
+constexpr int GRU_SPLITS = 32;
 WsLayout ws_layout(long B, long T, int I) {
     WsLayout L;
     size_t o = 0;
@@ -191,7 +209,7 @@ WsLayout ws_layout(long B, long T, int I) {
     L.gi = take(M * 3 * GH);        // projections, overwritten by dGi in the backward pass
     L.dgh = take(M * 3 * GH);
     L.r = take(M * GH); L.z = take(M * GH); L.n = take(M * GH); L.hn = take(M * GH); L.hp = take(M * GH);
-    L.part = take((size_t)GRU_SPLITS * 3 * GH * std::max(I, GH) + (size_t)GRU_CHUNKS * 3 * GH);
+    L.part = take((size_t)GRU_SPLITS * 3 * GH * std::max(I, GH) + (size_t)((B + GBT - 1) / GBT) * 6 * GH);
     L.total = o;
     return L;
 }
@@ -267,18 +285,18 @@ extern "C" int ww_gru_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
     ww_prof_scope ps_(ctx, WW_K_GRU, st);
     float *dgi = (float *)(w + L.gi), *dgh = (float *)(w + L.dgh), *part = (float *)(w + L.part);
     const GruSaved sv = saved(w, L);
-    hipLaunchKernelGGL(k_gru_bwd, dim3((B + GBT - 1) / GBT), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse,
-                       sv, dgi, dgh, dh0);
+    float *bpart = part + (size_t)GRU_SPLITS * 3 * GH * std::max(I, GH);
+    const int nblk = (B + GBT - 1) / GBT;
+    hipLaunchKernelGGL(k_gru_bwd, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi, dgh,
+                       dh0, bpart);
     WW_LAUNCH_CHECK();
     const int M = B * T;
     const int splits = M >= 4096 ? GRU_SPLITS : 1;
     // dW_hh[c][k] = sum_m dGh[m][c] h_prev[m][k]   ;   dW_ih[c][i] = sum_m dGi[m][c] x[m][i]
     if ((rc = ww_gemm(mode, dgh, 1, 3 * GH, 3 * GH, sv.hp, 1, GH, GH, M, dw_hh, GH, nullptr, 0, splits, part, st))) return rc;
     if ((rc = ww_gemm(mode, dgi, 1, 3 * GH, 3 * GH, x, 1, ldx, I, M, dw_ih, I, nullptr, 0, splits, part, st))) return rc;
-    float *cpart = part + (size_t)GRU_SPLITS * 3 * GH * std::max(I, GH);
-    const int chunks = std::max(1, std::min(GRU_CHUNKS, M / 64));
-    if ((rc = ww_colsum_rows(dgi, M, 3 * GH, db_ih, cpart, chunks, st))) return rc;
-    if ((rc = ww_colsum_rows(dgh, M, 3 * GH, db_hh, cpart, chunks, st))) return rc;
+    // db_ih | db_hh: fixed-order sum of the per-block partials the recurrent kernel left (one launch for both: 768 columns)
+    if ((rc = ww_colsum_pair(bpart, nblk, 3 * GH, db_ih, db_hh, st))) return rc;
     // dx[m][i] (+)= sum_c dGi[m][c] W_ih[c][i]
     if (dx) {
         WW_REQUIRE(lddx >= I, WW_E_INVALID, "ww_gru_bwd: dx row stride smaller than the input size");

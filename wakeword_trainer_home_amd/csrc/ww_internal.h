@@ -112,6 +112,7 @@ int ww_launch_bwd_finalize(const float *stat, int rows, double count, const floa
 int ww_gemm(int mode, const float *A, long a_srow, long a_sk, int a_rows, const float *B, long b_srow, long b_sk, int b_rows,
             int K, float *C, long ldc, const float *bias, int accumulate, int splits, float *part, hipStream_t st);
 int ww_colsum_rows(const float *a, long rows, int cols, float *out, float *part, int chunks, hipStream_t st);
+int ww_colsum_pair(const float *a, int rows, int cols, float *out0, float *out1, hipStream_t st);
 int ww_occupancy_grid(const void *fn, int block, size_t smem, long want, int cap);
 
 // ---- Philox4x32-10 (host + device), must match oracle/philox.py bit for bit

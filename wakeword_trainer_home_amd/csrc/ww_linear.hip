@@ -317,6 +317,30 @@ int ww_gemm(int mode, const float *A, long a_srow, long a_sk, int a_rows, const 
     if (!kca && kcb) return launch_gemm<false, true, true>(mode, a, b, K, C, ldc, e, st, splits, part);
     return launch_gemm<false, false, true>(mode, a, b, K, C, ldc, e, st, splits, part);
 }
+// a: rows x (2*cols) row-major; out0 = column sums of the left half, out1 of the right half (one launch)
+__global__ __launch_bounds__(1024) void k_colsum_pair(const float *__restrict__ a, int rows, int cols, float *__restrict__ out0,
+                                                      float *__restrict__ out1) {
+    __shared__ double sh[16][64];
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
+    double acc = 0.0;
+    if (col < 2 * cols) {
+#pragma unroll 8
+        for (int r = part; r < rows; r += 16) acc += (double)a[(size_t)r * (2 * cols) + col];
+    }
+    sh[part][c] = acc;
+    __syncthreads();
+    if (part == 0 && col < 2 * cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += sh[p][c];
+        if (col < cols) out0[col] = (float)t; else out1[col - cols] = (float)t;
+    }
+}
+int ww_colsum_pair(const float *a, int rows, int cols, float *out0, float *out1, hipStream_t st) {
+    hipLaunchKernelGGL(k_colsum_pair, dim3((2 * cols + 63) / 64), dim3(1024), 0, st, a, rows, cols, out0, out1);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
 // out[j] = sum_i a[i][j] for tall matrices: chunked partial sums (part: chunks x cols floats), then a fixed-order sum
 int ww_colsum_rows(const float *a, long rows, int cols, float *out, float *part, int chunks, hipStream_t st) {
     const long rpc = (rows + chunks - 1) / chunks;
