@@ -49,18 +49,18 @@ __device__ __forceinline__ bool drop_keep(const Epilogue &e, long row, int col) 
     return (uint64_t)rv >= e.drop_thresh;
 }
 
-// ---- operand staging.  A tile is 64 rows x 32 k.  It is kept in LDS in the operand's own memory orientation, so both the
-// global reads (float4) and the LDS writes are contiguous:  KC (k contiguous in memory): [row][k];  otherwise: [k][row].
-// Each thread moves 2 float4 per tile; the next tile's float4s are fetched before the MFMAs of the current one.
-template <bool KC>
-__device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k0, int K, bool vec_ok, float4 (&v)[2]) {
+// ---- operand staging.  A tile is ROWS x 32 k (ROWS = 64 or 128).  It is kept in LDS in the operand's own memory orientation,
+// so both the global reads (float4) and the LDS writes are contiguous:  KC (k contiguous in memory): [row][k];  otherwise:
+// [k][row].  Each thread moves ROWS/32 float4 per tile; the next tile's float4s are fetched before the MFMAs of the current one.
+template <bool KC, int ROWS>
+__device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k0, int K, bool vec_ok, float4 (&v)[ROWS / 32]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = tid + 256 * j;                 // float4 index within the tile (512 per tile)
+    for (int j = 0; j < ROWS / 32; ++j) {
+        const int q = tid + 256 * j;                 // float4 index within the tile (ROWS * 8 per tile)
         long row; int k;
-        if (KC) { row = r0 + (q >> 3); k = k0 + 4 * (q & 7); }         // 8 float4 per row of 32 k
-        else { k = k0 + (q >> 4); row = r0 + 4 * (q & 15); }           // 16 float4 per k-line of 64 rows
+        if (KC) { row = r0 + (q >> 3); k = k0 + 4 * (q & 7); }                       // 8 float4 per row of 32 k
+        else { k = k0 + q / (ROWS / 4); row = r0 + 4 * (q % (ROWS / 4)); }           // ROWS/4 float4 per k-line
         const long lim_c = KC ? K : op.rows, c = KC ? k : row;         // the contiguous coordinate and its bound
         const bool other_ok = KC ? row < op.rows : k < K;
         const float *src = op.p + row * op.s_row + (long)k * op.s_k;
@@ -75,15 +75,16 @@ __device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k
         }
     }
 }
-constexpr int LDF_KC = 36, LDF_T = 68;   // fp32 strides: [row][k] and [k][row]
-constexpr int LDH_KC = 40, LDH_T = 72;   // bf16 strides
-template <bool BF16, bool KC>
-__device__ __forceinline__ void stage_tile(void *lds, const float4 (&v)[2]) {
+constexpr int LDF_KC = 36;               // fp32 [row][k] stride;  [k][row] strides are ROWS + 4 (fp32) / ROWS + 8 (bf16)
+constexpr int LDH_KC = 40;               // bf16 [row][k] stride
+template <bool BF16, bool KC, int ROWS>
+__device__ __forceinline__ void stage_tile(void *lds, const float4 (&v)[ROWS / 32]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < ROWS / 32; ++j) {
         const int q = tid + 256 * j;
-        const int off = KC ? (q >> 3) * (BF16 ? LDH_KC : LDF_KC) + 4 * (q & 7) : (q >> 4) * (BF16 ? LDH_T : LDF_T) + 4 * (q & 15);
+        const int off = KC ? (q >> 3) * (BF16 ? LDH_KC : LDF_KC) + 4 * (q & 7)
+                           : (q / (ROWS / 4)) * (BF16 ? ROWS + 8 : ROWS + 4) + 4 * (q % (ROWS / 4));
         if (BF16) {
             typedef Act<ww_bf16> A16;
             *reinterpret_cast<uint2 *>(reinterpret_cast<ww_bf16 *>(lds) + off) =
@@ -94,57 +95,72 @@ __device__ __forceinline__ void stage_tile(void *lds, const float4 (&v)[2]) {
     }
 }
 typedef short short4v __attribute__((ext_vector_type(4)));
-// bf16 MFMA operand (rows row0 + lane&31, k = 16t + 8*(lane>>5) .. +7) from a [k][row] tile: transposing LDS reads
-__device__ __forceinline__ bf16x8 tr_frag(const ww_bf16 *tile, int k0, int row0, int lane) {
+// bf16 MFMA operand (rows row0 + lane&31, k = k0 + 8*(lane>>5) .. +7) from a [k][row] tile of stride ld: transposing LDS reads
+__device__ __forceinline__ bf16x8 tr_frag(const ww_bf16 *tile, int ld, int k0, int row0, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-    const ww_bf16 *base = tile + (k0 + 8 * (g >> 1) + q) * LDH_T + row0 + 16 * (g & 1) + 4 * pp;
+    const ww_bf16 *base = tile + (k0 + 8 * (g >> 1) + q) * ld + row0 + 16 * (g & 1) + 4 * pp;
     typedef short4v __attribute__((address_space(3))) * lds_p;
     const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
-    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * LDH_T));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * ld));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-// grid: x = column tiles, y = row tiles, z = K splits (partial products go to C + z*split_stride)
-template <bool BF16, bool KCA, bool KCB, bool EPI>
+// Block tile (64*TM) x 64: 4 wavefronts as 2 x 2, each TM 32x32 MFMA tiles stacked along the rows (TM = 2 for tall
+// problems: twice the MFMA work per staged B byte).  grid: x = column tiles, y = row tiles, z = K splits (partial
+// products go to C + z*split_stride)
+template <bool BF16, bool KCA, bool KCB, bool EPI, int TM>
 __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int K, int k_per_split, float *__restrict__ C,
                                               long ldc, long split_stride, int vecA, int vecB, Epilogue e) {
-    __shared__ __align__(16) unsigned char lds[2 * 64 * 40 * 4];      // two tiles, the larger of all layouts (fp32 [k][row]: 32*68*4)
-    void *As = lds, *Bs = lds + 64 * 40 * 4;
+    constexpr int RA = 64 * TM;
+    constexpr int A_BYTES = BF16 ? (KCA ? RA * LDH_KC : GK * (RA + 8)) * 2 : (KCA ? RA * LDF_KC : GK * (RA + 4)) * 4;
+    constexpr int B_BYTES = BF16 ? (KCB ? 64 * LDH_KC : GK * (64 + 8)) * 2 : (KCB ? 64 * LDF_KC : GK * (64 + 4)) * 4;
+    __shared__ __align__(16) unsigned char lds[A_BYTES + B_BYTES];
+    void *As = lds, *Bs = lds + A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5, rh = wv >> 1, nh = wv & 1;
-    const long m0 = (long)blockIdx.y * GT, n0 = (long)blockIdx.x * GT;
+    const long m0 = (long)blockIdx.y * RA, n0 = (long)blockIdx.x * GT;
     const int kb = blockIdx.z * k_per_split, ke = min(K, kb + k_per_split);
-    floatx16 acc = {0.f};
-    float4 va[2], vb[2];
+    floatx16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) acc[tm] = floatx16{0.f};
+    float4 va[RA / 32], vb[2];
     if (kb < ke) {
-        fetch_tile<KCA>(A, m0, kb, ke, vecA, va);
-        fetch_tile<KCB>(B, n0, kb, ke, vecB, vb);
+        fetch_tile<KCA, RA>(A, m0, kb, ke, vecA, va);
+        fetch_tile<KCB, 64>(B, n0, kb, ke, vecB, vb);
     }
     for (int k0 = kb; k0 < ke; k0 += GK) {
         __syncthreads();
-        stage_tile<BF16, KCA>(As, va);
-        stage_tile<BF16, KCB>(Bs, vb);
+        stage_tile<BF16, KCA, RA>(As, va);
+        stage_tile<BF16, KCB, 64>(Bs, vb);
         __syncthreads();
         if (k0 + GK < ke) {                        // next tile in flight under the MFMAs
-            fetch_tile<KCA>(A, m0, k0 + GK, ke, vecA, va);
-            fetch_tile<KCB>(B, n0, k0 + GK, ke, vecB, vb);
+            fetch_tile<KCA, RA>(A, m0, k0 + GK, ke, vecA, va);
+            fetch_tile<KCB, 64>(B, n0, k0 + GK, ke, vecB, vb);
         }
         if (BF16) {
             const ww_bf16 *a = reinterpret_cast<const ww_bf16 *>(As), *b = reinterpret_cast<const ww_bf16 *>(Bs);
 #pragma unroll
             for (int t = 0; t < GK / 16; ++t) {
-                const bf16x8 fa = KCA ? *reinterpret_cast<const bf16x8 *>(a + (32 * rh + r) * LDH_KC + 16 * t + 8 * h)
-                                      : tr_frag(a, 16 * t, 32 * rh, lane);
                 const bf16x8 fb = KCB ? *reinterpret_cast<const bf16x8 *>(b + (32 * nh + r) * LDH_KC + 16 * t + 8 * h)
-                                      : tr_frag(b, 16 * t, 32 * nh, lane);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+                                      : tr_frag(b, 64 + 8, 16 * t, 32 * nh, lane);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int row0 = 32 * TM * rh + 32 * tm;
+                    const bf16x8 fa = KCA ? *reinterpret_cast<const bf16x8 *>(a + (row0 + r) * LDH_KC + 16 * t + 8 * h)
+                                          : tr_frag(a, RA + 8, 16 * t, row0, lane);
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tm], 0, 0, 0);
+                }
             }
         } else {
             const float *a = reinterpret_cast<const float *>(As), *b = reinterpret_cast<const float *>(Bs);
 #pragma unroll
             for (int t = 0; t < GK / 2; ++t) {
-                const float fa = KCA ? a[(32 * rh + r) * LDF_KC + 2 * t + h] : a[(2 * t + h) * LDF_T + 32 * rh + r];
-                const float fb = KCB ? b[(32 * nh + r) * LDF_KC + 2 * t + h] : b[(2 * t + h) * LDF_T + 32 * nh + r];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+                const float fb = KCB ? b[(32 * nh + r) * LDF_KC + 2 * t + h] : b[(2 * t + h) * (64 + 4) + 32 * nh + r];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int row0 = 32 * TM * rh + 32 * tm;
+                    const float fa = KCA ? a[(row0 + r) * LDF_KC + 2 * t + h] : a[(2 * t + h) * (RA + 4) + row0 + r];
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[tm], 0, 0, 0);
+                }
             }
         }
     }
@@ -153,19 +169,21 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
     C += (long)blockIdx.z * split_stride;
     const float bias = (EPI && e.bias) ? e.bias[col] : 0.f;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const long row = m0 + 32 * rh + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (row >= A.rows) continue;
-        float v = acc[reg];
-        if (EPI) {
-            v += bias;
-            if (e.pre) e.pre[row * ldc + col] = v;
-            if (e.act == WW_LIN_HARDSWISH) v = hardswish(v);
-            if (e.use_dropout) v = drop_keep(e, row, (int)col) ? v * e.drop_scale : 0.f;
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const long row = m0 + 32 * TM * rh + 32 * tm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (row >= A.rows) continue;
+            float v = acc[tm][reg];
+            if (EPI) {
+                v += bias;
+                if (e.pre) e.pre[row * ldc + col] = v;
+                if (e.act == WW_LIN_HARDSWISH) v = hardswish(v);
+                if (e.use_dropout) v = drop_keep(e, row, (int)col) ? v * e.drop_scale : 0.f;
+            }
+            if (e.accumulate && gridDim.z == 1) v += C[row * ldc + col];
+            C[row * ldc + col] = v;
         }
-        if (e.accumulate && gridDim.z == 1) v += C[row * ldc + col];
-        C[row * ldc + col] = v;
-    }
 }
 
 // C[i] = sum_z P[z][i] in fixed order (split-K partial products)
@@ -279,13 +297,20 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
     int kps = K;
     if (splits > 1) kps = ((K + splits - 1) / splits + GK - 1) / GK * GK;
     const int nz = (K + kps - 1) / kps;
-    dim3 grid((B.rows + GT - 1) / GT, (A.rows + GT - 1) / GT, nz);
+    // 128-row blocks only when there are plenty of them (measured: at 2048 rows they halve the block count and lose 30 %;
+    // at 16384 rows they gain 8 %)
+    const bool tall = A.rows >= 8192;
+    const int RA = tall ? 128 : 64;
+    dim3 grid((B.rows + GT - 1) / GT, (A.rows + RA - 1) / RA, nz);
     float *dst = nz > 1 ? part : C;
     const long sstride = (long)A.rows * ldc;
-    if (mode == WW_ACT_BF16)
-        hipLaunchKernelGGL((k_gemm<true, KCA, KCB, EPI>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
-    else
-        hipLaunchKernelGGL((k_gemm<false, KCA, KCB, EPI>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
+    if (mode == WW_ACT_BF16) {
+        if (tall) hipLaunchKernelGGL((k_gemm<true, KCA, KCB, EPI, 2>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
+        else hipLaunchKernelGGL((k_gemm<true, KCA, KCB, EPI, 1>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
+    } else {
+        if (tall) hipLaunchKernelGGL((k_gemm<false, KCA, KCB, EPI, 2>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
+        else hipLaunchKernelGGL((k_gemm<false, KCA, KCB, EPI, 1>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
+    }
     WW_LAUNCH_CHECK();
     if (nz > 1) {
         const long n = sstride;
