@@ -13,7 +13,14 @@ from .heads import MFMALinear
 
 
 class _GRUStackFn(torch.autograd.Function):
-    """All layers and directions of the stack; parameters arrive flat in nn.GRU's ``_flat_weights`` order."""
+    """All layers and directions of the stack; parameters arrive flat in nn.GRU's ``_flat_weights`` order.  The two
+    directions of a layer are independent: the reverse one runs on a second HIP stream beside the forward one (a
+    per-direction recurrence occupies B/16 workgroups -- at the per-GPU batches of data-parallel training that is a
+    fraction of the 256 CUs), joined before the next layer."""
+
+    @staticmethod
+    def _par(mod, dev):
+        return mod.num_directions == 2 and mod.overlap_directions
 
     @staticmethod
     def forward(ctx, x, mod, step, *params):
@@ -21,20 +28,33 @@ class _GRUStackFn(torch.autograd.Function):
         B, T, _ = x.shape
         dev = x.device
         p = mod.dropout if (mod.training and L > 1) else 0.0
+        main = torch.cuda.current_stream(dev)
+        side = mod.side_stream(dev) if _GRUStackFn._par(mod, dev) else None
         inputs, workspaces, h_last = [x], [], []
         cur = x
         for k in range(L):
             out = torch.empty((B, T, nd * H), dtype=torch.float32, device=dev)
-            ws_k = []
-            for d in range(nd):
+            ws_k, h_k = [None] * nd, [None] * nd
+
+            def run(d):
                 w_ih, w_hh, b_ih, b_hh = params[4 * (k * nd + d):4 * (k * nd + d) + 4]
-                ws = nat.gru_workspace(B, T, cur.shape[2], H, dev)
-                h_n = nat.gru_fwd(cur, w_ih, w_hh, b_ih, b_hh, out[:, :, d * H:(d + 1) * H], ws, reverse=(d == 1),
-                                  mode=mod.mode)
-                ws_k.append(ws)
-                if k == L - 1:
-                    h_last.append(h_n)
+                ws_k[d] = nat.gru_workspace(B, T, cur.shape[2], H, dev)
+                h_k[d] = nat.gru_fwd(cur, w_ih, w_hh, b_ih, b_hh, out[:, :, d * H:(d + 1) * H], ws_k[d], reverse=(d == 1),
+                                     mode=mod.mode)
+            if side is not None:
+                side.wait_stream(main)                       # `cur` and `out` are ready / allocated
+                with torch.cuda.stream(side):
+                    run(1)
+                run(0)
+                main.wait_stream(side)
+                ws_k[1].record_stream(main)
+                h_k[1].record_stream(main)
+            else:
+                for d in range(nd):
+                    run(d)
             workspaces.append(ws_k)
+            if k == L - 1:
+                h_last = h_k
             if p > 0 and k + 1 < L:
                 out = nat.dropout_bt(out, p, seed=mod.dropout_seed, step=step, sample_offset=mod.sample_offset, stream_id=1 + k)
             cur = out
@@ -51,25 +71,41 @@ class _GRUStackFn(torch.autograd.Function):
         L, nd, H = mod.num_layers, mod.num_directions, mod.hidden_size
         grads = [None] * len(params)
         dh = dh.contiguous()
+        dev = dh.device
+        main = torch.cuda.current_stream(dev)
+        side = mod.side_stream(dev) if _GRUStackFn._par(mod, dev) else None
         dy = None                                  # gradient of layer k's (dropped-out) output, (B,T,nd*H)
         for k in reversed(range(L)):
             xin = ctx.inputs[k]
             need_dx = k > 0 or ctx.needs_input_grad[0]
             dx = torch.empty_like(xin) if need_dx else None
-            for d in range(nd):
+            dhn = [dh[:, d * H:(d + 1) * H].contiguous() if k == L - 1 else None for d in range(nd)]
+
+            def run(d, dx_d, acc):
                 w_ih, w_hh = params[4 * (k * nd + d)], params[4 * (k * nd + d) + 1]
                 dyd = dy[:, :, d * H:(d + 1) * H] if dy is not None else None
-                dhn = dh[:, d * H:(d + 1) * H].contiguous() if k == L - 1 else None
-                g = nat.gru_bwd(xin, w_ih, w_hh, dyd, dhn, ctx.workspaces[k][d], reverse=(d == 1), dx=dx,
-                                accumulate_dx=(d > 0), mode=mod.mode)
+                g = nat.gru_bwd(xin, w_ih, w_hh, dyd, dhn[d], ctx.workspaces[k][d], reverse=(d == 1), dx=dx_d,
+                                accumulate_dx=acc, mode=mod.mode)
                 grads[4 * (k * nd + d):4 * (k * nd + d) + 4] = g[:4]
-            if k > 0:
-                dy = dx
-                if ctx.p > 0:                      # backward of the inter-layer dropout: the same mask on the gradient
-                    dy = nat.dropout_bt(dy, ctx.p, seed=mod.dropout_seed, step=ctx.step, sample_offset=mod.sample_offset,
-                                        stream_id=k)
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dx1 = torch.empty_like(xin) if need_dx else None       # its own dx: the two run concurrently
+                    run(1, dx1, False)
+                run(0, dx, False)
+                main.wait_stream(side)
+                for t in grads[4 * (k * nd + 1):4 * (k * nd + 1) + 4]:
+                    t.record_stream(main)
+                if need_dx:
+                    dx1.record_stream(main)
+                    dx.add_(dx1)
             else:
-                dy = dx
+                for d in range(nd):
+                    run(d, dx, d > 0)
+            dy = dx
+            if k > 0 and ctx.p > 0:                # backward of the inter-layer dropout: the same mask on the gradient
+                dy = nat.dropout_bt(dy, ctx.p, seed=mod.dropout_seed, step=ctx.step, sample_offset=mod.sample_offset,
+                                    stream_id=k)
         ctx.workspaces = ctx.inputs = None
         return (dy if ctx.needs_input_grad[0] else None, None, None) + tuple(grads)
 
@@ -88,6 +124,8 @@ class NativeGRU(nn.Module):
         self.num_directions = 2 if bidirectional else 1
         self.dropout, self.dropout_seed = float(dropout), dropout_seed
         self.dropout_step, self.sample_offset = 0, 0
+        self.overlap_directions = True       # reverse direction on a second HIP stream
+        self._side = {}
         k = 1.0 / math.sqrt(hidden_size)
         self._names = []
         for layer in range(num_layers):
@@ -99,6 +137,11 @@ class NativeGRU(nn.Module):
                                     (f"bias_ih_l{layer}{sfx}", (3 * hidden_size,)), (f"bias_hh_l{layer}{sfx}", (3 * hidden_size,))):
                     self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))     # nn.GRU.reset_parameters
                     self._names.append(name)
+
+    def side_stream(self, dev):
+        if dev not in self._side:
+            self._side[dev] = torch.cuda.Stream(device=dev)
+        return self._side[dev]
 
     def forward(self, x):
         if not x.is_cuda:
