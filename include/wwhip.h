@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 3
+#define WW_ABI_VERSION 4
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */

@@ -13,7 +13,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ACT_F32, ACT_BF16 = 0, 1
 LOSS_CE, LOSS_FOCAL = 0, 1
 WAVE_F32, WAVE_I16 = 0, 1
