@@ -19,7 +19,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int GT = 64;      // block tile (rows and columns)
-constexpr int GK = 32;      // K per LDS stage
+constexpr int GK = 32;      // K per LDS stage, fp32 mode
+constexpr int GKH = 128;    // K per LDS stage, bf16 mode
 
 struct GemmOperand {
     const float *p;
@@ -52,14 +53,15 @@ __device__ __forceinline__ bool drop_keep(const Epilogue &e, long row, int col) 
 // ---- operand staging.  A tile is ROWS x 32 k (ROWS = 64 or 128).  It is kept in LDS in the operand's own memory orientation,
 // so both the global reads (float4) and the LDS writes are contiguous:  KC (k contiguous in memory): [row][k];  otherwise:
 // [k][row].  Each thread moves ROWS/32 float4 per tile; the next tile's float4s are fetched before the MFMAs of the current one.
-template <bool KC, int ROWS>
-__device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k0, int K, bool vec_ok, float4 (&v)[ROWS / 32]) {
+template <bool KC, int ROWS, int KT>
+__device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k0, int K, bool vec_ok,
+                                           float4 (&v)[ROWS * KT / 1024]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < ROWS / 32; ++j) {
-        const int q = tid + 256 * j;                 // float4 index within the tile (ROWS * 8 per tile)
+    for (int j = 0; j < ROWS * KT / 1024; ++j) {
+        const int q = tid + 256 * j;                 // float4 index within the tile (ROWS * KT / 4 per tile)
         long row; int k;
-        if (KC) { row = r0 + (q >> 3); k = k0 + 4 * (q & 7); }                       // 8 float4 per row of 32 k
+        if (KC) { row = r0 + q / (KT / 4); k = k0 + 4 * (q % (KT / 4)); }            // KT/4 float4 per row
         else { k = k0 + q / (ROWS / 4); row = r0 + 4 * (q % (ROWS / 4)); }           // ROWS/4 float4 per k-line
         const long lim_c = KC ? K : op.rows, c = KC ? k : row;         // the contiguous coordinate and its bound
         const bool other_ok = KC ? row < op.rows : k < K;
@@ -75,15 +77,14 @@ __device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k
         }
     }
 }
-constexpr int LDF_KC = 36;               // fp32 [row][k] stride;  [k][row] strides are ROWS + 4 (fp32) / ROWS + 8 (bf16)
-constexpr int LDH_KC = 40;               // bf16 [row][k] stride
-template <bool BF16, bool KC, int ROWS>
-__device__ __forceinline__ void stage_tile(void *lds, const float4 (&v)[ROWS / 32]) {
+// LDS strides: [row][k]: KT + 4 (fp32) / KT + 8 (bf16);  [k][row]: ROWS + 4 (fp32) / ROWS + 8 (bf16)
+template <bool BF16, bool KC, int ROWS, int KT>
+__device__ __forceinline__ void stage_tile(void *lds, const float4 (&v)[ROWS * KT / 1024]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < ROWS / 32; ++j) {
+    for (int j = 0; j < ROWS * KT / 1024; ++j) {
         const int q = tid + 256 * j;
-        const int off = KC ? (q >> 3) * (BF16 ? LDH_KC : LDF_KC) + 4 * (q & 7)
+        const int off = KC ? (q / (KT / 4)) * (BF16 ? KT + 8 : KT + 4) + 4 * (q % (KT / 4))
                            : (q / (ROWS / 4)) * (BF16 ? ROWS + 8 : ROWS + 4) + 4 * (q % (ROWS / 4));
         if (BF16) {
             typedef Act<ww_bf16> A16;
@@ -111,8 +112,12 @@ template <bool BF16, bool KCA, bool KCB, bool EPI, int TM>
 __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int K, int k_per_split, float *__restrict__ C,
                                               long ldc, long split_stride, int vecA, int vecB, Epilogue e) {
     constexpr int RA = 64 * TM;
-    constexpr int A_BYTES = BF16 ? (KCA ? RA * LDH_KC : GK * (RA + 8)) * 2 : (KCA ? RA * LDF_KC : GK * (RA + 4)) * 4;
-    constexpr int B_BYTES = BF16 ? (KCB ? 64 * LDH_KC : GK * (64 + 8)) * 2 : (KCB ? 64 * LDF_KC : GK * (64 + 4)) * 4;
+    // K per LDS stage: the bf16 MFMA eats 16 k per instruction, so a 32-deep stage is two MFMAs between barrier pairs --
+    // 128 gives eight (the fp32 MFMA eats 2 k: 32 is already sixteen of them)
+    constexpr int KT = BF16 ? GKH : GK;
+    constexpr int LDH_KC = KT + 8, LDF_KC = KT + 4;
+    constexpr int A_BYTES = BF16 ? (KCA ? RA * LDH_KC : KT * (RA + 8)) * 2 : (KCA ? RA * LDF_KC : KT * (RA + 4)) * 4;
+    constexpr int B_BYTES = BF16 ? (KCB ? 64 * LDH_KC : KT * (64 + 8)) * 2 : (KCB ? 64 * LDF_KC : KT * (64 + 4)) * 4;
     __shared__ __align__(16) unsigned char lds[A_BYTES + B_BYTES];
     void *As = lds, *Bs = lds + A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -122,24 +127,24 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
     floatx16 acc[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) acc[tm] = floatx16{0.f};
-    float4 va[RA / 32], vb[2];
+    float4 va[RA * KT / 1024], vb[64 * KT / 1024];
     if (kb < ke) {
-        fetch_tile<KCA, RA>(A, m0, kb, ke, vecA, va);
-        fetch_tile<KCB, 64>(B, n0, kb, ke, vecB, vb);
+        fetch_tile<KCA, RA, KT>(A, m0, kb, ke, vecA, va);
+        fetch_tile<KCB, 64, KT>(B, n0, kb, ke, vecB, vb);
     }
-    for (int k0 = kb; k0 < ke; k0 += GK) {
+    for (int k0 = kb; k0 < ke; k0 += KT) {
         __syncthreads();
-        stage_tile<BF16, KCA, RA>(As, va);
-        stage_tile<BF16, KCB, 64>(Bs, vb);
+        stage_tile<BF16, KCA, RA, KT>(As, va);
+        stage_tile<BF16, KCB, 64, KT>(Bs, vb);
         __syncthreads();
-        if (k0 + GK < ke) {                        // next tile in flight under the MFMAs
-            fetch_tile<KCA, RA>(A, m0, k0 + GK, ke, vecA, va);
-            fetch_tile<KCB, 64>(B, n0, k0 + GK, ke, vecB, vb);
+        if (k0 + KT < ke) {                        // next tile in flight under the MFMAs
+            fetch_tile<KCA, RA, KT>(A, m0, k0 + KT, ke, vecA, va);
+            fetch_tile<KCB, 64, KT>(B, n0, k0 + KT, ke, vecB, vb);
         }
         if (BF16) {
             const ww_bf16 *a = reinterpret_cast<const ww_bf16 *>(As), *b = reinterpret_cast<const ww_bf16 *>(Bs);
 #pragma unroll
-            for (int t = 0; t < GK / 16; ++t) {
+            for (int t = 0; t < KT / 16; ++t) {
                 const bf16x8 fb = KCB ? *reinterpret_cast<const bf16x8 *>(b + (32 * nh + r) * LDH_KC + 16 * t + 8 * h)
                                       : tr_frag(b, 64 + 8, 16 * t, 32 * nh, lane);
 #pragma unroll
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
         } else {
             const float *a = reinterpret_cast<const float *>(As), *b = reinterpret_cast<const float *>(Bs);
 #pragma unroll
-            for (int t = 0; t < GK / 2; ++t) {
+            for (int t = 0; t < KT / 2; ++t) {
                 const float fb = KCB ? b[(32 * nh + r) * LDF_KC + 2 * t + h] : b[(2 * t + h) * (64 + 4) + 32 * nh + r];
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
@@ -295,7 +300,8 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
     };
     const int vecA = aligned(A, KCA), vecB = aligned(B, KCB);
     int kps = K;
-    if (splits > 1) kps = ((K + splits - 1) / splits + GK - 1) / GK * GK;
+    const int kt = mode == WW_ACT_BF16 ? GKH : GK;
+    if (splits > 1) kps = ((K + splits - 1) / splits + kt - 1) / kt * kt;
     const int nz = (K + kps - 1) / kps;
     // 128-row blocks only when there are plenty of them (measured: at 2048 rows they halve the block count and lose 30 %;
     // at 16384 rows they gain 8 %)
