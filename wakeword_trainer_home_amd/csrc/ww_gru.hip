@@ -10,15 +10,25 @@
 //     sequence -- the per-step product h W_hh^T is 96 v_mfma_f32_16x16x4_f32 per wave with no weight traffic at all;
 //   * backward mirrors it (dh carried in LDS, W_hh slice by output unit in registers, dGh W_hh per step), and the weight
 //     gradients are three large GEMMs over all (batch, time) rows afterwards, split over K with fixed-order sums.
-// The recurrence is fp32 (exact-fp32 MFMA) in both modes; `mode` selects the matrix type of the big GEMMs (input projection,
-// dX, dW_ih, dW_hh): WW_ACT_F32 = fp32 MFMA (parity mode), WW_ACT_BF16 = operands rounded to bf16, fp32 accumulation
-// (what autocast does to them).  Hidden size 128 only.
+// `mode` selects the matrix type everywhere a matrix core is used: WW_ACT_F32 = exact-fp32 MFMA (parity mode);
+// WW_ACT_BF16 = operands rounded to bf16, fp32 accumulation (what autocast does to a GRU) for the big GEMMs (input
+// projection, dX, dW_ih, dW_hh) AND for the per-step products of the recurrence (h and W_hh enter the MFMA as bf16; the hidden
+// state, the gates and every elementwise step stay fp32).  Hidden size 128 only.
 #include "ww_internal.h"
+#include "ww_act.h"
 #include <algorithm>
 
 namespace {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int HB_LD = 128 + 8;       // bf16 row strides (16-byte aligned 8-element fragments)
+constexpr int DGB_LD = 3 * 128 + 8;
+__device__ __forceinline__ bf16x8 pack8g(const float (&v)[8]) {
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    return __builtin_convertvector(f, bf16x8);
+}
 constexpr int GH = 128;          // hidden size
 constexpr int GBT = 16;          // batch rows per block (one 16-row MFMA tile)
 constexpr int HS_LD = GH + 4;    // LDS row strides: lane (row i, k) -> bank 4i + k, conflict-free fragment reads
@@ -28,23 +38,41 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 
 struct GruSaved { float *r, *z, *n, *hn, *hp; };    // (B*T, 128) each: gates, W_hn h + b_hn, h_{t-1}
 
-// grid ceil(B/16), block 512 = 8 waves; wave w owns hidden units [16w, 16w+16)
+// grid ceil(B/16), block 512 = 8 waves; wave w owns hidden units [16w, 16w+16).  BF16: h and W_hh enter the MFMA as bf16
+// (v_mfma_f32_16x16x32_bf16, 12 instead of 96 matrix instructions per step); h itself, the gates and the update stay fp32.
+template <bool BF16>
 __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, const float *__restrict__ w_hh,
                                                  const float *__restrict__ b_hh, const float *__restrict__ h0, int B, int T,
                                                  int reverse, float *__restrict__ y, long ldy, long bsy,
                                                  float *__restrict__ hn_out, GruSaved sv) {
     __shared__ float hs[2][GBT][HS_LD];
+    __shared__ __align__(16) ww_bf16 hb[BF16 ? 2 : 1][BF16 ? GBT : 1][HB_LD];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
     const int b0 = blockIdx.x * GBT, u = 16 * w + j;
-    float wreg[3][32];      // B operand of k-step kk, gate g: W_hh[g*128 + u][4kk + kq]
+    float wreg[BF16 ? 1 : 3][BF16 ? 1 : 32];      // fp32: B operand of k-step kk, gate g: W_hh[g*128 + u][4kk + kq]
+    bf16x8 wb[BF16 ? 3 : 1][BF16 ? 4 : 1];        // bf16: W_hh[g*128 + u][32kk + 8kq .. +7]
+    if constexpr (BF16) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) wreg[g][kk] = w_hh[(size_t)(g * GH + u) * GH + 4 * kk + kq];
+            for (int kk = 0; kk < 4; ++kk) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = w_hh[(size_t)(g * GH + u) * GH + 32 * kk + 8 * kq + e];
+                wb[g][kk] = pack8g(v);
+            }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) wreg[g][kk] = w_hh[(size_t)(g * GH + u) * GH + 4 * kk + kq];
+    }
     const float bhr = b_hh[u], bhz = b_hh[GH + u], bhn = b_hh[2 * GH + u];
     for (int e = tid; e < GBT * GH; e += 512) {
         const int row = e >> 7, c = e & 127;
-        hs[0][row][c] = (h0 && b0 + row < B) ? h0[(size_t)(b0 + row) * GH + c] : 0.f;
+        const float hv = (h0 && b0 + row < B) ? h0[(size_t)(b0 + row) * GH + c] : 0.f;
+        hs[0][row][c] = hv;
+        if constexpr (BF16) hb[0][row][c] = (ww_bf16)hv;
     }
     __syncthreads();
     for (int it = 0; it < T; ++it) {
@@ -57,11 +85,20 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
             gir[reg] = g3[u]; giz[reg] = g3[GH + u]; gin[reg] = g3[2 * GH + u];
         }
         floatx4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if constexpr (BF16) {
 #pragma unroll
-        for (int kk = 0; kk < 32; ++kk) {
-            const float a = hs[cur][j][4 * kk + kq];
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&hb[cur][j][32 * kk + 8 * kq]);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[g][kk], acc[g], 0, 0, 0);
+                for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wb[g][kk], acc[g], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) {
+                const float a = hs[cur][j][4 * kk + kq];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[g][kk], acc[g], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {     // D[row = 4kq + reg][unit u]
@@ -75,6 +112,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
                 const float hp = hs[cur][row][u];
                 const float h = (1.0f - z) * n + z * hp;
                 hs[cur ^ 1][row][u] = h;
+                if constexpr (BF16) hb[cur ^ 1][row][u] = (ww_bf16)h;
                 sv.r[m * GH + u] = r; sv.z[m * GH + u] = z; sv.n[m * GH + u] = n; sv.hn[m * GH + u] = hnv; sv.hp[m * GH + u] = hp;
                 y[(size_t)b * bsy + (size_t)t * ldy + u] = h;
             }
@@ -89,17 +127,30 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
 }
 
 // same decomposition; wave w owns OUTPUT units [16w,16w+16) of dh_{t-1} = dh*z + dGh W_hh
+template <bool BF16>
 __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh, const float *__restrict__ dy, long ldy,
                                                  long bsy, const float *__restrict__ dhn, int B, int T, int reverse,
                                                  GruSaved sv, float *__restrict__ dgi, float *__restrict__ dgh,
                                                  float *__restrict__ dh0, float *__restrict__ bias_part) {
     __shared__ float dhs[GBT][HS_LD];
-    __shared__ float dg[GBT][DG_LD];
+    __shared__ float dg[BF16 ? 8 : GBT][DG_LD];      // fp32 operand tile (bf16 mode: only the bias-gradient reduction uses it)
+    __shared__ __align__(16) ww_bf16 dgb[BF16 ? GBT : 1][DGB_LD];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
     const int b0 = blockIdx.x * GBT, u = 16 * w + j;
-    float wreg[96];         // B operand of k-step cc: W_hh[4cc + kq][u]  (contraction over the 384 gate rows)
+    float wreg[BF16 ? 1 : 96];         // fp32: B operand of k-step cc: W_hh[4cc + kq][u]  (contraction over the 384 gate rows)
+    bf16x8 wb[BF16 ? 12 : 1];          // bf16: W_hh[32cc + 8kq .. +7][u]
+    if constexpr (BF16) {
 #pragma unroll
-    for (int cc = 0; cc < 96; ++cc) wreg[cc] = w_hh[(size_t)(4 * cc + kq) * GH + u];
+        for (int cc = 0; cc < 12; ++cc) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = w_hh[(size_t)(32 * cc + 8 * kq + e) * GH + u];
+            wb[cc] = pack8g(v);
+        }
+    } else {
+#pragma unroll
+        for (int cc = 0; cc < 96; ++cc) wreg[cc] = w_hh[(size_t)(4 * cc + kq) * GH + u];
+    }
     for (int e = tid; e < GBT * GH; e += 512) {
         const int row = e >> 7, c = e & 127;
         dhs[row][c] = (dhn && b0 + row < B) ? dhn[(size_t)(b0 + row) * GH + c] : 0.f;
@@ -139,15 +190,26 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
                 p[c] = dar; p[GH + c] = daz; p[2 * GH + c] = dhn_;
                 sar += dar; saz += daz; san += dan; shn += dhn_;
             }
-            dg[row][c] = dar; dg[row][GH + c] = daz; dg[row][2 * GH + c] = dhn_;
+            if constexpr (BF16) {
+                dgb[row][c] = (ww_bf16)dar; dgb[row][GH + c] = (ww_bf16)daz; dgb[row][2 * GH + c] = (ww_bf16)dhn_;
+            } else {
+                dg[row][c] = dar; dg[row][GH + c] = daz; dg[row][2 * GH + c] = dhn_;
+            }
             dhs[row][c] = keep;                          // read and written by this thread only
         }
         __syncthreads();
         if (it + 1 < T) prefetch(reverse ? it + 1 : T - 2 - it);      // in flight under the MFMAs
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF16) {
 #pragma unroll
-        for (int cc = 0; cc < 96; ++cc)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dg[j][4 * cc + kq], wreg[cc], acc, 0, 0, 0);
+            for (int cc = 0; cc < 12; ++cc)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&dgb[j][32 * cc + 8 * kq]), wb[cc], acc,
+                                                              0, 0, 0);
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < 96; ++cc)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dg[j][4 * cc + kq], wreg[cc], acc, 0, 0, 0);
+        }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) dhs[4 * kq + reg][u] += acc[reg];
         __syncthreads();
@@ -264,8 +326,12 @@ extern "C" int ww_gru_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
     // Gi[(b,t)][3H] = x[(b,t)][:] W_ih^T + b_ih for all time steps at once
     rc = ww_gemm(mode, x, ldx, 1, B * T, w_ih, I, 1, 3 * GH, I, (float *)(w + L.gi), 3 * GH, b_ih, 0, 1, nullptr, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gru_fwd, dim3((B + GBT - 1) / GBT), dim3(512), 0, st, (const float *)(w + L.gi), w_hh, b_hh, h0, B, T,
-                       reverse, y, ldy, (long)T * ldy, h_n, saved(w, L));
+    if (mode == WW_ACT_BF16)
+        hipLaunchKernelGGL(k_gru_fwd<true>, dim3((B + GBT - 1) / GBT), dim3(512), 0, st, (const float *)(w + L.gi), w_hh, b_hh, h0,
+                           B, T, reverse, y, ldy, (long)T * ldy, h_n, saved(w, L));
+    else
+        hipLaunchKernelGGL(k_gru_fwd<false>, dim3((B + GBT - 1) / GBT), dim3(512), 0, st, (const float *)(w + L.gi), w_hh, b_hh, h0,
+                           B, T, reverse, y, ldy, (long)T * ldy, h_n, saved(w, L));
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -287,8 +353,12 @@ extern "C" int ww_gru_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
     const GruSaved sv = saved(w, L);
     float *bpart = part + (size_t)GRU_SPLITS * 3 * GH * std::max(I, GH);
     const int nblk = (B + GBT - 1) / GBT;
-    hipLaunchKernelGGL(k_gru_bwd, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi, dgh,
-                       dh0, bpart);
+    if (mode == WW_ACT_BF16)
+        hipLaunchKernelGGL(k_gru_bwd<true>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
+                           dgh, dh0, bpart);
+    else
+        hipLaunchKernelGGL(k_gru_bwd<false>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
+                           dgh, dh0, bpart);
     WW_LAUNCH_CHECK();
     const int M = B * T;
     const int splits = M >= 4096 ? GRU_SPLITS : 1;
