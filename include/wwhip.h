@@ -238,6 +238,8 @@ int ww_grad_norm_clip(ww_ctx *ctx, float *flat_grads, size_t n, float max_norm, 
  * pre-activation the backward of the activation needs.                                                              */
 #define WW_LIN_NONE 0
 #define WW_LIN_HARDSWISH 1
+#define WW_LIN_RELU 2          /* squeeze-excitation fc1 */
+#define WW_LIN_HARDSIGMOID 3   /* squeeze-excitation fc2 (scale_activation of torchvision's MobileNetV3) */
 typedef struct {
     int32_t act;
     float dropout_p;
@@ -249,6 +251,32 @@ size_t ww_linear_mfma_bwd_scratch_bytes(int M, int K, int N);
 int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const float *w, const float *pre /* nullable if no act */,
                        const float *dy, int M, int K, int N, const ww_linear_epi *epi, float *dx /* nullable */, float *dw,
                        float *db /* nullable */, void *scratch, size_t scratch_bytes, ww_stream_t stream);
+
+/* ------------------------------------------------------------------ generic channels-last layers
+ * Building blocks of bodies with varying channel counts (torchvision's mobilenet_v3_small, as MobileNetV3Wakeword
+ * instantiates it: src/models/architectures.py:91-102).  Activations are fp32 row-major (M = B*H*W, C) matrices, so 1x1
+ * convolutions and the squeeze-excitation FCs are ww_linear_mfma_* calls; these entry points cover the rest.
+ * scratch: ww_nhwc_scratch_bytes(C) bytes.  act: WW_LIN_*.                                                         */
+size_t ww_nhwc_scratch_bytes(int C);
+/* BatchNorm2d (+activation): y = act(bn(x)); ss (2C) = scale|shift and mr (2C) = mean|rstd are kept for the backward.   */
+int ww_bn_act_fwd(ww_ctx *ctx, const float *x, long M, int C, const ww_bn_t *bn, int act, float *y, float *ss, float *mr,
+                  void *scratch, ww_stream_t stream);
+int ww_bn_act_bwd(ww_ctx *ctx, const float *x, const float *da, long M, int C, const float *ss, const float *mr, int act,
+                  int training, float *dx, float *dgamma, float *dbeta, void *scratch, ww_stream_t stream);
+/* depthwise Conv2d(C, C, k, stride, padding=k/2, groups=C, bias=False): x (B,H,W,C), w (C,1,k,k), k in {3,5}, stride in {1,2} */
+int ww_dwconv_nhwc_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int H, int W, int C, int k, int stride, float *y,
+                       ww_stream_t stream);
+int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, const float *dy, int B, int H, int W, int C, int k,
+                       int stride, float *dx /* nullable */, float *dw, void *scratch, ww_stream_t stream);
+/* AdaptiveAvgPool2d(1) on (B,HW,C) -> (B,C); per-(b,c) scaling y = x*gate and its two gradients; dx = dy*gate + dpool/HW   */
+int ww_pool_hw_fwd(ww_ctx *ctx, const float *x, int B, int HW, int C, float *s, ww_stream_t stream);
+int ww_scale_bc_fwd(ww_ctx *ctx, const float *x, const float *gate, int B, int HW, int C, float *y, ww_stream_t stream);
+int ww_scale_bc_bwd_gate(ww_ctx *ctx, const float *x, const float *dy, int B, int HW, int C, float *dgate, ww_stream_t stream);
+int ww_scale_pool_bwd(ww_ctx *ctx, const float *dy /* nullable */, const float *gate, const float *dpool /* nullable */, int B,
+                      int HW, int C, float *dx, ww_stream_t stream);
+/* 3x3 stride-2 pad-1 patches of a one-channel image (B,H,W) -> (B*ceil(H/2)*ceil(W/2), 9): the stem conv becomes a GEMM */
+int ww_im2col3x3s2(ww_ctx *ctx, const float *x, int B, int H, int W, float *cols, ww_stream_t stream);
+int ww_add_f32(ww_ctx *ctx, const float *a, const float *b, size_t n, float *y, ww_stream_t stream);
 
 /* ------------------------------------------------------------------ conv front-end of the CRNN
  * cnn_small's conv stack (stem + 4 depthwise-separable blocks) without GAP / classifier, followed by the mean over the

@@ -1,0 +1,121 @@
+"""MobileNetV3-small body on the native channels-last layer library against torch.nn in float64:
+per-layer (BatchNorm+activation, depthwise k x k / stride, squeeze-excitation pieces, stem patches) and the whole
+``MobileNetV3Wakeword`` against ``oracle/mobilenetv3.py`` (torchvision's published architecture restated in torch.nn;
+torchvision itself is not installed -> parity with it is unpinned, see the oracle's header).
+fp32 device vs float64: layers <= 2e-5 relative, whole model logits <= 2e-4, gradients <= 2e-3 of the vector norm."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+ACTS = {0: lambda z: z, 1: Fn.hardswish, 2: torch.relu, 3: Fn.hardsigmoid}
+
+
+@pytest.mark.parametrize("M,C,act,training", [(1000, 16, 1, True), (333, 72, 2, True), (64, 576, 1, True), (50, 24, 0, True),
+                                              (200, 40, 3, True), (300, 88, 2, False)])
+def test_bn_act_layer(M, C, act, training):
+    from wakeword_trainer_home_amd import _native as nat
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g, dtype=torch.float64) * 2 + 1).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    rm, rv = torch.randn(C, generator=g, dtype=torch.float64) * 0.1, torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    da = torch.randn(M, C, generator=g, dtype=torch.float64)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = Fn.batch_norm(x, rm_ref, rv_ref, gamma, beta, training=training, momentum=0.01, eps=1e-3)
+    y_ref = ACTS[act](z)
+    (y_ref * da).sum().backward()
+    f = lambda t: t.detach().float().to(DEV).contiguous()
+    rmd, rvd = f(rm), f(rv)
+    gm, bt = f(gamma), f(beta)
+    bn = nat.make_bn(gm, bt, rmd, rvd, momentum=0.01, eps=1e-3, training=training)
+    xd = f(x)
+    y, ss, mr = nat.bn_act_fwd(xd, bn, act, C)
+    assert _rel(y.cpu().double(), y_ref.detach()) <= 2e-5
+    assert _rel(rmd.cpu().double(), rm_ref) <= 1e-5 and _rel(rvd.cpu().double(), rv_ref) <= 1e-5
+    dx, dg, db = nat.bn_act_bwd(xd, f(da), ss, mr, act, training, C)
+    assert _rel(dx.cpu().double(), x.grad) <= 5e-5
+    assert _rel(dg.cpu().double(), gamma.grad) <= 5e-5 and _rel(db.cpu().double(), beta.grad) <= 5e-5
+
+
+@pytest.mark.parametrize("B,H,W,C,k,s", [(3, 20, 76, 16, 3, 2), (2, 10, 38, 72, 3, 2), (2, 5, 19, 96, 5, 2), (2, 3, 10, 240, 5, 1),
+                                         (1, 2, 5, 576, 5, 1), (2, 7, 9, 10, 3, 1)])
+def test_depthwise_layer(B, H, W, C, k, s):
+    from wakeword_trainer_home_amd import _native as nat
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(C, 1, k, k, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    y_ref = Fn.conv2d(x, w, stride=s, padding=k // 2, groups=C)
+    dy = torch.randn_like(y_ref)
+    (y_ref * dy).sum().backward()
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).float().contiguous().to(DEV)
+    y = nat.dwconv_nhwc_fwd(nhwc(x), w.detach().float().to(DEV), k, s)
+    assert y.shape == nhwc(y_ref).shape and _rel(y.cpu().double(), nhwc(y_ref).cpu().double()) <= 2e-6
+    dx, dw = nat.dwconv_nhwc_bwd(nhwc(x), w.detach().float().to(DEV), nhwc(dy), k, s)
+    assert _rel(dx.cpu().double(), nhwc(x.grad).cpu().double()) <= 2e-6
+    assert _rel(dw.cpu().double(), w.grad) <= 2e-5
+
+
+def test_se_pieces_and_stem_patches():
+    from wakeword_trainer_home_amd import _native as nat
+    g = torch.Generator().manual_seed(5)
+    B, HW, C = 6, 50, 72
+    x = torch.randn(B, HW, C, generator=g)
+    gate = torch.rand(B, C, generator=g)
+    dy = torch.randn(B, HW, C, generator=g)
+    dpool = torch.randn(B, C, generator=g)
+    xd, gd, dyd, dpd = (t.to(DEV) for t in (x, gate, dy, dpool))
+    assert _rel(nat.pool_hw_fwd(xd).cpu(), x.mean(1)) <= 1e-6
+    assert torch.equal(nat.scale_bc_fwd(xd, gd).cpu(), x * gate[:, None, :])
+    assert _rel(nat.scale_bc_bwd_gate(xd, dyd).cpu(), (x * dy).sum(1)) <= 1e-6
+    assert _rel(nat.scale_pool_bwd(dyd, gd, dpd, (B, HW, C)).cpu(), dy * gate[:, None, :] + dpool[:, None, :] / HW) <= 1e-6
+    assert _rel(nat.scale_pool_bwd(None, None, dpd, (B, HW, C)).cpu(), (dpool[:, None, :] / HW).expand(B, HW, C)) <= 1e-6
+    assert torch.equal(nat.add_f32(xd, dyd).cpu(), x + dy)
+    img = torch.randn(3, 1, 41, 151, generator=g)
+    cols = nat.im2col3x3s2(img[:, 0].contiguous().to(DEV)).cpu()
+    ref = Fn.unfold(img, 3, padding=1, stride=2).transpose(1, 2).reshape(-1, 9)
+    assert torch.equal(cols, ref)
+
+
+def test_mobilenetv3_matches_oracle():
+    from wakeword_trainer_home_amd.models import create_model
+    from oracle.mobilenetv3 import MobileNetV3Oracle
+    from tests.golden_util import make_inputs
+    torch.manual_seed(11)
+    model = create_model("mobilenetv3", num_classes=2, dropout=0.3, dropout_seed=6).to(DEV)
+    oracle = MobileNetV3Oracle(2, dropout=0.3, seed=6)
+    assert list(model.state_dict().keys()) == list(oracle.state_dict().keys())
+    assert sum(p.numel() for p in model.parameters()) == 1519618          # mobilenet_v3_small body (1 input channel) + the reference head
+    oracle.load_state_dict({k: v.cpu().double() if v.is_floating_point() else v.cpu() for k, v in model.state_dict().items()})
+    x, y = make_inputs(3, 10)
+    model.train()
+    oracle.train()
+    out = model(x.to(DEV))
+    loss = Fn.cross_entropy(out, y.to(DEV))
+    loss.backward()
+    ref = oracle(x, step=0, training=True)
+    lo = Fn.cross_entropy(ref, y)
+    lo.backward()
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 2e-4
+    assert abs(loss.item() - lo.item()) <= 2e-4
+    gd = torch.cat([p.grad.flatten().cpu().double() for p in model.parameters()])
+    go = torch.cat([p.grad.flatten() for p in oracle.parameters()])
+    assert ((gd - go).norm() / go.norm()).item() <= 2e-3
+    for (n, p), q in zip(model.named_parameters(), oracle.parameters()):        # and no tensor is off by itself
+        assert (p.grad.cpu().double() - q.grad).norm().item() <= 1e-2 * q.grad.norm().item() + 1e-7, n
+    for (n, b), (_, c) in zip(model.named_buffers(), oracle.named_buffers()):   # running statistics after one training step
+        assert (b.cpu().double() - c.double()).abs().max().item() <= 1e-4 * c.double().abs().max().item() + 1e-7, n
+    model.eval()
+    oracle.eval()
+    with torch.no_grad():
+        ev = model(x.to(DEV))
+        ev_ref = oracle(x, training=False)
+    assert (ev.cpu().double() - ev_ref).abs().max().item() <= 2e-4

@@ -48,7 +48,7 @@ class LinearEpi(C.Structure):
                 ("sample_offset", C.c_uint64)]
 
 
-LIN_NONE, LIN_HARDSWISH = 0, 1
+LIN_NONE, LIN_HARDSWISH, LIN_RELU, LIN_HARDSIGMOID = 0, 1, 2, 3
 
 
 class OptimCfg(C.Structure):
@@ -87,6 +87,17 @@ _SIGS = {
     "ww_linear_mfma_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(LinearEpi), _vp, _vp, _vp, _vp, _sz,
                                      _vp]),
     "ww_dropout_bt": (C.c_int, [_vp, _vp, C.c_long, _i, _i, _i, _f, _u64, _u64, _u64, _i, _vp, C.c_long, _vp]),
+    "ww_nhwc_scratch_bytes": (_sz, [_i]),
+    "ww_bn_act_fwd": (C.c_int, [_vp, _vp, C.c_long, _i, C.POINTER(BN), _i, _vp, _vp, _vp, _vp, _vp]),
+    "ww_bn_act_bwd": (C.c_int, [_vp, _vp, _vp, C.c_long, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ww_dwconv_nhwc_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ww_dwconv_nhwc_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ww_pool_hw_fwd": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ww_scale_bc_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ww_scale_bc_bwd_gate": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ww_scale_pool_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ww_im2col3x3s2": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ww_add_f32": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "ww_gru_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ww_gru_fwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_long, _vp, _vp, _sz, _vp]),
     "ww_gru_bwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, C.c_long, _i,
@@ -391,6 +402,113 @@ def dropout_bt(x, p, seed=0, step=0, sample_offset=0, stream_id=0, out=None):
         _check(load().ww_dropout_bt(ctx(dev), _p(x), ldx, B, T, Cc, p, seed, step, sample_offset, stream_id, _p(out),
                                     _bt_rows(out, "out"), _stream(dev)), "ww_dropout_bt")
     return out
+
+
+# ---- generic channels-last layers (MobileNetV3 body); activations are contiguous fp32 (M, C) / (B, H, W, C) tensors
+def nhwc_scratch(Cn, dev):
+    return torch.empty(load().ww_nhwc_scratch_bytes(Cn) // 4, dtype=torch.float32, device=dev)
+
+
+def bn_act_fwd(x, bn: BN, act, Cn):
+    """x (..., C) -> (y, ss (2C), mr (2C))."""
+    dev = _dev(x)
+    M = x.numel() // Cn
+    y = torch.empty_like(x)
+    ss = torch.empty(2 * Cn, dtype=torch.float32, device=dev)
+    mr = torch.empty(2 * Cn, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_bn_act_fwd(ctx(dev), _p(x), M, Cn, C.byref(bn), act, _p(y), _p(ss), _p(mr), _p(nhwc_scratch(Cn, dev)),
+                                    _stream(dev)), "ww_bn_act_fwd")
+    return y, ss, mr
+
+
+def bn_act_bwd(x, da, ss, mr, act, training, Cn):
+    dev = _dev(x, da, ss, mr)
+    M = x.numel() // Cn
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_bn_act_bwd(ctx(dev), _p(x), _p(da), M, Cn, _p(ss), _p(mr), act, int(training), _p(dx), _p(dgamma),
+                                    _p(dbeta), _p(nhwc_scratch(Cn, dev)), _stream(dev)), "ww_bn_act_bwd")
+    return dx, dgamma, dbeta
+
+
+def dwconv_nhwc_fwd(x, w, k, stride):
+    dev = _dev(x, w)
+    B, H, W, Cn = x.shape
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    y = torch.empty((B, Ho, Wo, Cn), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_dwconv_nhwc_fwd(ctx(dev), _p(x), _p(w), B, H, W, Cn, k, stride, _p(y), _stream(dev)), "ww_dwconv_nhwc_fwd")
+    return y
+
+
+def dwconv_nhwc_bwd(x, w, dy, k, stride, need_dx=True):
+    dev = _dev(x, w, dy)
+    B, H, W, Cn = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty_like(w)
+    with torch.cuda.device(dev):
+        _check(load().ww_dwconv_nhwc_bwd(ctx(dev), _p(x), _p(w), _p(dy), B, H, W, Cn, k, stride, _p(dx), _p(dw),
+                                         _p(nhwc_scratch(Cn, dev)), _stream(dev)), "ww_dwconv_nhwc_bwd")
+    return dx, dw
+
+
+def pool_hw_fwd(x):
+    dev = _dev(x)
+    B, HW, Cn = x.shape
+    s = torch.empty((B, Cn), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_pool_hw_fwd(ctx(dev), _p(x), B, HW, Cn, _p(s), _stream(dev)), "ww_pool_hw_fwd")
+    return s
+
+
+def scale_bc_fwd(x, gate):
+    dev = _dev(x, gate)
+    B, HW, Cn = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        _check(load().ww_scale_bc_fwd(ctx(dev), _p(x), _p(gate), B, HW, Cn, _p(y), _stream(dev)), "ww_scale_bc_fwd")
+    return y
+
+
+def scale_bc_bwd_gate(x, dy):
+    dev = _dev(x, dy)
+    B, HW, Cn = x.shape
+    dg = torch.empty((B, Cn), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_scale_bc_bwd_gate(ctx(dev), _p(x), _p(dy), B, HW, Cn, _p(dg), _stream(dev)), "ww_scale_bc_bwd_gate")
+    return dg
+
+
+def scale_pool_bwd(dy, gate, dpool, shape):
+    """dx (B,HW,C) = dy*gate + dpool/HW (either term may be absent)."""
+    dev = _dev(dy, gate, dpool)
+    B, HW, Cn = shape
+    dx = torch.empty(shape, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_scale_pool_bwd(ctx(dev), _p(dy), _p(gate), _p(dpool), B, HW, Cn, _p(dx), _stream(dev)),
+               "ww_scale_pool_bwd")
+    return dx
+
+
+def im2col3x3s2(x):
+    """x (B,H,W) one-channel images -> (B*ceil(H/2)*ceil(W/2), 9) patches."""
+    dev = _dev(x)
+    B, H, W = x.shape
+    cols = torch.empty((B * ((H + 1) // 2) * ((W + 1) // 2), 9), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().ww_im2col3x3s2(ctx(dev), _p(x), B, H, W, _p(cols), _stream(dev)), "ww_im2col3x3s2")
+    return cols
+
+
+def add_f32(a, b):
+    dev = _dev(a, b)
+    y = torch.empty_like(a)
+    with torch.cuda.device(dev):
+        _check(load().ww_add_f32(ctx(dev), _p(a), _p(b), a.numel(), _p(y), _stream(dev)), "ww_add_f32")
+    return y
 
 
 def gru_workspace(B, T, I, H, dev):

@@ -441,7 +441,7 @@ int ww_occupancy_grid(const void *fn, int block, size_t smem, long want, int cap
 // ------------------------------------------------------------------------------------------
 static const char *k_class_names[WW_K_NCLASS] = {"logmel_specaug", "conv_stem_fwd", "dwconv3x3_fwd", "pwconv1x1_fwd",
                                                  "gap_fwd", "head_loss", "pwconv1x1_bwd", "dwconv3x3_bwd",
-                                                 "conv_stem_bwd", "finalize", "grad_norm_clip", "audio_augment", "linear_mfma", "gru"};
+                                                 "conv_stem_bwd", "finalize", "grad_norm_clip", "audio_augment", "linear_mfma", "gru", "nhwc_layers"};
 extern "C" int ww_prof_num_classes(void) { return WW_K_NCLASS; }
 extern "C" const char *ww_prof_class_name(int cls) { return (cls >= 0 && cls < WW_K_NCLASS) ? k_class_names[cls] : ""; }
 extern "C" int ww_prof_enable(ww_ctx *ctx, uint32_t class_mask) {

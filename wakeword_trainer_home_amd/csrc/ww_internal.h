@@ -61,7 +61,7 @@ struct ww_feat_tables {
 // ---- opt-in per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
 enum {
     WW_K_LOGMEL = 0, WW_K_STEM_FWD, WW_K_DW_FWD, WW_K_PW_FWD, WW_K_GAP_FWD, WW_K_HEAD_LOSS, WW_K_PW_BWD, WW_K_DW_BWD,
-    WW_K_STEM_BWD, WW_K_FINALIZE, WW_K_CLIP, WW_K_AUDIO_AUG, WW_K_LINEAR, WW_K_GRU, WW_K_NCLASS
+    WW_K_STEM_BWD, WW_K_FINALIZE, WW_K_CLIP, WW_K_AUDIO_AUG, WW_K_LINEAR, WW_K_GRU, WW_K_NHWC, WW_K_NCLASS
 };
 struct ww_prof_rec { int cls; hipEvent_t a, b; };
 struct ww_ctx {
@@ -113,6 +113,7 @@ int ww_gemm(int mode, const float *A, long a_srow, long a_sk, int a_rows, const 
             int K, float *C, long ldc, const float *bias, int accumulate, int splits, float *part, hipStream_t st);
 int ww_colsum_rows(const float *a, long rows, int cols, float *out, float *part, int chunks, hipStream_t st);
 int ww_colsum_pair(const float *a, int rows, int cols, float *out0, float *out1, hipStream_t st);
+int ww_colsum_rows_small(const float *a, int rows, int cols, float *out, hipStream_t st);
 int ww_occupancy_grid(const void *fn, int block, size_t smem, long want, int cap);
 
 // ---- Philox4x32-10 (host + device), must match oracle/philox.py bit for bit

@@ -39,8 +39,18 @@ struct Epilogue {
     int accumulate;             // C += result (second direction of a bidirectional layer adds into dX)
 };
 
-__device__ __forceinline__ float hardswish(float x) { return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f); }
-__device__ __forceinline__ float hardswish_grad(float x) { return x < -3.f ? 0.f : (x <= 3.f ? x * (1.f / 3.f) + 0.5f : 1.f); }
+__device__ __forceinline__ float lin_act(int act, float z) {
+    if (act == WW_LIN_HARDSWISH) return z * fminf(fmaxf(z + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    if (act == WW_LIN_RELU) return z < 0.f ? 0.f : z;
+    if (act == WW_LIN_HARDSIGMOID) return fminf(fmaxf(z + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    return z;
+}
+__device__ __forceinline__ float lin_act_grad(int act, float z) {      // torch's hardswish / hardsigmoid / relu backward
+    if (act == WW_LIN_HARDSWISH) return z < -3.f ? 0.f : (z <= 3.f ? z * (1.f / 3.f) + 0.5f : 1.f);
+    if (act == WW_LIN_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == WW_LIN_HARDSIGMOID) return (z > -3.f && z < 3.f) ? (1.f / 6.f) : 0.f;
+    return 1.f;
+}
 __device__ __forceinline__ bool drop_keep(const Epilogue &e, long row, int col) {
     uint32_t rr[4];
     ww_philox(e.step_lo, e.step_hi, (uint32_t)(e.sample_offset + (uint64_t)row), (WW_TAG_DROPOUT << 24) | (uint32_t)(col >> 2),
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
             if (EPI) {
                 v += bias;
                 if (e.pre) e.pre[row * ldc + col] = v;
-                if (e.act == WW_LIN_HARDSWISH) v = hardswish(v);
+                v = lin_act(e.act, v);
                 if (e.use_dropout) v = drop_keep(e, row, (int)col) ? v * e.drop_scale : 0.f;
             }
             if (e.accumulate && gridDim.z == 1) v += C[row * ldc + col];
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256) void k_linear_dpre(const float *__restrict__ d
         const int col = (int)(i - row * N);
         float g = dy[i];
         if (e.use_dropout) g = drop_keep(e, row, col) ? g * e.drop_scale : 0.f;
-        if (e.act == WW_LIN_HARDSWISH) g *= hardswish_grad(pre[i]);
+        if (e.act != WW_LIN_NONE) g *= lin_act_grad(e.act, pre[i]);
         dpre[i] = g;
     }
 }
@@ -275,7 +285,7 @@ int make_epilogue(const ww_linear_epi *epi, const float *bias, float *pre, Epilo
     e.bias = bias;
     e.pre = pre;
     if (epi) {
-        WW_REQUIRE(epi->act == WW_LIN_NONE || epi->act == WW_LIN_HARDSWISH, WW_E_INVALID, "ww_linear_mfma: unknown activation %d", epi->act);
+        WW_REQUIRE(epi->act >= WW_LIN_NONE && epi->act <= WW_LIN_HARDSIGMOID, WW_E_INVALID, "ww_linear_mfma: unknown activation %d", epi->act);
         WW_REQUIRE(epi->dropout_p >= 0.f && epi->dropout_p < 1.f, WW_E_INVALID, "ww_linear_mfma: dropout_p=%f not in [0,1)",
                    (double)epi->dropout_p);
         e.act = epi->act;
@@ -366,6 +376,12 @@ __global__ __launch_bounds__(1024) void k_colsum_pair(const float *__restrict__ 
         for (int p = 0; p < 16; ++p) t += sh[p][c];
         if (col < cols) out0[col] = (float)t; else out1[col - cols] = (float)t;
     }
+}
+// out[j] = sum_i a[i][j] for a short matrix (one launch, fixed order)
+int ww_colsum_rows_small(const float *a, int rows, int cols, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_colsum_any, dim3((cols + 63) / 64), dim3(1024), 0, st, a, rows, cols, out);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
 }
 int ww_colsum_pair(const float *a, int rows, int cols, float *out0, float *out1, hipStream_t st) {
     hipLaunchKernelGGL(k_colsum_pair, dim3((2 * cols + 63) / 64), dim3(1024), 0, st, a, rows, cols, out0, out1);

@@ -1,0 +1,431 @@
+// Generic channels-last (NHWC, fp32) layers for bodies whose channel counts vary layer to layer -- the MobileNetV3-small body
+// of BASELINE config 3 (torchvision's mobilenet_v3_small as the reference instantiates it,
+// src/models/architectures.py:91-102).  Unlike the 64-channel cnn_small kernels (BatchNorm folded into producers and
+// consumers) these are plain, unfused building blocks: an activation tensor is a row-major (M = B*H*W, C) matrix, so
+//   * every 1x1 convolution and every squeeze-excitation FC is ww_gemm / ww_linear_mfma_* on the matrix cores;
+//   * BatchNorm(+activation) is a statistics pass (chunked column sums, fixed-order fp64 finish) and an apply pass;
+//   * depthwise k x k (3 or 5, stride 1 or 2) is a per-(pixel, 4-channel) gather;
+//   * squeeze-excitation is pool -> FC+ReLU -> FC+Hardsigmoid -> scale.
+// First version: correctness and the reference's layer semantics; fusion of these passes is the next step.
+#include "ww_internal.h"
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ float act_fwd(int act, float z) {
+    if (act == WW_LIN_RELU) return z < 0.f ? 0.f : z;
+    if (act == WW_LIN_HARDSWISH) return z * fminf(fmaxf(z + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    if (act == WW_LIN_HARDSIGMOID) return fminf(fmaxf(z + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    return z;
+}
+__device__ __forceinline__ float act_grad(int act, float z) {
+    if (act == WW_LIN_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == WW_LIN_HARDSWISH) return z < -3.f ? 0.f : (z <= 3.f ? z * (1.f / 3.f) + 0.5f : 1.f);
+    if (act == WW_LIN_HARDSIGMOID) return (z > -3.f && z < 3.f) ? (1.f / 6.f) : 0.f;
+    return 1.f;
+}
+
+constexpr int NCHUNK = 64;      // row chunks of the column reductions
+
+// partial[chunk][0:C] = sum x, [C:2C] = sum x^2 over the chunk's rows.  grid (ceil(C/64), chunks), block 1024
+__global__ __launch_bounds__(1024) void k_colstats(const float *__restrict__ x, long M, int C, long rows_per_chunk,
+                                                   float *__restrict__ part) {
+    __shared__ double sh[2][16][64];
+    const int c = threadIdx.x & 63, p = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
+    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    double s = 0.0, q = 0.0;
+    if (col < C) {
+#pragma unroll 4
+        for (long r = r0 + p; r < r1; r += 16) { const double v = x[r * C + col]; s += v; q += v * v; }
+    }
+    sh[0][p][c] = s; sh[1][p][c] = q;
+    __syncthreads();
+    if (p == 0 && col < C) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a += sh[0][i][c]; b += sh[1][i][c]; }
+        part[(long)blockIdx.y * 2 * C + col] = (float)a;
+        part[(long)blockIdx.y * 2 * C + C + col] = (float)b;
+    }
+}
+// BatchNorm2d statistics -> scale|shift (ss) and mean|rstd (mr); torch semantics for the running statistics
+__global__ void k_bn_finish(const float *__restrict__ part, int chunks, long M, int C, ww_bn_t bn, float *__restrict__ ss,
+                            float *__restrict__ mr) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean, var;
+    if (bn.training) {
+        double s = 0.0, q = 0.0;
+        for (int i = 0; i < chunks; ++i) { s += part[(long)i * 2 * C + c]; q += part[(long)i * 2 * C + C + c]; }
+        mean = s / (double)M;
+        var = q / (double)M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (bn.running_mean) {
+            const double m = bn.momentum, unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            bn.running_mean[c] = (float)((1.0 - m) * (double)bn.running_mean[c] + m * mean);
+            bn.running_var[c] = (float)((1.0 - m) * (double)bn.running_var[c] + m * unb);
+        }
+    } else {
+        mean = bn.running_mean[c];
+        var = bn.running_var[c];
+    }
+    const double rstd = 1.0 / sqrt(var + (double)bn.eps), scale = (double)bn.gamma[c] * rstd;
+    ss[c] = (float)scale;
+    ss[C + c] = (float)((double)bn.beta[c] - mean * scale);
+    mr[c] = (float)mean;
+    mr[C + c] = (float)rstd;
+}
+__global__ __launch_bounds__(256) void k_bn_act_apply(const float *__restrict__ x, const float *__restrict__ ss, long n, int C,
+                                                      int act, float *__restrict__ y) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        y[i] = act_fwd(act, fmaf(x[i], ss[c], ss[C + c]));
+    }
+}
+// backward pass 1: dz = da * act'(z); partial sums of dz and dz*xhat
+__global__ __launch_bounds__(1024) void k_bnact_bwd_stats(const float *__restrict__ x, const float *__restrict__ da,
+                                                          const float *__restrict__ ss, const float *__restrict__ mr, long M,
+                                                          int C, int act, long rows_per_chunk, float *__restrict__ part) {
+    __shared__ double sh[2][16][64];
+    const int c = threadIdx.x & 63, p = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
+    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    double s1 = 0.0, s2 = 0.0;
+    if (col < C) {
+        const float sc = ss[col], sf = ss[C + col], mu = mr[col], rs = mr[C + col];
+#pragma unroll 4
+        for (long r = r0 + p; r < r1; r += 16) {
+            const float xv = x[r * C + col];
+            const float dz = da[r * C + col] * act_grad(act, fmaf(xv, sc, sf));
+            s1 += dz;
+            s2 += (double)dz * (double)((xv - mu) * rs);
+        }
+    }
+    sh[0][p][c] = s1; sh[1][p][c] = s2;
+    __syncthreads();
+    if (p == 0 && col < C) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a += sh[0][i][c]; b += sh[1][i][c]; }
+        part[(long)blockIdx.y * 2 * C + col] = (float)a;
+        part[(long)blockIdx.y * 2 * C + C + col] = (float)b;
+    }
+}
+__global__ void k_bnact_bwd_finish(const float *__restrict__ part, int chunks, int C, float *__restrict__ sums,
+                                   float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < chunks; ++i) { s1 += part[(long)i * 2 * C + c]; s2 += part[(long)i * 2 * C + C + c]; }
+    sums[c] = (float)s1; sums[C + c] = (float)s2;
+    dgamma[c] = (float)s2; dbeta[c] = (float)s1;
+}
+// backward pass 2: dx = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat))   (training);  eval: dx = scale*dz
+__global__ __launch_bounds__(256) void k_bnact_bwd_apply(const float *__restrict__ x, const float *__restrict__ da,
+                                                         const float *__restrict__ ss, const float *__restrict__ mr,
+                                                         const float *__restrict__ sums, long M, int C, int act, int training,
+                                                         float *__restrict__ dx) {
+    const long n = M * C;
+    const float invM = 1.0f / (float)M;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float xv = x[i], sc = ss[c];
+        const float dz = da[i] * act_grad(act, fmaf(xv, sc, ss[C + c]));
+        if (training) {
+            const float xh = (xv - mr[c]) * mr[C + c];
+            dx[i] = sc * (dz - sums[c] * invM - xh * sums[C + c] * invM);
+        } else {
+            dx[i] = sc * dz;
+        }
+    }
+}
+
+// ---- depthwise k x k, stride s, padding k/2.  thread = (output pixel, 4 channels); w (C,1,k,k) as in nn.Conv2d
+struct DwG { int B, H, W, C, k, s, Ho, Wo; };
+__global__ __launch_bounds__(256) void k_dwg_fwd(const float *__restrict__ x, const float *__restrict__ w, DwG g,
+                                                 float *__restrict__ y) {
+    const int c4n = (g.C + 3) / 4, pad = g.k / 2;
+    const long n = (long)g.B * g.Ho * g.Wo * c4n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int cq = (int)(i % c4n);
+        long p = i / c4n;
+        const int wo = (int)(p % g.Wo); p /= g.Wo;
+        const int ho = (int)(p % g.Ho);
+        const int b = (int)(p / g.Ho);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < g.k; ++kh) {
+            const int hi = ho * g.s + kh - pad;
+            if (hi < 0 || hi >= g.H) continue;
+            for (int kw = 0; kw < g.k; ++kw) {
+                const int wi = wo * g.s + kw - pad;
+                if (wi < 0 || wi >= g.W) continue;
+                const float *xp = x + (((size_t)b * g.H + hi) * g.W + wi) * g.C + 4 * cq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * cq + e < g.C) acc[e] = fmaf(xp[e], w[(size_t)(4 * cq + e) * g.k * g.k + kh * g.k + kw], acc[e]);
+            }
+        }
+        float *yp = y + (((size_t)b * g.Ho + ho) * g.Wo + wo) * g.C + 4 * cq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * cq + e < g.C) yp[e] = acc[e];
+    }
+}
+// dx[b,hi,wi,c] = sum over taps with (hi + pad - kh) divisible by s of w[c,kh,kw] * dy[b,(hi+pad-kh)/s,(wi+pad-kw)/s,c]
+__global__ __launch_bounds__(256) void k_dwg_bwd_dx(const float *__restrict__ dy, const float *__restrict__ w, DwG g,
+                                                    float *__restrict__ dx) {
+    const int c4n = (g.C + 3) / 4, pad = g.k / 2;
+    const long n = (long)g.B * g.H * g.W * c4n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int cq = (int)(i % c4n);
+        long p = i / c4n;
+        const int wi = (int)(p % g.W); p /= g.W;
+        const int hi = (int)(p % g.H);
+        const int b = (int)(p / g.H);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < g.k; ++kh) {
+            const int th = hi + pad - kh;
+            if (th < 0 || th % g.s) continue;
+            const int ho = th / g.s;
+            if (ho >= g.Ho) continue;
+            for (int kw = 0; kw < g.k; ++kw) {
+                const int tw = wi + pad - kw;
+                if (tw < 0 || tw % g.s) continue;
+                const int wo = tw / g.s;
+                if (wo >= g.Wo) continue;
+                const float *dp = dy + (((size_t)b * g.Ho + ho) * g.Wo + wo) * g.C + 4 * cq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * cq + e < g.C) acc[e] = fmaf(dp[e], w[(size_t)(4 * cq + e) * g.k * g.k + kh * g.k + kw], acc[e]);
+            }
+        }
+        float *xp = dx + (((size_t)b * g.H + hi) * g.W + wi) * g.C + 4 * cq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * cq + e < g.C) xp[e] = acc[e];
+    }
+}
+// dw[c][tap] partials: block = 64 channels x 4 pixel lanes... grid (ceil(C/64), chunks): part[chunk][C*k*k]
+__global__ __launch_bounds__(256) void k_dwg_bwd_dw(const float *__restrict__ x, const float *__restrict__ dy, DwG g,
+                                                    long px_per_chunk, float *__restrict__ part) {
+    __shared__ float sh[4][64][25];
+    const int c = threadIdx.x & 63, lane_p = threadIdx.x >> 6, col = blockIdx.x * 64 + c, pad = g.k / 2, kk = g.k * g.k;
+    const long P = (long)g.B * g.Ho * g.Wo;
+    const long p0 = (long)blockIdx.y * px_per_chunk, p1 = min(P, p0 + px_per_chunk);
+    float acc[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) acc[t] = 0.f;
+    if (col < g.C) {
+        for (long p = p0 + lane_p; p < p1; p += 4) {
+            const int wo = (int)(p % g.Wo);
+            const long q = p / g.Wo;
+            const int ho = (int)(q % g.Ho), b = (int)(q / g.Ho);
+            const float d = dy[(size_t)p * g.C + col];
+            for (int kh = 0; kh < g.k; ++kh) {
+                const int hi = ho * g.s + kh - pad;
+                if (hi < 0 || hi >= g.H) continue;
+                for (int kw = 0; kw < g.k; ++kw) {
+                    const int wi = wo * g.s + kw - pad;
+                    if (wi < 0 || wi >= g.W) continue;
+                    acc[kh * g.k + kw] = fmaf(d, x[(((size_t)b * g.H + hi) * g.W + wi) * g.C + col], acc[kh * g.k + kw]);
+                }
+            }
+        }
+    }
+    for (int t = 0; t < kk; ++t) sh[lane_p][c][t] = acc[t];
+    __syncthreads();
+    if (lane_p == 0 && col < g.C)
+        for (int t = 0; t < kk; ++t)
+            part[(size_t)blockIdx.y * g.C * kk + (size_t)col * kk + t] = sh[0][c][t] + sh[1][c][t] + sh[2][c][t] + sh[3][c][t];
+}
+
+// ---- squeeze-excitation / pooling pieces on (B, HW, C)
+__global__ __launch_bounds__(256) void k_pool_fwd(const float *__restrict__ x, int B, int HW, int C, float *__restrict__ s) {
+    const long n = (long)B * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C), b = (int)(i / C);
+        const float *p = x + (size_t)b * HW * C + c;
+        double a = 0.0;
+        for (int h = 0; h < HW; ++h) a += p[(size_t)h * C];
+        s[i] = (float)(a / HW);
+    }
+}
+// y = x * g[b][c]
+__global__ __launch_bounds__(256) void k_scale_fwd(const float *__restrict__ x, const float *__restrict__ gte, int B, int HW, int C,
+                                                   float *__restrict__ y) {
+    const long n = (long)B * HW * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long b = i / ((long)HW * C);
+        y[i] = x[i] * gte[b * C + c];
+    }
+}
+// dg[b][c] = sum_hw dy * x
+__global__ __launch_bounds__(256) void k_scale_bwd_gate(const float *__restrict__ x, const float *__restrict__ dy, int B, int HW,
+                                                        int C, float *__restrict__ dg) {
+    const long n = (long)B * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C), b = (int)(i / C);
+        const size_t o = (size_t)b * HW * C + c;
+        double a = 0.0;
+        for (int h = 0; h < HW; ++h) a += (double)dy[o + (size_t)h * C] * (double)x[o + (size_t)h * C];
+        dg[i] = (float)a;
+    }
+}
+// dx = dy * g[b][c] + dpool[b][c] / HW     (dy nullable: plain pooling backward; dpool nullable: plain scaling backward)
+__global__ __launch_bounds__(256) void k_scale_pool_bwd(const float *__restrict__ dy, const float *__restrict__ gte,
+                                                        const float *__restrict__ dpool, int B, int HW, int C,
+                                                        float *__restrict__ dx) {
+    const long n = (long)B * HW * C;
+    const float inv = 1.0f / (float)HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long b = i / ((long)HW * C);
+        float v = dy ? dy[i] * gte[b * C + c] : 0.f;
+        if (dpool) v = fmaf(dpool[b * C + c], inv, v);
+        dx[i] = v;
+    }
+}
+// 3x3 stride-2 pad-1 patches of a single-channel image: cols (B*Ho*Wo, 9)
+__global__ __launch_bounds__(256) void k_im2col3x3s2(const float *__restrict__ x, int B, int H, int W, int Ho, int Wo,
+                                                     float *__restrict__ cols) {
+    const long n = (long)B * Ho * Wo * 9;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % 9);
+        long p = i / 9;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const int hi = 2 * ho + t / 3 - 1, wi = 2 * wo + t % 3 - 1;
+        cols[i] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? x[((size_t)b * H + hi) * W + wi] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void k_add(const float *__restrict__ a, const float *__restrict__ b, long n, float *__restrict__ y) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = a[i] + b[i];
+}
+
+inline int egrid(long n) { return (int)std::min<long>((n + 255) / 256, 256 * 32); }
+inline int chunks_for(long M) { return (int)std::max<long>(1, std::min<long>(NCHUNK, M / 32)); }
+
+}  // namespace
+
+// scratch of one layer call: chunk partials (BatchNorm: 2C per chunk, depthwise weight gradient: up to 25C per chunk) + 2C sums
+extern "C" size_t ww_nhwc_scratch_bytes(int C) { return (size_t)(NCHUNK * 25 + 2) * std::max(C, 1) * sizeof(float); }
+
+extern "C" int ww_bn_act_fwd(ww_ctx *ctx, const float *x, long M, int C, const ww_bn_t *bn, int act, float *y, float *ss,
+                             float *mr, void *scratch, ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && bn && bn->gamma && bn->beta && y && ss && mr && scratch, WW_E_INVALID, "ww_bn_act_fwd: null argument");
+    WW_REQUIRE(M >= 1 && C >= 1, WW_E_INVALID, "ww_bn_act_fwd: bad shape (%ld,%d)", M, C);
+    WW_REQUIRE(bn->training || (bn->running_mean && bn->running_var), WW_E_INVALID, "ww_bn_act_fwd: eval needs running statistics");
+    WW_REQUIRE(act >= WW_LIN_NONE && act <= WW_LIN_HARDSIGMOID, WW_E_INVALID, "ww_bn_act_fwd: unknown activation %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    ww_prof_scope ps_(ctx, WW_K_NHWC, st);
+    float *part = (float *)scratch;
+    const int chunks = chunks_for(M);
+    if (bn->training) {
+        hipLaunchKernelGGL(k_colstats, dim3((C + 63) / 64, chunks), dim3(1024), 0, st, x, M, C, (M + chunks - 1) / chunks, part);
+        WW_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_bn_finish, dim3((C + 127) / 128), dim3(128), 0, st, part, chunks, M, C, *bn, ss, mr);
+    WW_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bn_act_apply, dim3(egrid(M * C)), dim3(256), 0, st, x, ss, M * C, C, act, y);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+
+extern "C" int ww_bn_act_bwd(ww_ctx *ctx, const float *x, const float *da, long M, int C, const float *ss, const float *mr, int act,
+                             int training, float *dx, float *dgamma, float *dbeta, void *scratch, ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && da && ss && mr && dx && dgamma && dbeta && scratch, WW_E_INVALID, "ww_bn_act_bwd: null argument");
+    WW_REQUIRE(M >= 1 && C >= 1, WW_E_INVALID, "ww_bn_act_bwd: bad shape (%ld,%d)", M, C);
+    hipStream_t st = (hipStream_t)stream;
+    ww_prof_scope ps_(ctx, WW_K_NHWC, st);
+    float *part = (float *)scratch, *sums = part + (size_t)NCHUNK * 2 * C;
+    const int chunks = chunks_for(M);
+    hipLaunchKernelGGL(k_bnact_bwd_stats, dim3((C + 63) / 64, chunks), dim3(1024), 0, st, x, da, ss, mr, M, C, act,
+                       (M + chunks - 1) / chunks, part);
+    WW_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bnact_bwd_finish, dim3((C + 127) / 128), dim3(128), 0, st, part, chunks, C, sums, dgamma, dbeta);
+    WW_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bnact_bwd_apply, dim3(egrid(M * C)), dim3(256), 0, st, x, da, ss, mr, sums, M, C, act, training, dx);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+
+static int make_dwg(const char *who, int B, int H, int W, int C, int k, int s, DwG *g) {
+    WW_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, WW_E_INVALID, "%s: bad shape", who);
+    WW_REQUIRE((k == 3 || k == 5) && (s == 1 || s == 2), WW_E_UNSUPPORTED, "%s: kernel %d stride %d not implemented", who, k, s);
+    g->B = B; g->H = H; g->W = W; g->C = C; g->k = k; g->s = s;
+    g->Ho = (H + 2 * (k / 2) - k) / s + 1;
+    g->Wo = (W + 2 * (k / 2) - k) / s + 1;
+    return WW_OK;
+}
+extern "C" int ww_dwconv_nhwc_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int H, int W, int C, int k, int stride,
+                                  float *y, ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && w && y, WW_E_INVALID, "ww_dwconv_nhwc_fwd: null argument");
+    DwG g;
+    int rc = make_dwg("ww_dwconv_nhwc_fwd", B, H, W, C, k, stride, &g);
+    if (rc) return rc;
+    ww_prof_scope ps_(ctx, WW_K_NHWC, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_dwg_fwd, dim3(egrid((long)B * g.Ho * g.Wo * ((C + 3) / 4))), dim3(256), 0, (hipStream_t)stream, x, w, g, y);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+extern "C" int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, const float *dy, int B, int H, int W, int C, int k,
+                                  int stride, float *dx, float *dw, void *scratch, ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && w && dy && dw && scratch, WW_E_INVALID, "ww_dwconv_nhwc_bwd: null argument");
+    DwG g;
+    int rc = make_dwg("ww_dwconv_nhwc_bwd", B, H, W, C, k, stride, &g);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ww_prof_scope ps_(ctx, WW_K_NHWC, st);
+    if (dx) {
+        hipLaunchKernelGGL(k_dwg_bwd_dx, dim3(egrid((long)B * H * W * ((C + 3) / 4))), dim3(256), 0, st, dy, w, g, dx);
+        WW_LAUNCH_CHECK();
+    }
+    const long P = (long)B * g.Ho * g.Wo;
+    const int chunks = chunks_for(P);
+    float *part = (float *)scratch;
+    hipLaunchKernelGGL(k_dwg_bwd_dw, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, g, (P + chunks - 1) / chunks, part);
+    WW_LAUNCH_CHECK();
+    return ww_colsum_rows_small(part, chunks, C * k * k, dw, st);
+}
+
+extern "C" int ww_pool_hw_fwd(ww_ctx *ctx, const float *x, int B, int HW, int C, float *s, ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && s && B >= 1 && HW >= 1 && C >= 1, WW_E_INVALID, "ww_pool_hw_fwd: bad argument");
+    hipLaunchKernelGGL(k_pool_fwd, dim3(egrid((long)B * C)), dim3(256), 0, (hipStream_t)stream, x, B, HW, C, s);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+extern "C" int ww_scale_bc_fwd(ww_ctx *ctx, const float *x, const float *gate, int B, int HW, int C, float *y, ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && gate && y && B >= 1 && HW >= 1 && C >= 1, WW_E_INVALID, "ww_scale_bc_fwd: bad argument");
+    hipLaunchKernelGGL(k_scale_fwd, dim3(egrid((long)B * HW * C)), dim3(256), 0, (hipStream_t)stream, x, gate, B, HW, C, y);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+extern "C" int ww_scale_bc_bwd_gate(ww_ctx *ctx, const float *x, const float *dy, int B, int HW, int C, float *dgate,
+                                    ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && dy && dgate && B >= 1 && HW >= 1 && C >= 1, WW_E_INVALID, "ww_scale_bc_bwd_gate: bad argument");
+    hipLaunchKernelGGL(k_scale_bwd_gate, dim3(egrid((long)B * C)), dim3(256), 0, (hipStream_t)stream, x, dy, B, HW, C, dgate);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+extern "C" int ww_scale_pool_bwd(ww_ctx *ctx, const float *dy, const float *gate, const float *dpool, int B, int HW, int C,
+                                 float *dx, ww_stream_t stream) {
+    WW_REQUIRE(ctx && dx && (dy || dpool) && (!dy || gate) && B >= 1 && HW >= 1 && C >= 1, WW_E_INVALID, "ww_scale_pool_bwd: bad argument");
+    hipLaunchKernelGGL(k_scale_pool_bwd, dim3(egrid((long)B * HW * C)), dim3(256), 0, (hipStream_t)stream, dy, gate, dpool, B, HW, C, dx);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+extern "C" int ww_im2col3x3s2(ww_ctx *ctx, const float *x, int B, int H, int W, float *cols, ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && cols && B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_im2col3x3s2: bad argument");
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(k_im2col3x3s2, dim3(egrid((long)B * Ho * Wo * 9)), dim3(256), 0, (hipStream_t)stream, x, B, H, W, Ho, Wo, cols);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+extern "C" int ww_add_f32(ww_ctx *ctx, const float *a, const float *b, size_t n, float *y, ww_stream_t stream) {
+    WW_REQUIRE(ctx && a && b && y, WW_E_INVALID, "ww_add_f32: null argument");
+    if (n == 0) return WW_OK;
+    hipLaunchKernelGGL(k_add, dim3(egrid((long)n)), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, y);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}

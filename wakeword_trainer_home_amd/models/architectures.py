@@ -15,8 +15,8 @@ import torch.nn as nn
 
 from .. import _native as nat
 
-_SUPPORTED = "cnn_small, gru, crnn"
-_REFERENCE_ONLY = ("resnet18", "mobilenetv3", "lstm", "tcn")
+_SUPPORTED = "cnn_small, gru, crnn, mobilenetv3"
+_REFERENCE_ONLY = ("resnet18", "lstm", "tcn")
 
 
 class _DSBlock(nn.Module):
@@ -325,6 +325,11 @@ def create_model(architecture: str, num_classes: int = 2, pretrained: bool = Fal
         return CNNSmallWakeword(num_classes=num_classes, pretrained=pretrained, dropout=kwargs.get("dropout", 0.3),
                                 input_channels=kwargs.get("input_channels", 1),
                                 dropout_seed=kwargs.get("dropout_seed", 0), act_dtype=kwargs.get("act_dtype", "fp32"))
+    if name == "mobilenetv3":                           # same kwargs as the reference factory (architectures.py:468-474)
+        from .mobilenet import MobileNetV3Wakeword
+        return MobileNetV3Wakeword(num_classes=num_classes, pretrained=pretrained, dropout=kwargs.get("dropout", 0.3),
+                                   input_channels=kwargs.get("input_channels", 1), mode=kwargs.get("mode", "fp32"),
+                                   dropout_seed=kwargs.get("dropout_seed", 0))
     if name == "crnn":                                  # not in the reference factory: BASELINE config 5's model
         from .recurrent import CRNNWakeword
         return CRNNWakeword(num_classes=num_classes, hidden_size=kwargs.get("hidden_size", 128),

@@ -1,0 +1,258 @@
+"""``MobileNetV3Wakeword`` (``src/models/architectures.py:68-123``: torchvision's ``mobilenet_v3_small`` with a one-channel
+stem conv and the ``Linear(576,1024) -> Hardswish -> Dropout -> Linear(1024, num_classes)`` classifier) on the native
+channels-last layer library (``ww_bn_act_*``, ``ww_dwconv_nhwc_*``, squeeze-excitation pieces) and the matrix cores
+(``ww_linear_mfma_*`` for every 1x1 convolution, SE FC and the classifier).  The module tree reproduces torchvision's, so the
+``state_dict`` keys are the reference model's (``mobilenet.features.4.block.2.fc1.weight`` ...).  torchvision itself is not
+available in this build environment: the architecture is restated from its published definition (``oracle/mobilenetv3.py``
+carries the same restatement in plain torch.nn) -- parity with torchvision is unpinned, parity with torch.nn is tested.
+First version: unfused fp32 layers (correctness and coverage before speed)."""
+import torch
+import torch.nn as nn
+
+from .. import _native as nat
+from .heads import MobileNetV3Head
+
+SMALL_CONF = ((16, 3, 16, 16, True, "RE", 2), (16, 3, 72, 24, False, "RE", 2), (24, 3, 88, 24, False, "RE", 1),
+              (24, 5, 96, 40, True, "HS", 2), (40, 5, 240, 40, True, "HS", 1), (40, 5, 240, 40, True, "HS", 1),
+              (40, 5, 120, 48, True, "HS", 1), (48, 5, 144, 48, True, "HS", 1), (48, 5, 288, 96, True, "HS", 2),
+              (96, 5, 576, 96, True, "HS", 1), (96, 5, 576, 96, True, "HS", 1))
+LAST_CONV, LAST_CHANNEL = 576, 1024
+_ACT = {None: nat.LIN_NONE, "RE": nat.LIN_RELU, "HS": nat.LIN_HARDSWISH}
+
+
+def _make_divisible(v, divisor=8):
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    return new_v + divisor if new_v < 0.9 * v else new_v
+
+
+# ------------------------------------------------------------------------------------------ autograd wrappers
+class _PWFn(torch.autograd.Function):          # 1x1 convolution on (B,H,W,Cin) = one GEMM over the pixels
+    @staticmethod
+    def forward(ctx, x, w4, bias, act, mode):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        w2 = w4.reshape(w4.shape[0], -1)
+        need_pre = act != nat.LIN_NONE
+        out = nat.linear_mfma_fwd(x2, w2, bias, act=act, mode=mode, want_pre=need_pre)
+        y, pre = out if need_pre else (out, None)
+        ctx.save_for_backward(x2, w2, pre)
+        ctx.act, ctx.mode, ctx.shp, ctx.wshape, ctx.has_bias = act, mode, shp, w4.shape, bias is not None
+        return y.reshape(*shp[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w2, pre = ctx.saved_tensors
+        dx, dw, db = nat.linear_mfma_bwd(x2, w2, pre, dy.reshape(-1, w2.shape[0]).contiguous(), act=ctx.act, mode=ctx.mode,
+                                         need_dx=ctx.needs_input_grad[0], need_db=ctx.has_bias)
+        return (dx.reshape(ctx.shp) if dx is not None else None), dw.reshape(ctx.wshape), db, None, None
+
+
+class _BNActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mod, act):
+        Cn = x.shape[-1]
+        bn = nat.make_bn(gamma, beta, mod.running_mean, mod.running_var, momentum=mod.momentum, eps=mod.eps,
+                         training=mod.training)
+        y, ss, mr = nat.bn_act_fwd(x.contiguous(), bn, act, Cn)
+        if mod.training:
+            mod.num_batches_tracked += 1
+        ctx.save_for_backward(x, ss, mr)
+        ctx.act, ctx.training, ctx.Cn = act, mod.training, Cn
+        return y
+
+    @staticmethod
+    def backward(ctx, da):
+        x, ss, mr = ctx.saved_tensors
+        dx, dg, db = nat.bn_act_bwd(x.contiguous(), da.contiguous(), ss, mr, ctx.act, ctx.training, ctx.Cn)
+        return dx, dg, db, None, None
+
+
+class _DWFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, k, stride):
+        ctx.save_for_backward(x, w)
+        ctx.k, ctx.stride = k, stride
+        return nat.dwconv_nhwc_fwd(x.contiguous(), w.contiguous(), k, stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw = nat.dwconv_nhwc_bwd(x.contiguous(), w.contiguous(), dy.contiguous(), ctx.k, ctx.stride)
+        return dx, dw, None, None
+
+
+class _PoolFn(torch.autograd.Function):       # (B,H,W,C) -> (B,C) mean
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, Cn = x.shape
+        ctx.shp = (B, H * W, Cn)
+        ctx.full = x.shape
+        return nat.pool_hw_fwd(x.reshape(B, H * W, Cn))
+
+    @staticmethod
+    def backward(ctx, ds):
+        return nat.scale_pool_bwd(None, None, ds.contiguous(), ctx.shp).reshape(ctx.full)
+
+
+class _ScaleFn(torch.autograd.Function):      # y[b,h,w,c] = x[b,h,w,c] * gate[b,c]
+    @staticmethod
+    def forward(ctx, x, gate):
+        B, H, W, Cn = x.shape
+        ctx.save_for_backward(x, gate)
+        return nat.scale_bc_fwd(x.reshape(B, H * W, Cn), gate.contiguous()).reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gate = ctx.saved_tensors
+        B, H, W, Cn = x.shape
+        dy3, x3 = dy.contiguous().reshape(B, H * W, Cn), x.reshape(B, H * W, Cn)
+        dx = nat.scale_pool_bwd(dy3, gate.contiguous(), None, (B, H * W, Cn)).reshape(x.shape)
+        return dx, nat.scale_bc_bwd_gate(x3, dy3)
+
+
+class _StemFn(torch.autograd.Function):       # Conv2d(1, C, 3, stride 2, pad 1): patches + GEMM; (B,1,H,W) -> (B,Ho,Wo,C)
+    @staticmethod
+    def forward(ctx, x, w4, mode):
+        B, _, H, W = x.shape
+        cols = nat.im2col3x3s2(x.reshape(B, H, W).contiguous())
+        w2 = w4.reshape(w4.shape[0], 9)
+        ctx.save_for_backward(cols, w2)
+        ctx.mode, ctx.wshape = mode, w4.shape
+        return nat.linear_mfma_fwd(cols, w2, None, mode=mode).reshape(B, (H + 1) // 2, (W + 1) // 2, w4.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, w2 = ctx.saved_tensors
+        _, dw, _ = nat.linear_mfma_bwd(cols, w2, None, dy.reshape(-1, w2.shape[0]).contiguous(), mode=ctx.mode, need_dx=False,
+                                       need_db=False)
+        return None, dw.reshape(ctx.wshape), None
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return nat.add_f32(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+# ------------------------------------------------------------------------------------------ modules (torchvision's tree)
+class _Conv(nn.Module):
+    """Parameter holder shaped like nn.Conv2d(bias=False): ``weight`` (Cout, Cin/groups, k, k)."""
+
+    def __init__(self, cin, cout, k, stride=1, groups=1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin // groups, k, k))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out")          # torchvision's MobileNetV3 initialisation
+        self.k, self.stride, self.groups = k, stride, groups
+
+
+class _BN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight, self.bias = nn.Parameter(torch.ones(c)), nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps, self.momentum = 0.001, 0.01
+
+
+class ConvBNAct(nn.Sequential):
+    """Conv2dNormActivation: children ``0`` (conv), ``1`` (BatchNorm2d); the activation is fused into the BN pass."""
+
+    def __init__(self, cin, cout, k, stride=1, groups=1, act=None, mode=torch.float32, stem=False):
+        super().__init__(_Conv(cin, cout, k, stride, groups), _BN(cout))
+        self.act, self.mode, self.stem, self.depthwise = _ACT[act], mode, stem, groups > 1
+
+    def forward(self, x):
+        conv, bn = self[0], self[1]
+        if self.stem:
+            y = _StemFn.apply(x, conv.weight, self.mode)
+        elif self.depthwise:
+            y = _DWFn.apply(x, conv.weight, conv.k, conv.stride)
+        else:
+            y = _PWFn.apply(x, conv.weight, None, nat.LIN_NONE, self.mode)
+        return _BNActFn.apply(y, bn.weight, bn.bias, bn, self.act)
+
+
+class _FC(nn.Module):
+    """nn.Conv2d(cin, cout, 1) parameter holder (the SE block's fc1 / fc2)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 1, 1))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out")
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class SqueezeExcitation(nn.Module):
+    def __init__(self, c, cs, mode):
+        super().__init__()
+        self.fc1, self.fc2, self.mode = _FC(c, cs), _FC(cs, c), mode
+
+    def forward(self, x):
+        s = _PoolFn.apply(x)
+        s = _PWFn.apply(s, self.fc1.weight, self.fc1.bias, nat.LIN_RELU, self.mode)
+        s = _PWFn.apply(s, self.fc2.weight, self.fc2.bias, nat.LIN_HARDSIGMOID, self.mode)
+        return _ScaleFn.apply(x, s)
+
+
+class InvertedResidual(nn.Module):
+    def __init__(self, cin, k, exp, cout, use_se, act, stride, mode):
+        super().__init__()
+        layers = []
+        if exp != cin:
+            layers.append(ConvBNAct(cin, exp, 1, act=act, mode=mode))
+        layers.append(ConvBNAct(exp, exp, k, stride, groups=exp, act=act, mode=mode))
+        if use_se:
+            layers.append(SqueezeExcitation(exp, _make_divisible(exp // 4, 8), mode))
+        layers.append(ConvBNAct(exp, cout, 1, act=None, mode=mode))
+        self.block = nn.Sequential(*layers)
+        self.use_res_connect = stride == 1 and cin == cout
+
+    def forward(self, x):
+        y = self.block(x)
+        return _AddFn.apply(x, y) if self.use_res_connect else y
+
+
+class _MobileNet(nn.Module):
+    def __init__(self, num_classes, dropout, mode, dropout_seed):
+        super().__init__()
+        feats = [ConvBNAct(1, 16, 3, 2, act="HS", mode=mode, stem=True)]
+        feats += [InvertedResidual(*c, mode=mode) for c in SMALL_CONF]
+        feats.append(ConvBNAct(SMALL_CONF[-1][3], LAST_CONV, 1, act="HS", mode=mode))
+        self.features = nn.Sequential(*feats)
+        self.classifier = MobileNetV3Head(LAST_CONV, LAST_CHANNEL, num_classes, dropout=dropout, mode=mode,
+                                          dropout_seed=dropout_seed)
+
+
+class MobileNetV3Wakeword(nn.Module):
+    def __init__(self, num_classes: int = 2, pretrained: bool = False, dropout: float = 0.3, input_channels: int = 1,
+                 mode="fp32", dropout_seed: int = 0):
+        super().__init__()
+        if pretrained:
+            raise ValueError("pretrained ImageNet weights cannot be downloaded in this build (pass pretrained=False)")
+        if input_channels != 1:
+            raise ValueError(f"mobilenetv3: the native stem takes one-channel spectrograms, got input_channels={input_channels}")
+        m = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(mode, mode)
+        nat.act_code(m)
+        self.mobilenet = _MobileNet(num_classes, dropout, m, dropout_seed)
+
+    @property
+    def sample_offset(self):
+        return self.mobilenet.classifier[0].sample_offset
+
+    @sample_offset.setter
+    def sample_offset(self, v):
+        self.mobilenet.classifier[0].sample_offset = v
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            raise nat.NativeError("mobilenetv3 runs on hand-written HIP kernels only: the input is on "
+                                  f"'{x.device}', need an MI355X ('cuda') device -- there is no CPU fallback")
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"mobilenetv3 expects (B,1,F,T) features, got {tuple(x.shape)}")
+        h = self.mobilenet.features(x.float().contiguous())          # (B,H,W,C) channels-last all the way
+        return self.mobilenet.classifier(_PoolFn.apply(h))
