@@ -266,7 +266,11 @@ def test_model_and_loss_factories_fail_loudly_without_gpu():
     with pytest.raises(ValueError, match="Unknown architecture"):
         create_model("vit")
     with pytest.raises(ValueError, match="outside this build"):
-        create_model("mobilenetv3")
+        create_model("resnet18")
+    for arch in ("mobilenetv3", "gru", "crnn"):                      # built, and just as loud off the GPU
+        mm = create_model(arch)
+        with pytest.raises(NativeError, match="no CPU fallback"):
+            mm(torch.zeros(2, 1, 40, 151))
     with pytest.raises(ValueError):
         create_model("cnn_small", num_classes=3)
     crit = create_loss_function("cross_entropy", label_smoothing=0.05, device="cpu")
