@@ -1,4 +1,4 @@
-"""BASELINE config 5's model on one GPU: CRNN (conv front-end + 2-layer bidirectional GRU) training step -- log-mel front end,
+"""BASELINE configs 3 and 5 on one GPU (MobileNetV3 with the reference head at the per-GPU and the global batch; CRNN (conv front-end + 2-layer bidirectional GRU) training step -- log-mel front end,
 forward, native loss, backward, clip, AdamW -- at batch 4096 (and 512), inputs resident in HBM.  Secondary measurement:
 bench.py's headline line stays BASELINE config 2."""
 import contextlib
@@ -17,21 +17,22 @@ from wakeword_trainer_home_amd.models import create_model
 from wakeword_trainer_home_amd.training import Trainer
 
 dev = "cuda:0"
-CONFIGS = (("crnn", 512, "bf16"), ("crnn", 4096, "bf16"), ("gru", 4096, "fp32"))
+CONFIGS = (("crnn", 512, "bf16"), ("crnn", 4096, "bf16"), ("gru", 4096, "fp32"), ("mobilenetv3", 256, "bf16"),
+           ("mobilenetv3", 2048, "bf16"))
 if len(sys.argv) > 1:                         # e.g.  bench_crnn.py crnn 4096 bf16
     CONFIGS = ((sys.argv[1], int(sys.argv[2]), sys.argv[3]),)
 for arch, B, act in CONFIGS:
     cfg = get_preset("cnn_small_logmel40")
     cfg.training.batch_size = B
     torch.manual_seed(0)
-    kw = {"act_dtype": act} if arch == "crnn" else {}
+    kw = {"act_dtype": act} if arch == "crnn" else ({"mode": act} if arch == "mobilenetv3" else {})
     model = create_model(arch, dropout=0.3, **kw)
     with contextlib.redirect_stdout(sys.stderr):
         tr = Trainer(model, [], [], cfg, checkpoint_dir=Path(tempfile.mkdtemp()), device=dev)
     tr.model.train()
     pool = [make_synthetic_batch(B, 24000, seed=i, device=dev) for i in range(2)]
     classes = ["logmel_specaug", "conv_stem_fwd", "dwconv3x3_fwd", "pwconv1x1_fwd", "pwconv1x1_bwd", "dwconv3x3_bwd", "conv_stem_bwd",
-               "finalize", "gru", "linear_mfma"]
+               "finalize", "gru", "linear_mfma", "nhwc_layers"]
 
     def step(i):
         tr._step_generic(*pool[i % 2], i)

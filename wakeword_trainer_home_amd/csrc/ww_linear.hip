@@ -410,10 +410,18 @@ extern "C" int ww_linear_mfma_fwd(ww_ctx *ctx, int mode, const float *x, const f
     return launch_gemm<true, true, true>(mode, A, B, K, y, N, e, (hipStream_t)stream);
 }
 
-constexpr int DW_SPLITS = 4;     // K splits of the weight-gradient product (its contraction runs over the batch)
+// K splits of the weight-gradient product dW (N x K) = dpre^T x: its contraction runs over the M rows (batch x pixels), which
+// for a 1x1 convolution is hundreds of thousands while N x K is a handful of 64 x 64 tiles -- the splits are what fills the
+// chip: enough of them for ~1024 workgroups, each at least 512 rows deep
+static int dw_splits(int M, int K, int N) {
+    const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
+    long s = (1024 + tiles - 1) / tiles;
+    s = std::min<long>(s, M / 512);
+    return (int)std::max<long>(1, std::min<long>(s, 256));
+}
 extern "C" size_t ww_linear_mfma_bwd_scratch_bytes(int M, int K, int N) {
     if (M < 1 || K < 1 || N < 1) return 0;
-    return ((size_t)M * N + (size_t)DW_SPLITS * N * K) * sizeof(float);      // dpre + split-K partial products of dW
+    return ((size_t)M * N + (size_t)dw_splits(M, K, N) * N * K) * sizeof(float);      // dpre + split-K partial products of dW
 }
 
 extern "C" int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const float *w, const float *pre, const float *dy,
@@ -444,7 +452,7 @@ extern "C" int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const f
     {           // dw[n][k] = sum_m dpre[m][n] x[m][k] : A(n, m) = dpre[m][n], B(k, m) = x[m][k]
         const GemmOperand A{dpre, 1, N, N}, B{x, 1, K, K};
         float *part = (float *)scratch + (size_t)M * N;
-        if ((rc = launch_gemm<false, false, false>(mode, A, B, M, dw, K, none, st, M >= 1024 ? DW_SPLITS : 1, part))) return rc;
+        if ((rc = launch_gemm<false, false, false>(mode, A, B, M, dw, K, none, st, dw_splits(M, K, N), part))) return rc;
     }
     if (db) {
         hipLaunchKernelGGL(k_colsum_any, dim3((N + 63) / 64), dim3(1024), 0, st, dpre, M, N, db);

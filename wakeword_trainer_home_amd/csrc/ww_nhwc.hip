@@ -25,27 +25,27 @@ __device__ __forceinline__ float act_grad(int act, float z) {
     return 1.f;
 }
 
-constexpr int NCHUNK = 64;      // row chunks of the column reductions
+constexpr int NCHUNK = 256;     // max row chunks of the column reductions (one workgroup each)
 
-// partial[chunk][0:C] = sum x, [C:2C] = sum x^2 over the chunk's rows.  grid (ceil(C/64), chunks), block 1024
-__global__ __launch_bounds__(1024) void k_colstats(const float *__restrict__ x, long M, int C, long rows_per_chunk,
+// Column reductions over a tall (M, C) matrix with ANY C <= 1024: a block has C*R threads, thread t owns column t % C and rows
+// r0 + t / C (+R, +2R, ...), so consecutive threads read consecutive addresses whatever C is (a 64-column tiling would
+// leave 3/4 of the lanes idle at C = 16); one block per row chunk, partials finished in fixed order afterwards.
+// partial[chunk][0:C] = sum x, [C:2C] = sum x^2 over the chunk's rows.  grid = chunks, block = C*R, smem = 2*R*C doubles
+__global__ __launch_bounds__(1024) void k_colstats(const float *__restrict__ x, long M, int C, int R, long rows_per_chunk,
                                                    float *__restrict__ part) {
-    __shared__ double sh[2][16][64];
-    const int c = threadIdx.x & 63, p = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
-    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    extern __shared__ double red[];
+    const int c = threadIdx.x % C, r = threadIdx.x / C;
+    const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
     double s = 0.0, q = 0.0;
-    if (col < C) {
 #pragma unroll 4
-        for (long r = r0 + p; r < r1; r += 16) { const double v = x[r * C + col]; s += v; q += v * v; }
-    }
-    sh[0][p][c] = s; sh[1][p][c] = q;
+    for (long row = r0 + r; row < r1; row += R) { const double v = x[row * C + c]; s += v; q += v * v; }
+    red[r * C + c] = s; red[(R + r) * C + c] = q;
     __syncthreads();
-    if (p == 0 && col < C) {
+    if (r == 0) {
         double a = 0.0, b = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { a += sh[0][i][c]; b += sh[1][i][c]; }
-        part[(long)blockIdx.y * 2 * C + col] = (float)a;
-        part[(long)blockIdx.y * 2 * C + C + col] = (float)b;
+        for (int i = 0; i < R; ++i) { a += red[i * C + c]; b += red[(R + i) * C + c]; }
+        part[(long)blockIdx.x * 2 * C + c] = (float)a;
+        part[(long)blockIdx.x * 2 * C + C + c] = (float)b;
     }
 }
 // BatchNorm2d statistics -> scale|shift (ss) and mean|rstd (mr); torch semantics for the running statistics
@@ -82,32 +82,29 @@ __global__ __launch_bounds__(256) void k_bn_act_apply(const float *__restrict__ 
         y[i] = act_fwd(act, fmaf(x[i], ss[c], ss[C + c]));
     }
 }
-// backward pass 1: dz = da * act'(z); partial sums of dz and dz*xhat
+// backward pass 1: dz = da * act'(z); partial sums of dz and dz*xhat (same thread layout as k_colstats)
 __global__ __launch_bounds__(1024) void k_bnact_bwd_stats(const float *__restrict__ x, const float *__restrict__ da,
                                                           const float *__restrict__ ss, const float *__restrict__ mr, long M,
-                                                          int C, int act, long rows_per_chunk, float *__restrict__ part) {
-    __shared__ double sh[2][16][64];
-    const int c = threadIdx.x & 63, p = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
-    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+                                                          int C, int R, int act, long rows_per_chunk, float *__restrict__ part) {
+    extern __shared__ double red[];
+    const int c = threadIdx.x % C, r = threadIdx.x / C;
+    const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    const float sc = ss[c], sf = ss[C + c], mu = mr[c], rs = mr[C + c];
     double s1 = 0.0, s2 = 0.0;
-    if (col < C) {
-        const float sc = ss[col], sf = ss[C + col], mu = mr[col], rs = mr[C + col];
 #pragma unroll 4
-        for (long r = r0 + p; r < r1; r += 16) {
-            const float xv = x[r * C + col];
-            const float dz = da[r * C + col] * act_grad(act, fmaf(xv, sc, sf));
-            s1 += dz;
-            s2 += (double)dz * (double)((xv - mu) * rs);
-        }
+    for (long row = r0 + r; row < r1; row += R) {
+        const float xv = x[row * C + c];
+        const float dz = da[row * C + c] * act_grad(act, fmaf(xv, sc, sf));
+        s1 += dz;
+        s2 += (double)dz * (double)((xv - mu) * rs);
     }
-    sh[0][p][c] = s1; sh[1][p][c] = s2;
+    red[r * C + c] = s1; red[(R + r) * C + c] = s2;
     __syncthreads();
-    if (p == 0 && col < C) {
+    if (r == 0) {
         double a = 0.0, b = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { a += sh[0][i][c]; b += sh[1][i][c]; }
-        part[(long)blockIdx.y * 2 * C + col] = (float)a;
-        part[(long)blockIdx.y * 2 * C + C + col] = (float)b;
+        for (int i = 0; i < R; ++i) { a += red[i * C + c]; b += red[(R + i) * C + c]; }
+        part[(long)blockIdx.x * 2 * C + c] = (float)a;
+        part[(long)blockIdx.x * 2 * C + C + c] = (float)b;
     }
 }
 __global__ void k_bnact_bwd_finish(const float *__restrict__ part, int chunks, int C, float *__restrict__ sums,
@@ -204,38 +201,47 @@ __global__ __launch_bounds__(256) void k_dwg_bwd_dx(const float *__restrict__ dy
             if (4 * cq + e < g.C) xp[e] = acc[e];
     }
 }
-// dw[c][tap] partials: block = 64 channels x 4 pixel lanes... grid (ceil(C/64), chunks): part[chunk][C*k*k]
-__global__ __launch_bounds__(256) void k_dwg_bwd_dw(const float *__restrict__ x, const float *__restrict__ dy, DwG g,
-                                                    long px_per_chunk, float *__restrict__ part) {
-    __shared__ float sh[4][64][25];
-    const int c = threadIdx.x & 63, lane_p = threadIdx.x >> 6, col = blockIdx.x * 64 + c, pad = g.k / 2, kk = g.k * g.k;
+// dw[c][tap] partials over a chunk of output pixels (thread layout of k_colstats): part[chunk][C*k*k]
+__global__ __launch_bounds__(1024) void k_dwg_bwd_dw(const float *__restrict__ x, const float *__restrict__ dy, DwG g, int R,
+                                                     long px_per_chunk, float *__restrict__ part) {
+    extern __shared__ float redf[];           // [R][C]
+    const int c = threadIdx.x % g.C, r = threadIdx.x / g.C, pad = g.k / 2, kk = g.k * g.k;
     const long P = (long)g.B * g.Ho * g.Wo;
-    const long p0 = (long)blockIdx.y * px_per_chunk, p1 = min(P, p0 + px_per_chunk);
+    const long p0 = (long)blockIdx.x * px_per_chunk, p1 = min(P, p0 + px_per_chunk);
     float acc[25];
 #pragma unroll
     for (int t = 0; t < 25; ++t) acc[t] = 0.f;
-    if (col < g.C) {
-        for (long p = p0 + lane_p; p < p1; p += 4) {
-            const int wo = (int)(p % g.Wo);
-            const long q = p / g.Wo;
-            const int ho = (int)(q % g.Ho), b = (int)(q / g.Ho);
-            const float d = dy[(size_t)p * g.C + col];
-            for (int kh = 0; kh < g.k; ++kh) {
-                const int hi = ho * g.s + kh - pad;
-                if (hi < 0 || hi >= g.H) continue;
-                for (int kw = 0; kw < g.k; ++kw) {
-                    const int wi = wo * g.s + kw - pad;
-                    if (wi < 0 || wi >= g.W) continue;
-                    acc[kh * g.k + kw] = fmaf(d, x[(((size_t)b * g.H + hi) * g.W + wi) * g.C + col], acc[kh * g.k + kw]);
-                }
+    for (long p = p0 + r; p < p1; p += R) {
+        const int wo = (int)(p % g.Wo);
+        const long q = p / g.Wo;
+        const int ho = (int)(q % g.Ho), b = (int)(q / g.Ho);
+        const float d = dy[(size_t)p * g.C + c];
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh) {
+            const int hi = ho * g.s + kh - pad;
+            if (kh >= g.k || hi < 0 || hi >= g.H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw) {
+                const int wi = wo * g.s + kw - pad;
+                if (kw >= g.k || wi < 0 || wi >= g.W) continue;
+                acc[kh * 5 + kw] = fmaf(d, x[(((size_t)b * g.H + hi) * g.W + wi) * g.C + c], acc[kh * 5 + kw]);
             }
         }
     }
-    for (int t = 0; t < kk; ++t) sh[lane_p][c][t] = acc[t];
-    __syncthreads();
-    if (lane_p == 0 && col < g.C)
-        for (int t = 0; t < kk; ++t)
-            part[(size_t)blockIdx.y * g.C * kk + (size_t)col * kk + t] = sh[0][c][t] + sh[1][c][t] + sh[2][c][t] + sh[3][c][t];
+    for (int kh = 0; kh < g.k; ++kh)
+        for (int kw = 0; kw < g.k; ++kw) {
+            __syncthreads();
+            float v = 0.f;                    // acc is indexed with compile-time constants only (no scratch)
+#pragma unroll
+            for (int a5 = 0; a5 < 25; ++a5) v = (a5 == kh * 5 + kw) ? acc[a5] : v;
+            redf[r * g.C + c] = v;
+            __syncthreads();
+            if (r == 0) {
+                float t = 0.f;
+                for (int i = 0; i < R; ++i) t += redf[i * g.C + c];
+                part[(size_t)blockIdx.x * g.C * kk + (size_t)c * kk + kh * g.k + kw] = t;
+            }
+        }
 }
 
 // ---- squeeze-excitation / pooling pieces on (B, HW, C)
@@ -304,7 +310,8 @@ __global__ __launch_bounds__(256) void k_add(const float *__restrict__ a, const 
 }
 
 inline int egrid(long n) { return (int)std::min<long>((n + 255) / 256, 256 * 32); }
-inline int chunks_for(long M) { return (int)std::max<long>(1, std::min<long>(NCHUNK, M / 32)); }
+inline int rows_r(int C) { return std::max(1, 1024 / C); }                       // row lanes R of a C*R-thread block
+inline int chunks_for(long M, int C) { return (int)std::max<long>(1, std::min<long>(NCHUNK, M / (4L * rows_r(C)))); }
 
 }  // namespace
 
@@ -320,9 +327,11 @@ extern "C" int ww_bn_act_fwd(ww_ctx *ctx, const float *x, long M, int C, const w
     hipStream_t st = (hipStream_t)stream;
     ww_prof_scope ps_(ctx, WW_K_NHWC, st);
     float *part = (float *)scratch;
-    const int chunks = chunks_for(M);
+    WW_REQUIRE(C <= 1024, WW_E_UNSUPPORTED, "ww_bn_act_fwd: C=%d > 1024", C);
+    const int chunks = chunks_for(M, C), R = rows_r(C);
     if (bn->training) {
-        hipLaunchKernelGGL(k_colstats, dim3((C + 63) / 64, chunks), dim3(1024), 0, st, x, M, C, (M + chunks - 1) / chunks, part);
+        hipLaunchKernelGGL(k_colstats, dim3(chunks), dim3(C * R), (size_t)2 * R * C * sizeof(double), st, x, M, C, R,
+                           (M + chunks - 1) / chunks, part);
         WW_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_bn_finish, dim3((C + 127) / 128), dim3(128), 0, st, part, chunks, M, C, *bn, ss, mr);
@@ -339,9 +348,10 @@ extern "C" int ww_bn_act_bwd(ww_ctx *ctx, const float *x, const float *da, long 
     hipStream_t st = (hipStream_t)stream;
     ww_prof_scope ps_(ctx, WW_K_NHWC, st);
     float *part = (float *)scratch, *sums = part + (size_t)NCHUNK * 2 * C;
-    const int chunks = chunks_for(M);
-    hipLaunchKernelGGL(k_bnact_bwd_stats, dim3((C + 63) / 64, chunks), dim3(1024), 0, st, x, da, ss, mr, M, C, act,
-                       (M + chunks - 1) / chunks, part);
+    WW_REQUIRE(C <= 1024, WW_E_UNSUPPORTED, "ww_bn_act_bwd: C=%d > 1024", C);
+    const int chunks = chunks_for(M, C), R = rows_r(C);
+    hipLaunchKernelGGL(k_bnact_bwd_stats, dim3(chunks), dim3(C * R), (size_t)2 * R * C * sizeof(double), st, x, da, ss, mr, M, C, R,
+                       act, (M + chunks - 1) / chunks, part);
     WW_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bnact_bwd_finish, dim3((C + 127) / 128), dim3(128), 0, st, part, chunks, C, sums, dgamma, dbeta);
     WW_LAUNCH_CHECK();
@@ -381,10 +391,12 @@ extern "C" int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, c
         hipLaunchKernelGGL(k_dwg_bwd_dx, dim3(egrid((long)B * H * W * ((C + 3) / 4))), dim3(256), 0, st, dy, w, g, dx);
         WW_LAUNCH_CHECK();
     }
+    WW_REQUIRE(C <= 1024, WW_E_UNSUPPORTED, "ww_dwconv_nhwc_bwd: C=%d > 1024", C);
     const long P = (long)B * g.Ho * g.Wo;
-    const int chunks = chunks_for(P);
+    const int chunks = chunks_for(P, C), R = rows_r(C);
     float *part = (float *)scratch;
-    hipLaunchKernelGGL(k_dwg_bwd_dw, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, dy, g, (P + chunks - 1) / chunks, part);
+    hipLaunchKernelGGL(k_dwg_bwd_dw, dim3(chunks), dim3(C * R), (size_t)R * C * sizeof(float), st, x, dy, g, R,
+                       (P + chunks - 1) / chunks, part);
     WW_LAUNCH_CHECK();
     return ww_colsum_rows_small(part, chunks, C * k * k, dw, st);
 }
