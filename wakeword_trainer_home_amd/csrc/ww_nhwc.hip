@@ -48,15 +48,31 @@ __global__ __launch_bounds__(1024) void k_colstats(const float *__restrict__ x, 
         part[(long)blockIdx.x * 2 * C + C + c] = (float)b;
     }
 }
-// BatchNorm2d statistics -> scale|shift (ss) and mean|rstd (mr); torch semantics for the running statistics
-__global__ void k_bn_finish(const float *__restrict__ part, int chunks, long M, int C, ww_bn_t bn, float *__restrict__ ss,
-                            float *__restrict__ mr) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// fixed-order sum of the chunk partials of 64 columns by 16 row lanes: tot0/tot1 valid in the threads with p == 0
+__device__ __forceinline__ void chunk_sums(const float *__restrict__ part, int chunks, int C, int col, int p, int c,
+                                           double (*sh)[16][64], double &tot0, double &tot1) {
+    double s = 0.0, q = 0.0;
+    if (col < C)
+        for (int i = p; i < chunks; i += 16) { s += part[(long)i * 2 * C + col]; q += part[(long)i * 2 * C + C + col]; }
+    sh[0][p][c] = s; sh[1][p][c] = q;
+    __syncthreads();
+    tot0 = tot1 = 0.0;
+    if (p == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { tot0 += sh[0][i][c]; tot1 += sh[1][i][c]; }
+    }
+}
+// BatchNorm2d statistics -> scale|shift (ss) and mean|rstd (mr); torch semantics for the running statistics.
+// grid ceil(C/64), block 1024 (64 columns x 16 chunk lanes)
+__global__ __launch_bounds__(1024) void k_bn_finish(const float *__restrict__ part, int chunks, long M, int C, ww_bn_t bn,
+                                                    float *__restrict__ ss, float *__restrict__ mr) {
+    __shared__ double sh[2][16][64];
+    const int cl = threadIdx.x & 63, p = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    double s = 0.0, q = 0.0;
+    if (bn.training) chunk_sums(part, chunks, C, c, p, cl, sh, s, q);
+    if (p != 0 || c >= C) return;
     double mean, var;
     if (bn.training) {
-        double s = 0.0, q = 0.0;
-        for (int i = 0; i < chunks; ++i) { s += part[(long)i * 2 * C + c]; q += part[(long)i * 2 * C + C + c]; }
         mean = s / (double)M;
         var = q / (double)M - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -107,12 +123,14 @@ __global__ __launch_bounds__(1024) void k_bnact_bwd_stats(const float *__restric
         part[(long)blockIdx.x * 2 * C + C + c] = (float)b;
     }
 }
-__global__ void k_bnact_bwd_finish(const float *__restrict__ part, int chunks, int C, float *__restrict__ sums,
-                                   float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < chunks; ++i) { s1 += part[(long)i * 2 * C + c]; s2 += part[(long)i * 2 * C + C + c]; }
+__global__ __launch_bounds__(1024) void k_bnact_bwd_finish(const float *__restrict__ part, int chunks, int C,
+                                                           float *__restrict__ sums, float *__restrict__ dgamma,
+                                                           float *__restrict__ dbeta) {
+    __shared__ double sh[2][16][64];
+    const int cl = threadIdx.x & 63, p = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    double s1, s2;
+    chunk_sums(part, chunks, C, c, p, cl, sh, s1, s2);
+    if (p != 0 || c >= C) return;
     sums[c] = (float)s1; sums[C + c] = (float)s2;
     dgamma[c] = (float)s2; dbeta[c] = (float)s1;
 }
@@ -140,7 +158,8 @@ __global__ __launch_bounds__(256) void k_bnact_bwd_apply(const float *__restrict
 struct DwG { int B, H, W, C, k, s, Ho, Wo; };
 __global__ __launch_bounds__(256) void k_dwg_fwd(const float *__restrict__ x, const float *__restrict__ w, DwG g,
                                                  float *__restrict__ y) {
-    const int c4n = (g.C + 3) / 4, pad = g.k / 2;
+    const int c4n = (g.C + 3) / 4, pad = g.k / 2, kk = g.k * g.k;
+    const bool vec = (g.C & 3) == 0;
     const long n = (long)g.B * g.Ho * g.Wo * c4n;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int cq = (int)(i % c4n);
@@ -156,21 +175,33 @@ __global__ __launch_bounds__(256) void k_dwg_fwd(const float *__restrict__ x, co
                 const int wi = wo * g.s + kw - pad;
                 if (wi < 0 || wi >= g.W) continue;
                 const float *xp = x + (((size_t)b * g.H + hi) * g.W + wi) * g.C + 4 * cq;
+                if (vec) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(xp);
+                    const float *wp = w + (size_t)(4 * cq) * kk + kh * g.k + kw;
+                    acc[0] = fmaf(xv.x, wp[0], acc[0]); acc[1] = fmaf(xv.y, wp[kk], acc[1]);
+                    acc[2] = fmaf(xv.z, wp[2 * kk], acc[2]); acc[3] = fmaf(xv.w, wp[3 * kk], acc[3]);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * cq + e < g.C) acc[e] = fmaf(xp[e], w[(size_t)(4 * cq + e) * g.k * g.k + kh * g.k + kw], acc[e]);
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * cq + e < g.C) acc[e] = fmaf(xp[e], w[(size_t)(4 * cq + e) * kk + kh * g.k + kw], acc[e]);
+                }
             }
         }
         float *yp = y + (((size_t)b * g.Ho + ho) * g.Wo + wo) * g.C + 4 * cq;
+        if (vec) {
+            *reinterpret_cast<float4 *>(yp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (4 * cq + e < g.C) yp[e] = acc[e];
+            for (int e = 0; e < 4; ++e)
+                if (4 * cq + e < g.C) yp[e] = acc[e];
+        }
     }
 }
 // dx[b,hi,wi,c] = sum over taps with (hi + pad - kh) divisible by s of w[c,kh,kw] * dy[b,(hi+pad-kh)/s,(wi+pad-kw)/s,c]
 __global__ __launch_bounds__(256) void k_dwg_bwd_dx(const float *__restrict__ dy, const float *__restrict__ w, DwG g,
                                                     float *__restrict__ dx) {
-    const int c4n = (g.C + 3) / 4, pad = g.k / 2;
+    const int c4n = (g.C + 3) / 4, pad = g.k / 2, kk = g.k * g.k;
+    const bool vec = (g.C & 3) == 0;
     const long n = (long)g.B * g.H * g.W * c4n;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int cq = (int)(i % c4n);
@@ -190,15 +221,26 @@ __global__ __launch_bounds__(256) void k_dwg_bwd_dx(const float *__restrict__ dy
                 const int wo = tw / g.s;
                 if (wo >= g.Wo) continue;
                 const float *dp = dy + (((size_t)b * g.Ho + ho) * g.Wo + wo) * g.C + 4 * cq;
+                if (vec) {
+                    const float4 dv = *reinterpret_cast<const float4 *>(dp);
+                    const float *wp = w + (size_t)(4 * cq) * kk + kh * g.k + kw;
+                    acc[0] = fmaf(dv.x, wp[0], acc[0]); acc[1] = fmaf(dv.y, wp[kk], acc[1]);
+                    acc[2] = fmaf(dv.z, wp[2 * kk], acc[2]); acc[3] = fmaf(dv.w, wp[3 * kk], acc[3]);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * cq + e < g.C) acc[e] = fmaf(dp[e], w[(size_t)(4 * cq + e) * g.k * g.k + kh * g.k + kw], acc[e]);
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * cq + e < g.C) acc[e] = fmaf(dp[e], w[(size_t)(4 * cq + e) * kk + kh * g.k + kw], acc[e]);
+                }
             }
         }
         float *xp = dx + (((size_t)b * g.H + hi) * g.W + wi) * g.C + 4 * cq;
+        if (vec) {
+            *reinterpret_cast<float4 *>(xp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (4 * cq + e < g.C) xp[e] = acc[e];
+            for (int e = 0; e < 4; ++e)
+                if (4 * cq + e < g.C) xp[e] = acc[e];
+        }
     }
 }
 // dw[c][tap] partials over a chunk of output pixels (thread layout of k_colstats): part[chunk][C*k*k]
@@ -334,7 +376,7 @@ extern "C" int ww_bn_act_fwd(ww_ctx *ctx, const float *x, long M, int C, const w
                            (M + chunks - 1) / chunks, part);
         WW_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_bn_finish, dim3((C + 127) / 128), dim3(128), 0, st, part, chunks, M, C, *bn, ss, mr);
+    hipLaunchKernelGGL(k_bn_finish, dim3((C + 63) / 64), dim3(1024), 0, st, part, chunks, M, C, *bn, ss, mr);
     WW_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bn_act_apply, dim3(egrid(M * C)), dim3(256), 0, st, x, ss, M * C, C, act, y);
     WW_LAUNCH_CHECK();
@@ -353,7 +395,7 @@ extern "C" int ww_bn_act_bwd(ww_ctx *ctx, const float *x, const float *da, long 
     hipLaunchKernelGGL(k_bnact_bwd_stats, dim3(chunks), dim3(C * R), (size_t)2 * R * C * sizeof(double), st, x, da, ss, mr, M, C, R,
                        act, (M + chunks - 1) / chunks, part);
     WW_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bnact_bwd_finish, dim3((C + 127) / 128), dim3(128), 0, st, part, chunks, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(k_bnact_bwd_finish, dim3((C + 63) / 64), dim3(1024), 0, st, part, chunks, C, sums, dgamma, dbeta);
     WW_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bnact_bwd_apply, dim3(egrid(M * C)), dim3(256), 0, st, x, da, ss, mr, sums, M, C, act, training, dx);
     WW_LAUNCH_CHECK();
