@@ -405,8 +405,16 @@ def dropout_bt(x, p, seed=0, step=0, sample_offset=0, stream_id=0, out=None):
 
 
 # ---- generic channels-last layers (MobileNetV3 body); activations are contiguous fp32 (M, C) / (B, H, W, C) tensors
+_nhwc_scratch = {}
+
+
 def nhwc_scratch(Cn, dev):
-    return torch.empty(load().ww_nhwc_scratch_bytes(Cn) // 4, dtype=torch.float32, device=dev)
+    """Scratch of one layer call, cached per (C, device): calls on one stream are ordered, so the buffer can be shared."""
+    key = (Cn, dev)
+    buf = _nhwc_scratch.get(key)
+    if buf is None:
+        buf = _nhwc_scratch[key] = torch.empty(load().ww_nhwc_scratch_bytes(Cn) // 4, dtype=torch.float32, device=dev)
+    return buf
 
 
 def bn_act_fwd(x, bn: BN, act, Cn):
