@@ -117,3 +117,42 @@ def test_native_two_rank_step_equals_sharded_emulation(tmp_path):
             continue
         # Adam amplifies round-off-level gradient differences into lr-sized steps: 2 steps x lr 1e-3
         np.testing.assert_allclose(r0["sd"][k].numpy(), v.numpy(), atol=2.5e-3, err_msg=k)
+
+
+def _worker_generic(rank, world, port, out_dir, arch):
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    cfg = _cfg()
+    torch.manual_seed(70 + rank)                      # different initial weights per rank: the Trainer broadcasts rank 0's
+    model = create_model(arch, dropout=0.3, dropout_seed=5)
+    wave, y = _data()
+    batches = [(wave[16 * s + 8 * rank:16 * s + 8 * rank + 8], y[16 * s + 8 * rank:16 * s + 8 * rank + 8]) for s in range(2)]
+    t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=Path(out_dir) / f"ck{rank}", device="cuda:0")
+    assert t.world_size == world and not t.native
+    losses = []
+    t.add_callback(type("R", (), {"on_batch_end": lambda self, i, l, a: losses.append(l)})())
+    t.train_epoch(0)
+    torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "loss": losses}, Path(out_dir) / f"r{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("arch", ["crnn", "mobilenetv3"])
+def test_generic_models_train_data_parallel(tmp_path, arch):
+    """crnn / mobilenetv3 through the Trainer's generic step with 2 ranks: parameters broadcast from rank 0, gradients averaged
+    every step -> the replicas' weights stay identical (BatchNorm running statistics are per rank, as under DDP)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    port = _free_port()
+    mp.start_processes(_worker_generic, args=(2, port, str(tmp_path), arch), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "r1.pt", weights_only=False)
+    assert len(r0["loss"]) == 2 and all(np.isfinite(r0["loss"] + r1["loss"]))
+    for k in r0["sd"]:
+        if "running" in k or "num_batches" in k:
+            continue
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
