@@ -158,8 +158,11 @@ __global__ __launch_bounds__(256) void k_bnact_bwd_apply(const float *__restrict
 struct DwG { int B, H, W, C, k, s, Ho, Wo; };
 __global__ __launch_bounds__(256) void k_dwg_fwd(const float *__restrict__ x, const float *__restrict__ w, DwG g,
                                                  float *__restrict__ y) {
+    extern __shared__ __align__(16) float wl[];      // the layer's weights, transposed to [tap][C]: one ds_read_b128 per tap
     const int c4n = (g.C + 3) / 4, pad = g.k / 2, kk = g.k * g.k;
     const bool vec = (g.C & 3) == 0;
+    for (int i = threadIdx.x; i < g.C * kk; i += 256) wl[(i % kk) * g.C + i / kk] = w[i];
+    __syncthreads();
     const long n = (long)g.B * g.Ho * g.Wo * c4n;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int cq = (int)(i % c4n);
@@ -177,13 +180,13 @@ __global__ __launch_bounds__(256) void k_dwg_fwd(const float *__restrict__ x, co
                 const float *xp = x + (((size_t)b * g.H + hi) * g.W + wi) * g.C + 4 * cq;
                 if (vec) {
                     const float4 xv = *reinterpret_cast<const float4 *>(xp);
-                    const float *wp = w + (size_t)(4 * cq) * kk + kh * g.k + kw;
-                    acc[0] = fmaf(xv.x, wp[0], acc[0]); acc[1] = fmaf(xv.y, wp[kk], acc[1]);
-                    acc[2] = fmaf(xv.z, wp[2 * kk], acc[2]); acc[3] = fmaf(xv.w, wp[3 * kk], acc[3]);
+                    const float4 wv = *reinterpret_cast<const float4 *>(wl + (kh * g.k + kw) * g.C + 4 * cq);
+                    acc[0] = fmaf(xv.x, wv.x, acc[0]); acc[1] = fmaf(xv.y, wv.y, acc[1]);
+                    acc[2] = fmaf(xv.z, wv.z, acc[2]); acc[3] = fmaf(xv.w, wv.w, acc[3]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (4 * cq + e < g.C) acc[e] = fmaf(xp[e], w[(size_t)(4 * cq + e) * kk + kh * g.k + kw], acc[e]);
+                        if (4 * cq + e < g.C) acc[e] = fmaf(xp[e], wl[(kh * g.k + kw) * g.C + 4 * cq + e], acc[e]);
                 }
             }
         }
@@ -200,8 +203,11 @@ __global__ __launch_bounds__(256) void k_dwg_fwd(const float *__restrict__ x, co
 // dx[b,hi,wi,c] = sum over taps with (hi + pad - kh) divisible by s of w[c,kh,kw] * dy[b,(hi+pad-kh)/s,(wi+pad-kw)/s,c]
 __global__ __launch_bounds__(256) void k_dwg_bwd_dx(const float *__restrict__ dy, const float *__restrict__ w, DwG g,
                                                     float *__restrict__ dx) {
+    extern __shared__ __align__(16) float wl[];      // weights as [tap][C]
     const int c4n = (g.C + 3) / 4, pad = g.k / 2, kk = g.k * g.k;
     const bool vec = (g.C & 3) == 0;
+    for (int i = threadIdx.x; i < g.C * kk; i += 256) wl[(i % kk) * g.C + i / kk] = w[i];
+    __syncthreads();
     const long n = (long)g.B * g.H * g.W * c4n;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int cq = (int)(i % c4n);
@@ -223,13 +229,13 @@ __global__ __launch_bounds__(256) void k_dwg_bwd_dx(const float *__restrict__ dy
                 const float *dp = dy + (((size_t)b * g.Ho + ho) * g.Wo + wo) * g.C + 4 * cq;
                 if (vec) {
                     const float4 dv = *reinterpret_cast<const float4 *>(dp);
-                    const float *wp = w + (size_t)(4 * cq) * kk + kh * g.k + kw;
-                    acc[0] = fmaf(dv.x, wp[0], acc[0]); acc[1] = fmaf(dv.y, wp[kk], acc[1]);
-                    acc[2] = fmaf(dv.z, wp[2 * kk], acc[2]); acc[3] = fmaf(dv.w, wp[3 * kk], acc[3]);
+                    const float4 wv = *reinterpret_cast<const float4 *>(wl + (kh * g.k + kw) * g.C + 4 * cq);
+                    acc[0] = fmaf(dv.x, wv.x, acc[0]); acc[1] = fmaf(dv.y, wv.y, acc[1]);
+                    acc[2] = fmaf(dv.z, wv.z, acc[2]); acc[3] = fmaf(dv.w, wv.w, acc[3]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (4 * cq + e < g.C) acc[e] = fmaf(dp[e], w[(size_t)(4 * cq + e) * kk + kh * g.k + kw], acc[e]);
+                        if (4 * cq + e < g.C) acc[e] = fmaf(dp[e], wl[(kh * g.k + kw) * g.C + 4 * cq + e], acc[e]);
                 }
             }
         }
@@ -417,7 +423,9 @@ extern "C" int ww_dwconv_nhwc_fwd(ww_ctx *ctx, const float *x, const float *w, i
     int rc = make_dwg("ww_dwconv_nhwc_fwd", B, H, W, C, k, stride, &g);
     if (rc) return rc;
     ww_prof_scope ps_(ctx, WW_K_NHWC, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_dwg_fwd, dim3(egrid((long)B * g.Ho * g.Wo * ((C + 3) / 4))), dim3(256), 0, (hipStream_t)stream, x, w, g, y);
+    const size_t wbytes = (size_t)C * k * k * sizeof(float);
+    WW_REQUIRE(wbytes <= 64 * 1024, WW_E_UNSUPPORTED, "ww_dwconv_nhwc_fwd: C*k*k = %d weights do not fit the LDS cache", C * k * k);
+    hipLaunchKernelGGL(k_dwg_fwd, dim3(egrid((long)B * g.Ho * g.Wo * ((C + 3) / 4))), dim3(256), wbytes, (hipStream_t)stream, x, w, g, y);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -430,7 +438,9 @@ extern "C" int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, c
     hipStream_t st = (hipStream_t)stream;
     ww_prof_scope ps_(ctx, WW_K_NHWC, st);
     if (dx) {
-        hipLaunchKernelGGL(k_dwg_bwd_dx, dim3(egrid((long)B * H * W * ((C + 3) / 4))), dim3(256), 0, st, dy, w, g, dx);
+        const size_t wbytes = (size_t)C * k * k * sizeof(float);
+        WW_REQUIRE(wbytes <= 64 * 1024, WW_E_UNSUPPORTED, "ww_dwconv_nhwc_bwd: C*k*k = %d weights do not fit the LDS cache", C * k * k);
+        hipLaunchKernelGGL(k_dwg_bwd_dx, dim3(egrid((long)B * H * W * ((C + 3) / 4))), dim3(256), wbytes, st, dy, w, g, dx);
         WW_LAUNCH_CHECK();
     }
     WW_REQUIRE(C <= 1024, WW_E_UNSUPPORTED, "ww_dwconv_nhwc_bwd: C=%d > 1024", C);
