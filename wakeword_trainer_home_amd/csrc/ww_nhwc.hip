@@ -292,6 +292,57 @@ __global__ __launch_bounds__(1024) void k_dwg_bwd_dw(const float *__restrict__ x
         }
 }
 
+// the same for C % 4 == 0: a thread owns FOUR channels (float4 loads) and rows r, r+R, ...: block = (C/4)*R <= 512 threads
+__global__ __launch_bounds__(512) void k_dwg_bwd_dw4(const float *__restrict__ x, const float *__restrict__ dy, DwG g, int R,
+                                                      long px_per_chunk, float *__restrict__ part) {
+    extern __shared__ __align__(16) float redf[];           // [R][C]
+    const int C4 = g.C / 4, cq = threadIdx.x % C4, r = threadIdx.x / C4, pad = g.k / 2, kk = g.k * g.k;
+    const long P = (long)g.B * g.Ho * g.Wo;
+    const long p0 = (long)blockIdx.x * px_per_chunk, p1 = min(P, p0 + px_per_chunk);
+    float ax[25], ay[25], az[25], aw[25];       // plain arrays: an array of HIP float4 structs is not promoted to registers
+#pragma unroll
+    for (int t = 0; t < 25; ++t) { ax[t] = 0.f; ay[t] = 0.f; az[t] = 0.f; aw[t] = 0.f; }
+    for (long p = p0 + r; p < p1; p += R) {
+        const int wo = (int)(p % g.Wo);
+        const long q = p / g.Wo;
+        const int ho = (int)(q % g.Ho), b = (int)(q / g.Ho);
+        const float4 d = *reinterpret_cast<const float4 *>(dy + (size_t)p * g.C + 4 * cq);
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh) {
+            const int hi = ho * g.s + kh - pad;
+            if (kh >= g.k || hi < 0 || hi >= g.H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw) {
+                const int wi = wo * g.s + kw - pad;
+                if (kw >= g.k || wi < 0 || wi >= g.W) continue;
+                const float4 xv = *reinterpret_cast<const float4 *>(x + (((size_t)b * g.H + hi) * g.W + wi) * g.C + 4 * cq);
+                const int t = kh * 5 + kw;
+                ax[t] = fmaf(d.x, xv.x, ax[t]); ay[t] = fmaf(d.y, xv.y, ay[t]);
+                az[t] = fmaf(d.z, xv.z, az[t]); aw[t] = fmaf(d.w, xv.w, aw[t]);
+            }
+        }
+    }
+    for (int kh = 0; kh < g.k; ++kh)
+        for (int kw = 0; kw < g.k; ++kw) {
+            __syncthreads();
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int a5 = 0; a5 < 25; ++a5)
+                if (a5 == kh * 5 + kw) v = make_float4(ax[a5], ay[a5], az[a5], aw[a5]);
+            *reinterpret_cast<float4 *>(redf + r * g.C + 4 * cq) = v;
+            __syncthreads();
+            if (r == 0) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = 0; i < R; ++i) {
+                    const float4 u = *reinterpret_cast<const float4 *>(redf + i * g.C + 4 * cq);
+                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                }
+                float *o = part + (size_t)blockIdx.x * g.C * kk + (size_t)(4 * cq) * kk + kh * g.k + kw;
+                o[0] = t.x; o[kk] = t.y; o[2 * kk] = t.z; o[3 * kk] = t.w;
+            }
+        }
+}
+
 // ---- squeeze-excitation / pooling pieces on (B, HW, C)
 __global__ __launch_bounds__(256) void k_pool_fwd(const float *__restrict__ x, int B, int HW, int C, float *__restrict__ s) {
     const long n = (long)B * C;
@@ -445,10 +496,19 @@ extern "C" int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, c
     }
     WW_REQUIRE(C <= 1024, WW_E_UNSUPPORTED, "ww_dwconv_nhwc_bwd: C=%d > 1024", C);
     const long P = (long)B * g.Ho * g.Wo;
-    const int chunks = chunks_for(P, C), R = rows_r(C);
     float *part = (float *)scratch;
-    hipLaunchKernelGGL(k_dwg_bwd_dw, dim3(chunks), dim3(C * R), (size_t)R * C * sizeof(float), st, x, dy, g, R,
-                       (P + chunks - 1) / chunks, part);
+    int chunks;
+    if ((C & 3) == 0) {
+        const int R4 = std::max(1, std::min(32, 512 / (C / 4)));      // <= 512 threads: 100 accumulator registers per thread
+        chunks = (int)std::max<long>(1, std::min<long>(NCHUNK, P / (4L * R4)));
+        hipLaunchKernelGGL(k_dwg_bwd_dw4, dim3(chunks), dim3((C / 4) * R4), (size_t)R4 * C * sizeof(float), st, x, dy, g, R4,
+                           (P + chunks - 1) / chunks, part);
+    } else {
+        const int R = rows_r(C);
+        chunks = chunks_for(P, C);
+        hipLaunchKernelGGL(k_dwg_bwd_dw, dim3(chunks), dim3(C * R), (size_t)R * C * sizeof(float), st, x, dy, g, R,
+                           (P + chunks - 1) / chunks, part);
+    }
     WW_LAUNCH_CHECK();
     return ww_colsum_rows_small(part, chunks, C * k * k, dw, st);
 }
