@@ -128,6 +128,75 @@ class _StemFn(torch.autograd.Function):       # Conv2d(1, C, 3, stride 2, pad 1)
         return None, dw.reshape(ctx.wshape), None
 
 
+class _ConvBNActFn(torch.autograd.Function):
+    """Conv2dNormActivation as ONE autograd node (conv -> BatchNorm -> activation): half the Python/autograd overhead of the
+    three-node form, which is what bounds the step at the per-GPU batch of data-parallel training.  kind: stem | dw | pw."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, conv, bn, kind, act, mode):
+        if kind == "stem":
+            B, _, H, W = x.shape
+            src = nat.im2col3x3s2(x.reshape(B, H, W).contiguous())
+            w2 = w.reshape(w.shape[0], 9)
+            y = nat.linear_mfma_fwd(src, w2, None, mode=mode).reshape(B, (H + 1) // 2, (W + 1) // 2, w.shape[0])
+        elif kind == "dw":
+            src = x.contiguous()
+            y = nat.dwconv_nhwc_fwd(src, w.contiguous(), conv.k, conv.stride)
+        else:
+            src = x.reshape(-1, x.shape[-1])
+            y = nat.linear_mfma_fwd(src, w.reshape(w.shape[0], -1), None, mode=mode).reshape(*x.shape[:-1], w.shape[0])
+        Cn = y.shape[-1]
+        bnp = nat.make_bn(gamma, beta, bn.running_mean, bn.running_var, momentum=bn.momentum, eps=bn.eps, training=bn.training)
+        a, ss, mr = nat.bn_act_fwd(y, bnp, act, Cn)
+        if bn.training:
+            bn.num_batches_tracked += 1
+        ctx.save_for_backward(src, w, y, ss, mr)
+        ctx.meta = (kind, act, mode, bn.training, conv.k, conv.stride, x.shape, Cn)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        src, w, y, ss, mr = ctx.saved_tensors
+        kind, act, mode, training, k, stride, xshape, Cn = ctx.meta
+        dy, dgamma, dbeta = nat.bn_act_bwd(y, da.contiguous(), ss, mr, act, training, Cn)
+        if kind == "dw":
+            dx, dw = nat.dwconv_nhwc_bwd(src, w.contiguous(), dy, k, stride, need_dx=ctx.needs_input_grad[0])
+        else:
+            need_dx = kind == "pw" and ctx.needs_input_grad[0]
+            w2 = w.reshape(w.shape[0], -1)
+            dx, dw, _ = nat.linear_mfma_bwd(src, w2, None, dy.reshape(-1, Cn), mode=mode, need_dx=need_dx, need_db=False)
+            dx = dx.reshape(xshape) if dx is not None else None
+            dw = dw.reshape(w.shape)
+        return dx, dw, dgamma, dbeta, None, None, None, None, None
+
+
+class _SEFn(torch.autograd.Function):
+    """Squeeze-excitation as one node: pool -> FC+ReLU -> FC+Hardsigmoid -> scale; the two uses of x meet in ONE backward
+    kernel (dx = dy*gate + dpool/HW) instead of two gradient tensors and an add."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, mode):
+        B, H, W, Cn = x.shape
+        x3 = x.reshape(B, H * W, Cn)
+        s = nat.pool_hw_fwd(x3)
+        h, pre1 = nat.linear_mfma_fwd(s, w1.reshape(w1.shape[0], -1), b1, act=nat.LIN_RELU, mode=mode, want_pre=True)
+        g, pre2 = nat.linear_mfma_fwd(h, w2.reshape(w2.shape[0], -1), b2, act=nat.LIN_HARDSIGMOID, mode=mode, want_pre=True)
+        ctx.save_for_backward(x3, s, h, pre1, pre2, g, w1, w2)
+        ctx.mode, ctx.xshape = mode, x.shape
+        return nat.scale_bc_fwd(x3, g).reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, s, h, pre1, pre2, g, w1, w2 = ctx.saved_tensors
+        B, HW, Cn = x3.shape
+        dy3 = dy.contiguous().reshape(B, HW, Cn)
+        dg = nat.scale_bc_bwd_gate(x3, dy3)
+        dh, dw2, db2 = nat.linear_mfma_bwd(h, w2.reshape(w2.shape[0], -1), pre2, dg, act=nat.LIN_HARDSIGMOID, mode=ctx.mode)
+        ds, dw1, db1 = nat.linear_mfma_bwd(s, w1.reshape(w1.shape[0], -1), pre1, dh, act=nat.LIN_RELU, mode=ctx.mode)
+        dx = nat.scale_pool_bwd(dy3, g, ds, (B, HW, Cn)).reshape(ctx.xshape)
+        return dx, dw1.reshape(w1.shape), db1, dw2.reshape(w2.shape), db2, None
+
+
 class _AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -168,13 +237,8 @@ class ConvBNAct(nn.Sequential):
 
     def forward(self, x):
         conv, bn = self[0], self[1]
-        if self.stem:
-            y = _StemFn.apply(x, conv.weight, self.mode)
-        elif self.depthwise:
-            y = _DWFn.apply(x, conv.weight, conv.k, conv.stride)
-        else:
-            y = _PWFn.apply(x, conv.weight, None, nat.LIN_NONE, self.mode)
-        return _BNActFn.apply(y, bn.weight, bn.bias, bn, self.act)
+        kind = "stem" if self.stem else ("dw" if self.depthwise else "pw")
+        return _ConvBNActFn.apply(x, conv.weight, bn.weight, bn.bias, conv, bn, kind, self.act, self.mode)
 
 
 class _FC(nn.Module):
@@ -193,10 +257,7 @@ class SqueezeExcitation(nn.Module):
         self.fc1, self.fc2, self.mode = _FC(c, cs), _FC(cs, c), mode
 
     def forward(self, x):
-        s = _PoolFn.apply(x)
-        s = _PWFn.apply(s, self.fc1.weight, self.fc1.bias, nat.LIN_RELU, self.mode)
-        s = _PWFn.apply(s, self.fc2.weight, self.fc2.bias, nat.LIN_HARDSIGMOID, self.mode)
-        return _ScaleFn.apply(x, s)
+        return _SEFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self.mode)
 
 
 class InvertedResidual(nn.Module):
