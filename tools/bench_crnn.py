@@ -35,7 +35,7 @@ for arch, B, act in CONFIGS:
                "finalize", "gru", "linear_mfma", "nhwc_layers"]
 
     def step(i):
-        tr._step_generic(*pool[i % 2], i)
+        (tr._step_autograd_async if tr._async_autograd else tr._step_generic)(*pool[i % 2], i)
 
     for i in range(3):
         step(i)

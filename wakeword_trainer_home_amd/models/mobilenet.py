@@ -290,6 +290,8 @@ class _MobileNet(nn.Module):
 
 
 class MobileNetV3Wakeword(nn.Module):
+    hip_backed = True
+
     def __init__(self, num_classes: int = 2, pretrained: bool = False, dropout: float = 0.3, input_channels: int = 1,
                  mode="fp32", dropout_seed: int = 0):
         super().__init__()

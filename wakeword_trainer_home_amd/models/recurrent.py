@@ -184,6 +184,8 @@ class _DropFn(torch.autograd.Function):
 
 
 class CRNNWakeword(nn.Module):
+    hip_backed = True      # every op is a HIP kernel of this build: the Trainer may run its sync-free step (no host reads)
+
     """Conv front-end + GRU (BASELINE config 5's model; the reference has no CRNN -- SURVEY.md F4 -- so the topology is this
     build's, made of the reference's own parts): cnn_small's conv stack (stem + 4 depthwise-separable blocks, 64 channels)
     -> BN+ReLU -> mean over the frequency axis -> (B, T/2, 64) -> GRUWakeword's recurrent part (2-layer bidirectional GRU,
@@ -212,6 +214,8 @@ class CRNNWakeword(nn.Module):
 
 
 class GRUWakeword(nn.Module):
+    hip_backed = True
+
     def __init__(self, input_size: int = 40, hidden_size: int = 128, num_layers: int = 2, num_classes: int = 2,
                  bidirectional: bool = True, dropout: float = 0.3, dropout_seed: int = 0, mode: str = "fp32"):
         super().__init__()

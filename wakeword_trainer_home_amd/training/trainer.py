@@ -121,8 +121,14 @@ class Trainer:
         # resolved while the NEXT step is already running (callbacks fire one step late, same order and content).
         self._fused_optimizer = isinstance(self.optimizer, FlatFusedOptimizer)    # clip + update = one launch
         self._skip_on_device = self._fused_optimizer or bool(getattr(self.optimizer, "_step_supports_amp_scaling", False))
-        self.deferred_metrics = (bool(getattr(config.training, "deferred_metrics", True)) and self.native
-                                 and self._native_loss and self._skip_on_device)
+        # HIP-backed models that go through autograd (gru, crnn, mobilenetv3) get the same sync-free step: native loss stats,
+        # device-side clip and skip decision, one deferred 48-byte read (the reference's step reads loss/acc/grad-norm back
+        # three times per batch, trainer.py:177-209)
+        self._async_autograd = (not self.native and self._native_loss and self._skip_on_device
+                                and bool(getattr(self.model, "hip_backed", False)) and not self.use_mixed_precision
+                                and torch.device(device).type == "cuda")
+        self.deferred_metrics = (bool(getattr(config.training, "deferred_metrics", True))
+                                 and (self.native or self._async_autograd) and self._native_loss and self._skip_on_device)
         self._pending = None
         self._host_bufs, self._buf_i = None, 0
         self._in_stream = None
@@ -289,6 +295,45 @@ class Trainer:
         self._pending = launched
         return done
 
+    def _step_autograd_async(self, inputs, targets, batch_idx):
+        """Training step of a HIP-backed autograd model without host reads: forward / native loss / backward through
+        autograd, gradient all-reduce, clip_grad_norm_ and the "skip a non-finite batch" decision on the device (the
+        fused optimizer takes it as found_inf), statistics resolved one step later."""
+        inputs = self._to_model_input(inputs, training=True)
+        targets = targets.to(self.device, non_blocking=True)
+        if hasattr(self.model, "sample_offset"):
+            self.model.sample_offset = self.rank * inputs.shape[0]
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.criterion(self.model(inputs), targets)
+        loss.backward()
+        self._allreduce_grads()
+        stats = self.criterion.last_stats
+        sv = stats.view(torch.float32)
+        if self.gradient_clip > 0:
+            norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), float(self.gradient_clip), foreach=True)
+            sv[1] = norm                                                               # ww_step_stats.grad_norm
+            sv[nat.FOUND_INF_FLOAT_INDEX] = torch.maximum(sv[nat.FOUND_INF_FLOAT_INDEX], (~torch.isfinite(norm)).float())
+        self.optimizer.grad_scale = None
+        self.optimizer.found_inf = sv[nat.FOUND_INF_FLOAT_INDEX]
+        try:
+            self.optimizer.step()
+        finally:
+            del self.optimizer.grad_scale, self.optimizer.found_inf
+        if self._host_bufs is None:
+            self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        buf = self._host_bufs[self._buf_i]
+        self._buf_i ^= 1
+        buf.copy_(stats, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        launched = (batch_idx, buf, event)
+        if not self.deferred_metrics:
+            r = self._resolve(launched)
+            return [] if r is None else [r]
+        done = self._flush_pending()
+        self._pending = launched
+        return done
+
     def _to_model_input(self, inputs, training):
         """(B,N) waveforms go through the native front end (log-mel/MFCC [+SpecAugment, audio augmentation]); feature
         batches are moved as the reference does (channels_last, trainer.py:160)."""
@@ -370,7 +415,8 @@ class Trainer:
             logger.warning("Training loader is empty, skipping epoch")
             return 0.0, 0.0
         epoch_loss = 0.0
-        step = self._step_native if (self.native and self._native_loss) else self._step_generic
+        step = (self._step_native if (self.native and self._native_loss)
+                else self._step_autograd_async if self._async_autograd else self._step_generic)
         bar = self._bar(self.train_loader, f"Epoch {epoch + 1}/{self.config.training.epochs} [Train]")
 
         def account(done):
