@@ -289,3 +289,40 @@ def test_gru_direction_bf16_mode(reverse):
     for got, p in ((dw_ih, P[0]), (dw_hh, P[1]), (db_ih, P[2]), (db_hh, P[3])):
         a, b = got.cpu().double().flatten(), p.grad.flatten()
         assert (a @ b / (a.norm() * b.norm())).item() > 0.999
+
+
+def test_async_autograd_step_skips_nonfinite_batch_on_device(tmp_path):
+    """The sync-free step of a HIP-backed autograd model: a batch with a non-finite loss changes no parameter (the fused
+    optimizer gets the flag on the device), is not reported to callbacks and still counts in the epoch average's
+    denominator (reference quirk Q5, trainer.py:177-179,228)."""
+    from wakeword_trainer_home_amd.config import get_preset
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    from wakeword_trainer_home_amd.data import make_synthetic_batch
+    cfg = get_preset("cnn_small_logmel40")
+    cfg.training.epochs, cfg.optimizer.warmup_epochs, cfg.training.batch_size = 1, 0, 8
+    torch.manual_seed(2)
+    model = create_model("gru", dropout=0.0)
+    wave, y = make_synthetic_batch(24, 24000, seed=6)
+    bad = wave[8:16].clone()
+    bad[3, 100] = float("nan")
+    batches = [(wave[:8], y[:8]), (bad, y[8:16]), (wave[16:], y[16:])]
+    t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=tmp_path, device=DEV)
+    assert t._async_autograd and t.deferred_metrics
+    seen = []
+    t.add_callback(type("R", (), {"on_batch_end": lambda self, i, l, a: seen.append((i, l))})())
+    snaps = []
+    orig = t._step_autograd_async
+
+    def spy(inputs, targets, idx):
+        snaps.append({k: v.clone() for k, v in model.state_dict().items()})
+        return orig(inputs, targets, idx)
+    t._step_autograd_async = spy
+    avg, _ = t.train_epoch(0)
+    after = {k: v.clone() for k, v in model.state_dict().items()}
+    assert [i for i, _ in seen] == [0, 2] and all(np.isfinite(l) for _, l in seen)
+    changed01 = any(not torch.equal(snaps[0][k], snaps[1][k]) for k in snaps[0])
+    same12 = all(torch.equal(snaps[1][k], snaps[2][k]) for k in snaps[1])          # the NaN batch left everything untouched
+    changed2 = any(not torch.equal(snaps[2][k], after[k]) for k in after)
+    assert changed01 and same12 and changed2
+    assert abs(avg - (seen[0][1] + seen[1][1]) / 3) < 1e-6
