@@ -18,7 +18,7 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int GT = 64;      // block tile (rows and columns)
+// block tiles are 64 or 128 rows/columns (template parameters TM, TN of k_gemm)
 constexpr int GK = 32;      // K per LDS stage, fp32 mode
 constexpr int GKH = 128;    // K per LDS stage, bf16 mode
 
@@ -118,70 +118,86 @@ __device__ __forceinline__ bf16x8 tr_frag(const ww_bf16 *tile, int ld, int k0, i
 // Block tile (64*TM) x 64: 4 wavefronts as 2 x 2, each TM 32x32 MFMA tiles stacked along the rows (TM = 2 for tall
 // problems: twice the MFMA work per staged B byte).  grid: x = column tiles, y = row tiles, z = K splits (partial
 // products go to C + z*split_stride)
-template <bool BF16, bool KCA, bool KCB, bool EPI, int TM>
+template <bool BF16, bool KCA, bool KCB, bool EPI, int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int K, int k_per_split, float *__restrict__ C,
                                               long ldc, long split_stride, int vecA, int vecB, Epilogue e) {
-    constexpr int RA = 64 * TM;
+    constexpr int RA = 64 * TM, RB = 64 * TN;
     // K per LDS stage: the bf16 MFMA eats 16 k per instruction, so a 32-deep stage is two MFMAs between barrier pairs --
-    // 128 gives eight (the fp32 MFMA eats 2 k: 32 is already sixteen of them)
-    constexpr int KT = BF16 ? GKH : GK;
+    // 128 gives eight (64 for the 128 x 128 tile, whose prefetch registers double); the fp32 MFMA eats 2 k: 32 is sixteen
+    constexpr int KT = BF16 ? (TM * TN == 4 ? 64 : GKH) : GK;
     constexpr int LDH_KC = KT + 8, LDF_KC = KT + 4;
     constexpr int A_BYTES = BF16 ? (KCA ? RA * LDH_KC : KT * (RA + 8)) * 2 : (KCA ? RA * LDF_KC : KT * (RA + 4)) * 4;
-    constexpr int B_BYTES = BF16 ? (KCB ? 64 * LDH_KC : KT * (64 + 8)) * 2 : (KCB ? 64 * LDF_KC : KT * (64 + 4)) * 4;
+    constexpr int B_BYTES = BF16 ? (KCB ? RB * LDH_KC : KT * (RB + 8)) * 2 : (KCB ? RB * LDF_KC : KT * (RB + 4)) * 4;
     __shared__ __align__(16) unsigned char lds[A_BYTES + B_BYTES];
     void *As = lds, *Bs = lds + A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5, rh = wv >> 1, nh = wv & 1;
-    const long m0 = (long)blockIdx.y * RA, n0 = (long)blockIdx.x * GT;
+    const long m0 = (long)blockIdx.y * RA, n0 = (long)blockIdx.x * RB;
     const int kb = blockIdx.z * k_per_split, ke = min(K, kb + k_per_split);
-    floatx16 acc[TM];
+    floatx16 acc[TM][TN];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) acc[tm] = floatx16{0.f};
-    float4 va[RA * KT / 1024], vb[64 * KT / 1024];
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = floatx16{0.f};
+    float4 va[RA * KT / 1024], vb[RB * KT / 1024];
     if (kb < ke) {
         fetch_tile<KCA, RA, KT>(A, m0, kb, ke, vecA, va);
-        fetch_tile<KCB, 64, KT>(B, n0, kb, ke, vecB, vb);
+        fetch_tile<KCB, RB, KT>(B, n0, kb, ke, vecB, vb);
     }
     for (int k0 = kb; k0 < ke; k0 += KT) {
         __syncthreads();
         stage_tile<BF16, KCA, RA, KT>(As, va);
-        stage_tile<BF16, KCB, 64, KT>(Bs, vb);
+        stage_tile<BF16, KCB, RB, KT>(Bs, vb);
         __syncthreads();
         if (k0 + KT < ke) {                        // next tile in flight under the MFMAs
             fetch_tile<KCA, RA, KT>(A, m0, k0 + KT, ke, vecA, va);
-            fetch_tile<KCB, 64, KT>(B, n0, k0 + KT, ke, vecB, vb);
+            fetch_tile<KCB, RB, KT>(B, n0, k0 + KT, ke, vecB, vb);
         }
         if (BF16) {
             const ww_bf16 *a = reinterpret_cast<const ww_bf16 *>(As), *b = reinterpret_cast<const ww_bf16 *>(Bs);
 #pragma unroll
             for (int t = 0; t < KT / 16; ++t) {
-                const bf16x8 fb = KCB ? *reinterpret_cast<const bf16x8 *>(b + (32 * nh + r) * LDH_KC + 16 * t + 8 * h)
-                                      : tr_frag(b, 64 + 8, 16 * t, 32 * nh, lane);
+                bf16x8 fb[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int col0 = 32 * TN * nh + 32 * tn;
+                    fb[tn] = KCB ? *reinterpret_cast<const bf16x8 *>(b + (col0 + r) * LDH_KC + 16 * t + 8 * h)
+                                 : tr_frag(b, RB + 8, 16 * t, col0, lane);
+                }
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
                     const int row0 = 32 * TM * rh + 32 * tm;
                     const bf16x8 fa = KCA ? *reinterpret_cast<const bf16x8 *>(a + (row0 + r) * LDH_KC + 16 * t + 8 * h)
                                           : tr_frag(a, RA + 8, 16 * t, row0, lane);
-                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tm], 0, 0, 0);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[tn], acc[tm][tn], 0, 0, 0);
                 }
             }
         } else {
             const float *a = reinterpret_cast<const float *>(As), *b = reinterpret_cast<const float *>(Bs);
 #pragma unroll
             for (int t = 0; t < KT / 2; ++t) {
-                const float fb = KCB ? b[(32 * nh + r) * LDF_KC + 2 * t + h] : b[(2 * t + h) * (64 + 4) + 32 * nh + r];
+                float fb[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int col0 = 32 * TN * nh + 32 * tn;
+                    fb[tn] = KCB ? b[(col0 + r) * LDF_KC + 2 * t + h] : b[(2 * t + h) * (RB + 4) + col0 + r];
+                }
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) {
                     const int row0 = 32 * TM * rh + 32 * tm;
                     const float fa = KCA ? a[(row0 + r) * LDF_KC + 2 * t + h] : a[(2 * t + h) * (RA + 4) + row0 + r];
-                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[tm], 0, 0, 0);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb[tn], acc[tm][tn], 0, 0, 0);
                 }
             }
         }
     }
-    const long col = n0 + 32 * nh + r;
-    if (col >= B.rows) return;
     C += (long)blockIdx.z * split_stride;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+    const long col = n0 + 32 * TN * nh + 32 * tn + r;
+    if (col >= B.rows) continue;
     const float bias = (EPI && e.bias) ? e.bias[col] : 0.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
         for (int reg = 0; reg < 16; ++reg) {
             const long row = m0 + 32 * TM * rh + 32 * tm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
             if (row >= A.rows) continue;
-            float v = acc[tm][reg];
+            float v = acc[tm][tn][reg];
             if (EPI) {
                 v += bias;
                 if (e.pre) e.pre[row * ldc + col] = v;
@@ -199,6 +215,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
             if (e.accumulate && gridDim.z == 1) v += C[row * ldc + col];
             C[row * ldc + col] = v;
         }
+    }
 }
 
 // C[i] = sum_z P[z][i] in fixed order (split-K partial products)
@@ -310,23 +327,26 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
     };
     const int vecA = aligned(A, KCA), vecB = aligned(B, KCB);
     int kps = K;
-    const int kt = mode == WW_ACT_BF16 ? GKH : GK;
+    const int kt = mode == WW_ACT_BF16 ? GKH : GK;      // a multiple of every stage depth in use (128, 64, 32)
     if (splits > 1) kps = ((K + splits - 1) / splits + kt - 1) / kt * kt;
     const int nz = (K + kps - 1) / kps;
-    // 128-row blocks only when there are plenty of them (measured: at 2048 rows they halve the block count and lose 30 %;
-    // at 16384 rows they gain 8 %)
-    const bool tall = A.rows >= 8192;
-    const int RA = tall ? 128 : 64;
-    dim3 grid((B.rows + GT - 1) / GT, (A.rows + RA - 1) / RA, nz);
+    // Block tile: 64 x 64 by default; 128 x 128 (each staged byte feeds twice the MFMA work: these GEMMs are bound by operand
+    // traffic, not by the matrix cores) when both extents allow it and enough workgroups remain; 128 x 64 for very tall ones
+    const long tiles128 = (long)((A.rows + 127) / 128) * ((B.rows + 127) / 128) * nz;
+    // (the 128 x 128 form pays in bf16 mode only: in fp32 mode its 64 accumulator + 32 prefetch registers cost occupancy, 72 vs 82 TF)
+    const int cfg = (mode == WW_ACT_BF16 && A.rows >= 128 && B.rows >= 128 && tiles128 >= 256) ? 2 : (A.rows >= 8192 ? 1 : 0);
+    const int RA = cfg ? 128 : 64, RBt = cfg == 2 ? 128 : 64;
+    dim3 grid((B.rows + RBt - 1) / RBt, (A.rows + RA - 1) / RA, nz);
     float *dst = nz > 1 ? part : C;
     const long sstride = (long)A.rows * ldc;
+#define WW_GEMM_LAUNCH(BF, TM_, TN_) \
+    hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, TN_>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e)
     if (mode == WW_ACT_BF16) {
-        if (tall) hipLaunchKernelGGL((k_gemm<true, KCA, KCB, EPI, 2>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
-        else hipLaunchKernelGGL((k_gemm<true, KCA, KCB, EPI, 1>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
+        if (cfg == 2) WW_GEMM_LAUNCH(true, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(true, 2, 1); else WW_GEMM_LAUNCH(true, 1, 1);
     } else {
-        if (tall) hipLaunchKernelGGL((k_gemm<false, KCA, KCB, EPI, 2>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
-        else hipLaunchKernelGGL((k_gemm<false, KCA, KCB, EPI, 1>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e);
+        if (cfg == 2) WW_GEMM_LAUNCH(false, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(false, 2, 1); else WW_GEMM_LAUNCH(false, 1, 1);
     }
+#undef WW_GEMM_LAUNCH
     WW_LAUNCH_CHECK();
     if (nz > 1) {
         const long n = sstride;
