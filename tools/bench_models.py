@@ -19,7 +19,7 @@ from wakeword_trainer_home_amd.training import Trainer
 dev = "cuda:0"
 CONFIGS = (("crnn", 512, "bf16"), ("crnn", 4096, "bf16"), ("gru", 4096, "fp32"), ("mobilenetv3", 256, "bf16"),
            ("mobilenetv3", 2048, "bf16"))
-if len(sys.argv) > 1:                         # e.g.  bench_crnn.py crnn 4096 bf16
+if len(sys.argv) > 1:                         # e.g.  bench_models.py crnn 4096 bf16
     CONFIGS = ((sys.argv[1], int(sys.argv[2]), sys.argv[3]),)
 for arch, B, act in CONFIGS:
     cfg = get_preset("cnn_small_logmel40")
