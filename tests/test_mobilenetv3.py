@@ -119,3 +119,15 @@ def test_mobilenetv3_matches_oracle():
         ev = model(x.to(DEV))
         ev_ref = oracle(x, training=False)
     assert (ev.cpu().double() - ev_ref).abs().max().item() <= 2e-4
+
+
+def test_reference_architecture_smoke_shapes():
+    """The reference's own model test (tests/test_training_pipeline.py:49-82): every architecture built by ``create_model``
+    maps its test input to (4, 2) -- (4,1,64,50) spectrograms for mobilenetv3, (4,50,40) sequences for gru."""
+    from wakeword_trainer_home_amd.models import create_model
+    for arch, shape in (("mobilenetv3", (4, 1, 64, 50)), ("gru", (4, 50, 40)), ("cnn_small", (4, 1, 64, 50)), ("crnn", (4, 1, 64, 50))):
+        model = create_model(arch, num_classes=2, pretrained=False).to(DEV)
+        out = model(torch.randn(*shape, device=DEV))
+        assert out.shape == (4, 2) and torch.isfinite(out).all(), arch
+        out.sum().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters()), arch
