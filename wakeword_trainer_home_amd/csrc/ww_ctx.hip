@@ -184,41 +184,47 @@ extern "C" size_t ww_layer_scratch_bytes(void) {
 // summed in double in a fixed order => bit-reproducible run to run.
 // ------------------------------------------------------------------------------------------
 
-// column sums of partials[rows][128] by one 1024-thread block: thread = (4 columns as float4, 1 of 32 row
-// parts); the <= 32 loads of a thread are independent, so the sweep is bandwidth- not latency-bound
-__device__ inline double ww_col128_sum(const float *__restrict__ partials, int rows, double *sh /*32*128*/) {
-    const int c4 = threadIdx.x & 31, part = threadIdx.x >> 5;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 16
-    for (int r = part; r < rows; r += 32) {
-        const float4 v = *reinterpret_cast<const float4 *>(partials + (size_t)r * 128 + 4 * c4);
-        a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+// Column sums for ONE group of 8 channels: columns 8*cg..+7 (first statistic) and 64 + 8*cg..+7 (second statistic) of
+// partials[rows][128], by one 256-thread block: thread = (one of the 4 float4 of a row's 16 values, 1 of 64 row parts).
+// The finalize kernels run 8 such blocks side by side instead of one block sweeping all 128 columns: the sweep of the
+// 512 KB slab by a single CU was the whole cost of a finalize launch (7 us); channels are independent.
+// tot[0..7] = first statistic, tot[8..15] = second, valid after the call in every thread.
+// (every thread of the block must call it -- it contains barriers; threads >= 256 of a larger block only wait)
+__device__ __forceinline__ void ww_colgroup_sum(const float *__restrict__ partials, int rows, int cg, double (*sh)[16],
+                                                double *tot /*16, shared*/) {
+    const int q = threadIdx.x & 3, part = threadIdx.x >> 2;
+    if (threadIdx.x < 256) {
+        const int col = (q < 2 ? 8 * cg + 4 * q : 64 + 8 * cg + 4 * (q - 2));
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 8
+        for (int r = part; r < rows; r += 64) {
+            const float4 v = *reinterpret_cast<const float4 *>(partials + (size_t)r * 128 + col);
+            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+        }
+        sh[part][4 * q] = a0; sh[part][4 * q + 1] = a1; sh[part][4 * q + 2] = a2; sh[part][4 * q + 3] = a3;
     }
-    sh[part * 128 + 4 * c4] = a0; sh[part * 128 + 4 * c4 + 1] = a1;
-    sh[part * 128 + 4 * c4 + 2] = a2; sh[part * 128 + 4 * c4 + 3] = a3;
     __syncthreads();
-    double tot = 0.0;
-    if (threadIdx.x < 128) {
-#pragma unroll
-        for (int p = 0; p < 32; ++p) tot += sh[p * 128 + threadIdx.x];
+    if (threadIdx.x < 16) {
+        double t = 0.0;
+#pragma unroll 8
+        for (int p = 0; p < 64; ++p) t += sh[p][threadIdx.x];
+        tot[threadIdx.x] = t;
     }
-    return tot;  // valid for threadIdx.x < 128
+    __syncthreads();
 }
 
 // BatchNorm2d training forward statistics (torch semantics: biased var for normalisation,
-// unbiased for running_var, running = (1-m)*running + m*batch)
-__global__ __launch_bounds__(1024) void k_bn_fwd_finalize(const float *__restrict__ partials, int rows,
-                                                          double count, ww_bn_t bn, float *__restrict__ ss,
-                                                          float *__restrict__ mr) {
-    __shared__ double sh[32 * 128];
-    __shared__ double tot[128];
-    double t = ww_col128_sum(partials, rows, sh);
-    if (threadIdx.x < 128) tot[threadIdx.x] = t;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int c = threadIdx.x;
-        const double mean = tot[c] / count;
-        double var = tot[64 + c] / count - mean * mean;
+// unbiased for running_var, running = (1-m)*running + m*batch).  grid 8 (channel groups), block 256
+__global__ __launch_bounds__(256) void k_bn_fwd_finalize(const float *__restrict__ partials, int rows,
+                                                         double count, ww_bn_t bn, float *__restrict__ ss,
+                                                         float *__restrict__ mr) {
+    __shared__ double sh[64][16];
+    __shared__ double tot[16];
+    ww_colgroup_sum(partials, rows, blockIdx.x, sh, tot);
+    if (threadIdx.x < 8) {
+        const int c = 8 * blockIdx.x + threadIdx.x;
+        const double mean = tot[threadIdx.x] / count;
+        double var = tot[8 + threadIdx.x] / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)bn.eps);
         const double scale = (double)bn.gamma[c] * rstd;
@@ -250,17 +256,15 @@ __global__ void k_bn_eval_ss(ww_bn_t bn, float *__restrict__ ss, float *__restri
 // BatchNorm2d backward reduction: partial columns = [sum dz (64) | sum dz*yhat (64)].
 //   dgamma = sum dz*yhat, dbeta = sum dz,
 //   dy = gamma*rstd*(dz - mean(dz) - yhat*mean(dz*yhat))  ==  A*dz + Bc*y + Cc
-__device__ __forceinline__ void bn_bwd_finalize_body(const float *__restrict__ partials, int rows, double count,
-                                                     const float *__restrict__ gamma, const float *__restrict__ mr,
-                                                     float *__restrict__ coef, float *__restrict__ dgamma,
-                                                     float *__restrict__ dbeta, double *sh /*32*128*/,
-                                                     double *tot /*128*/) {
-    double t = ww_col128_sum(partials, rows, sh);
-    if (threadIdx.x < 128) tot[threadIdx.x] = t;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int c = threadIdx.x;
-        const double s1 = tot[c], s2 = tot[64 + c];
+// one channel group (8 channels) per 256-thread block
+__device__ __forceinline__ void bn_bwd_finalize_group(const float *__restrict__ partials, int rows, double count, int cg,
+                                                      const float *__restrict__ gamma, const float *__restrict__ mr,
+                                                      float *__restrict__ coef, float *__restrict__ dgamma,
+                                                      float *__restrict__ dbeta, double (*sh)[16], double *tot) {
+    ww_colgroup_sum(partials, rows, cg, sh, tot);
+    if (threadIdx.x < 8) {
+        const int c = 8 * cg + threadIdx.x;
+        const double s1 = tot[threadIdx.x], s2 = tot[8 + threadIdx.x];
         const double mean = mr[c], rstd = mr[64 + c], g = gamma[c];
         const double c1 = s1 / count, c2 = s2 / count;
         const double A = g * rstd;
@@ -272,13 +276,13 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const float *__restrict__ p
     }
 }
 
-__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restrict__ partials, int rows,
-                                                          double count, const float *__restrict__ gamma,
-                                                          const float *__restrict__ mr, float *__restrict__ coef,
-                                                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    __shared__ double sh[32 * 128];
-    __shared__ double tot[128];
-    bn_bwd_finalize_body(partials, rows, count, gamma, mr, coef, dgamma, dbeta, sh, tot);
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float *__restrict__ partials, int rows,
+                                                         double count, const float *__restrict__ gamma,
+                                                         const float *__restrict__ mr, float *__restrict__ coef,
+                                                         float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ double sh[64][16];
+    __shared__ double tot[16];
+    bn_bwd_finalize_group(partials, rows, count, blockIdx.x, gamma, mr, coef, dgamma, dbeta, sh, tot);
 }
 
 // generic column sum: out[col] = sum_r partials[r][col]; block = 64 columns (16 float4 groups) x 64 row parts.
@@ -312,24 +316,26 @@ __global__ __launch_bounds__(1024) void k_colsum(const float *__restrict__ parti
     colsum_body(partials, rows, cols, out, blockIdx.x, sh);
 }
 
-// one launch for a backward layer's two reductions: block 0 = BatchNorm-backward constants of the input layer,
-// blocks 1.. = column sums of the weight-gradient slab
+// one launch for a backward layer's two reductions: blocks 0..7 = BatchNorm-backward constants of the input layer (one
+// channel group each, their first 256 threads), blocks 8.. = column sums of the weight-gradient slab
 __global__ __launch_bounds__(1024) void k_bwd_finalize(const float *__restrict__ stat, int rows, double count,
                                                        const float *__restrict__ gamma, const float *__restrict__ mr,
                                                        float *__restrict__ coef, float *__restrict__ dgamma,
                                                        float *__restrict__ dbeta, const float *__restrict__ dwp,
                                                        int cols, float *__restrict__ dw) {
     __shared__ double sh[64 * 64];
-    __shared__ double tot[128];
-    if (blockIdx.x == 0)
-        bn_bwd_finalize_body(stat, rows, count, gamma, mr, coef, dgamma, dbeta, sh, tot);
-    else
-        colsum_body(dwp, rows, cols, dw, blockIdx.x - 1, sh);
+    __shared__ double tot[16];
+    if (blockIdx.x < 8) {
+        bn_bwd_finalize_group(stat, rows, count, blockIdx.x, gamma, mr, coef, dgamma, dbeta,
+                              reinterpret_cast<double(*)[16]>(sh), tot);
+    } else {
+        colsum_body(dwp, rows, cols, dw, blockIdx.x - 8, sh);
+    }
 }
 
 int ww_launch_bn_fwd_finalize(const float *partials, int rows, double count, const ww_bn_t *bn, float *ss_out,
                               float *mr_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3(1), dim3(1024), 0, st, partials, rows, count, *bn, ss_out, mr_out);
+    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3(8), dim3(256), 0, st, partials, rows, count, *bn, ss_out, mr_out);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -340,7 +346,7 @@ int ww_launch_bn_eval_ss(const ww_bn_t *bn, float *ss_out, float *mr_out, hipStr
 }
 int ww_launch_bn_bwd_finalize(const float *partials, int rows, double count, const float *gamma,
                               const float *mr, float *coef_out, float *dgamma, float *dbeta, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(1), dim3(1024), 0, st, partials, rows, count, gamma, mr, coef_out,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(8), dim3(256), 0, st, partials, rows, count, gamma, mr, coef_out,
                        dgamma, dbeta);
     WW_LAUNCH_CHECK();
     return WW_OK;
@@ -348,7 +354,7 @@ int ww_launch_bn_bwd_finalize(const float *partials, int rows, double count, con
 int ww_launch_bwd_finalize(const float *stat, int rows, double count, const float *gamma, const float *mr,
                            float *coef, float *dgamma, float *dbeta, const float *dwp, int cols, float *dw,
                            hipStream_t st) {
-    hipLaunchKernelGGL(k_bwd_finalize, dim3(1 + (cols + 63) / 64), dim3(1024), 0, st, stat, rows, count, gamma, mr, coef,
+    hipLaunchKernelGGL(k_bwd_finalize, dim3(8 + (cols + 63) / 64), dim3(1024), 0, st, stat, rows, count, gamma, mr, coef,
                        dgamma, dbeta, dwp, cols, dw);
     WW_LAUNCH_CHECK();
     return WW_OK;
