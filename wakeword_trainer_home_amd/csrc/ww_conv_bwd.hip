@@ -22,7 +22,9 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int PW_LD = 68;
 
 // ------------------------------------------------------------------------------------- head
-// single block: thread = (channel c, part of 16 over the batch)
+
+// grid 8: block g owns channels 8g..8g+7 (the batch loop with its Philox draws is split 128 ways inside each block instead of
+// 16 ways inside ONE block: the single-block form took 26 us of a 1.46 ms step)
 __global__ __launch_bounds__(1024) void k_head_bwd(const float *__restrict__ dlogits, const float *__restrict__ pd,
                                                   const float *__restrict__ pool, int B, int HW,
                                                   const float *__restrict__ fc_w, float drop_scale,
@@ -34,12 +36,11 @@ __global__ __launch_bounds__(1024) void k_head_bwd(const float *__restrict__ dlo
                                                   float *__restrict__ coef, float *__restrict__ dgamma,
                                                   float *__restrict__ dbeta) {
     __shared__ double sh[6][1024];
-    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = 8 * blockIdx.x + (threadIdx.x & 7), part = threadIdx.x >> 3;      // 128 batch parts
     const float w0 = fc_w[c], w1 = fc_w[64 + c];
     const float inv_hw = 1.0f / (float)HW;
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll 4
-    for (int b = part; b < B; b += 16) {
+    for (int b = part; b < B; b += 128) {
         const float dl0 = dlogits[(size_t)b * 2], dl1 = dlogits[(size_t)b * 2 + 1];
         const float pv = pd[(size_t)b * 64 + c];
         a0 += (double)dl0 * pv;
@@ -63,13 +64,13 @@ __global__ __launch_bounds__(1024) void k_head_bwd(const float *__restrict__ dlo
     sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1; sh[2][threadIdx.x] = b0;
     sh[3][threadIdx.x] = b1; sh[4][threadIdx.x] = s1; sh[5][threadIdx.x] = s2;
     __syncthreads();
-    if (part == 0) {
+    if (threadIdx.x < 8) {
         double t[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             double a = 0.0;
-#pragma unroll 4      // all 96 loads in flight at once spilled; a kernel with scratch pays ~6 us on each side of its dispatch
-            for (int q = 0; q < 16; ++q) a += sh[k][64 * q + c];
+#pragma unroll 4      // all loads in flight at once spilled; a kernel with scratch pays ~6 us on each side of its dispatch
+            for (int q = 0; q < 128; ++q) a += sh[k][8 * q + threadIdx.x];
             t[k] = a;
         }
         dfc_w[c] = (float)t[0];
@@ -660,7 +661,7 @@ extern "C" int ww_head_bwd(ww_ctx *ctx, const float *dlogits, const float *pd, c
     const int use_dropout = training && dropout_p > 0.f;
     const float scale = (float)(1.0 / (1.0 - (double)dropout_p));
     ww_prof_scope ps_(ctx, WW_K_HEAD_LOSS, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_head_bwd, dim3(1), dim3(1024), 0, (hipStream_t)stream, dlogits, pd, pool, B, HW, fc_w, scale,
+    hipLaunchKernelGGL(k_head_bwd, dim3(8), dim3(1024), 0, (hipStream_t)stream, dlogits, pd, pool, B, HW, fc_w, scale,
                        ww_prob_threshold((double)dropout_p), use_dropout, (uint32_t)seed, (uint32_t)(seed >> 32),
                        (uint32_t)step, (uint32_t)(step >> 32), sample_offset, gamma_last, mr_last, dfc_w, dfc_b, dpool,
                        coef_last, dgamma_last, dbeta_last);
