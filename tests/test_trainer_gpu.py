@@ -222,3 +222,40 @@ def test_nonfinite_batch_is_skipped_on_the_device(tmp_path, deferred):
     model2.eval()
     with torch.no_grad():
         assert torch.isnan(model2(bad.to(DEV))).any()
+
+
+def test_native_resume_continues_like_an_uninterrupted_run(tmp_path):
+    """Checkpoint after 2 of 4 epochs (native cnn_small, fused clip+optimizer, dropout on), resume in a fresh Trainer: the
+    remaining steps reproduce the uninterrupted run bit for bit -- weights, BatchNorm statistics, optimizer moments and
+    step count, scheduler and the dropout stream all continue."""
+    from wakeword_trainer_home_amd.config import get_preset
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+
+    def run(d, stop_after=None, resume=None):
+        cfg = get_preset("cnn_small_logmel40")
+        cfg.training.epochs, cfg.optimizer.warmup_epochs, cfg.training.batch_size = 4, 0, 8
+        cfg.training.checkpoint_frequency = "every_epoch"
+        torch.manual_seed(12)
+        model = create_model("cnn_small", dropout=0.3, dropout_seed=3)
+        x, y = make_inputs(31, 24)
+        batches = [(x[i:i + 8], y[i:i + 8]) for i in range(0, 24, 8)]
+        t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=d, device=DEV)
+        rec = _Rec()
+        t.add_callback(rec)
+        if stop_after is not None:       # Ctrl-C after the epoch's checkpoint is written (train() catches it)
+            class _Stop:
+                def on_epoch_end(self, epoch, *a):
+                    if epoch + 1 == stop_after:
+                        raise KeyboardInterrupt
+            t.add_callback(_Stop())
+        t.train(resume_from=resume)
+        return rec.loss, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    full_loss, full_sd = run(tmp_path / "full")
+    run(tmp_path / "a", stop_after=2)
+    tail_loss, tail_sd = run(tmp_path / "b", resume=tmp_path / "a" / "checkpoint_epoch_002.pt")
+    assert len(full_loss) == 12 and len(tail_loss) == 6
+    assert tail_loss == full_loss[6:]
+    for k in full_sd:
+        assert torch.equal(full_sd[k], tail_sd[k]), k

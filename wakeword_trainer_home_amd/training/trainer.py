@@ -660,6 +660,11 @@ class Trainer:
             except Exception as e:
                 logger.warning("Failed to load %s state dict: %s. Continuing with fresh %s.", name, e, name)
         self.state = ckpt["state"]
+        # the Philox streams of the HIP modules (dropout masks) continue where the interrupted run stood: their counter is the
+        # number of training steps taken (SpecAugment / audio augmentation take theirs from state.global_step directly)
+        for m in self.model.modules():
+            if hasattr(m, "dropout_step"):
+                m.dropout_step = int(self.state.global_step)
         logger.info("Checkpoint loaded: Epoch %d", self.state.epoch + 1)
 
     # ------------------------------------------------------------------------------- callbacks
