@@ -269,107 +269,131 @@ __device__ __forceinline__ bf16x8 tr_operand(const ww_bf16 *tile, int p0, int c0
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// The layer's own output y_out is NOT read back: it is recomputed from the a tile with the forward kernel's exact
+// MFMA chain (same operands, same k order, same RNE rounding to bf16 -> bit-identical to the tensor k_pw_fwd_bf16
+// stored), which trades one activation-tensor read (97 MB at the full batch) for 4 MFMAs per wave and a third barrier.
 template <bool FROM_POOL>
-__global__ __launch_bounds__(256) void k_pw_bwd_bf16(const ww_bf16 *__restrict__ g, const float *__restrict__ dpool,
-                                                     const ww_bf16 *__restrict__ y_out, const float *__restrict__ ss_out,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_pw_bwd_bf16(const ww_bf16 *__restrict__ g, const float *__restrict__ dpool,
+                                                     const float *__restrict__ ss_out,
                                                      const float *__restrict__ coef, const ww_bf16 *__restrict__ y_in,
                                                      const float *__restrict__ ss_in, const float *__restrict__ mr_in,
                                                      const float *__restrict__ w, long M, int HW,
                                                      ww_bf16 *__restrict__ g_in, float *__restrict__ stat_partials,
                                                      float *__restrict__ dw_partials) {
-    __shared__ __align__(16) ww_bf16 tiles[3 * PWB_TILE * PWH_LD];
-    __shared__ __align__(16) float otile[PWB_TILE * PW_LD];
-    ww_bf16 *dyt = tiles, *yit = tiles + PWB_TILE * PWH_LD, *at = tiles + 2 * PWB_TILE * PWH_LD;
+    // dy, a = relu(bn(y_in)), and two y_in tiles (even / odd tile of the unrolled loop): g_in overwrites the raw y_in tile
+    // in place and is stored from there while the next tile is staged into the other one.  36.9 KB -> 4 workgroups per CU.
+    // + the 64x64 weights (bf16): both MFMA B operands come from this one copy (row reads forward, transposing reads for dX)
+    __shared__ __align__(16) ww_bf16 tiles[5 * PWB_TILE * PWH_LD];
+    ww_bf16 *dyt = tiles, *at = tiles + PWB_TILE * PWH_LD, *yit0 = tiles + 2 * PWB_TILE * PWH_LD, *yit1 = tiles + 3 * PWB_TILE * PWH_LD;
+    ww_bf16 *wtile = tiles + 4 * PWB_TILE * PWH_LD;
     typedef Act<ww_bf16> A16;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int rh = wv >> 1, n = wv & 1;   // dX: pixels [32rh,+32) x in-channels [32n,+32); dW: quadrant (jt,kt) = (rh,n)
-    // dX B operand of k-step t: B[j = 16t + 8h + jj][k = 32n + r] = w[j][k]
-    bf16x8 wt[4];
+    const int rh = wv >> 1, n = wv & 1;   // y/dX: pixels [32rh,+32) x channels [32n,+32); dW: quadrant (jt,kt) = (rh,n)
+    const int ch = 32 * n + r;
+    // forward B operand of k-step t: B[k = 16t + 8h + jj][j = ch] = w[ch][k] (ds_read_b128 of a wtile row);
+    // dX B operand:                  B[j = 16t + 8h + jj][k = ch] = w[j][ch]  (transposing read of the same tile)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = w[(size_t)(16 * t + 8 * h + j) * 64 + 32 * n + r];
-        wt[t] = pack8b(v);
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 4) + 16 * i, c = 4 * (tid & 15);
+        const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)row * 64 + c);
+        *reinterpret_cast<uint2 *>(wtile + row * PWH_LD + c) = make_uint2(Act<ww_bf16>::pack2(v.x, v.y), Act<ww_bf16>::pack2(v.z, v.w));
     }
     const int c4 = tid & 15;
-    const float4 cA = *reinterpret_cast<const float4 *>(coef + 4 * c4);
-    const float4 cB = *reinterpret_cast<const float4 *>(coef + 64 + 4 * c4);
-    const float4 cC = *reinterpret_cast<const float4 *>(coef + 128 + 4 * c4);
+    const float cA = coef[ch], cB = coef[64 + ch], cC = coef[128 + ch];
     const float4 si = *reinterpret_cast<const float4 *>(ss_in + 4 * c4);
     const float4 ti4 = *reinterpret_cast<const float4 *>(ss_in + 64 + 4 * c4);
-    float4 so = make_float4(0.f, 0.f, 0.f, 0.f), to = so;
+    float so = 0.f, to = 0.f;
     if (FROM_POOL) {
-        so = *reinterpret_cast<const float4 *>(ss_out + 4 * c4);
-        to = *reinterpret_cast<const float4 *>(ss_out + 64 + 4 * c4);
+        so = ss_out[ch];
+        to = ss_out[64 + ch];
     }
-    const float sci = ss_in[32 * n + r], sfi = ss_in[64 + 32 * n + r];
-    const float mui = mr_in[32 * n + r], rsi = mr_in[64 + 32 * n + r];
+    const float sci = ss_in[ch], sfi = ss_in[64 + ch];
+    const float mui = mr_in[ch], rsi = mr_in[64 + ch];
     floatx16 dwacc = {0.f};
     float st1 = 0.f, st2 = 0.f;
 
     const long ntiles = (M + PWB_TILE - 1) / PWB_TILE;
-    A16::raw4 rg[4], ro[4], ri[4];
-    auto issue = [&](long ti) {
+    const long last_img = (M - 1) / HW;
+    A16::raw4 rg0[4], ri0[4];
+    float dpA0 = 0.f, dpB0 = 0.f;   // pooled gradient of the (at most two, when HW >= tile) images of a tile
+    auto issue = [&](long ti, A16::raw4 (&rg)[4], A16::raw4 (&ri)[4], float &ndpA, float &ndpB) {
+        if (ti >= ntiles) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             long p = ti * PWB_TILE + (tid >> 4) + 16 * i;
             p = p < M ? p : M - 1;
-            ro[i] = A16::ldraw4(y_out + (size_t)p * 64 + 4 * c4);
             ri[i] = A16::ldraw4(y_in + (size_t)p * 64 + 4 * c4);
             if (!FROM_POOL) rg[i] = A16::ldraw4(g + (size_t)p * 64 + 4 * c4);
         }
+        if (FROM_POOL && HW >= PWB_TILE) {
+            const long b0 = ti * PWB_TILE / HW;
+            ndpA = dpool[(size_t)b0 * 64 + ch];
+            ndpB = dpool[(size_t)(b0 < last_img ? b0 + 1 : last_img) * 64 + ch];
+        }
     };
-    if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
-    for (long ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+    auto tile = [&](long ti, ww_bf16 *yit, A16::raw4 (&rg)[4], A16::raw4 (&ri)[4], float &ndpA, float &ndpB) {
         const long p0 = ti * PWB_TILE;
+        const float dpA = ndpA, dpB = ndpB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (tid >> 4) + 16 * i;
-            const long p = p0 + row;
-            const bool ok = p < M;
-            const float4 yo = A16::cvt4(ro[i]);
+            const bool ok = p0 + row < M;
             const float4 yr = A16::cvt4(ri[i]);
-            float4 dz;
-            if (FROM_POOL) {
-                const float4 dp = *reinterpret_cast<const float4 *>(dpool + (size_t)((ok ? p : M - 1) / HW) * 64 + 4 * c4);
-                dz.x = fmaf(yo.x, so.x, to.x) > 0.f ? dp.x : 0.f;
-                dz.y = fmaf(yo.y, so.y, to.y) > 0.f ? dp.y : 0.f;
-                dz.z = fmaf(yo.z, so.z, to.z) > 0.f ? dp.z : 0.f;
-                dz.w = fmaf(yo.w, so.w, to.w) > 0.f ? dp.w : 0.f;
-            } else {
-                dz = A16::cvt4(rg[i]);
-            }
-            const float d0 = ok ? fmaf(cA.x, dz.x, fmaf(cB.x, yo.x, cC.x)) : 0.f;
-            const float d1 = ok ? fmaf(cA.y, dz.y, fmaf(cB.y, yo.y, cC.y)) : 0.f;
-            const float d2 = ok ? fmaf(cA.z, dz.z, fmaf(cB.z, yo.z, cC.z)) : 0.f;
-            const float d3 = ok ? fmaf(cA.w, dz.w, fmaf(cB.w, yo.w, cC.w)) : 0.f;
             const float z0 = fmaf(yr.x, si.x, ti4.x), z1 = fmaf(yr.y, si.y, ti4.y);
             const float z2 = fmaf(yr.z, si.z, ti4.z), z3 = fmaf(yr.w, si.w, ti4.w);
             const float a0 = !ok || z0 < 0.f ? 0.f : z0, a1 = !ok || z1 < 0.f ? 0.f : z1;
             const float a2 = !ok || z2 < 0.f ? 0.f : z2, a3 = !ok || z3 < 0.f ? 0.f : z3;
-            *reinterpret_cast<uint2 *>(dyt + row * PWH_LD + 4 * c4) = make_uint2(A16::pack2(d0, d1), A16::pack2(d2, d3));
             *reinterpret_cast<uint2 *>(at + row * PWH_LD + 4 * c4) = make_uint2(A16::pack2(a0, a1), A16::pack2(a2, a3));
             *reinterpret_cast<uint2 *>(yit + row * PWH_LD + 4 * c4) = ok ? ri[i] : make_uint2(0u, 0u);
+            if (!FROM_POOL) *reinterpret_cast<uint2 *>(dyt + row * PWH_LD + 4 * c4) = rg[i];   // raw dz; dy in place below
+        }
+        issue(ti + (long)gridDim.x, rg, ri, ndpA, ndpB);
+        __syncthreads();
+        const int rbase = 32 * rh;
+        // ---- y = a . W^T as the forward computed it, then dy = A dz + B y + C in place (each element is owned by one lane)
+        {
+            floatx16 yacc = {0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(at + (rbase + r) * PWH_LD + 16 * t + 8 * h);
+                const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wtile + ch * PWH_LD + 16 * t + 8 * h);
+                yacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf, yacc, 0, 0, 0);
+            }
+            const long bnd = FROM_POOL ? (p0 / HW + 1) * (long)HW : 0;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const long p = p0 + prow;
+                const bool ok = p < M;
+                const float yv = A16::round1(yacc[reg]);
+                float dz;
+                if (FROM_POOL) {
+                    const float dp = HW >= PWB_TILE ? (p >= bnd ? dpB : dpA) : dpool[(size_t)((ok ? p : M - 1) / HW) * 64 + ch];
+                    dz = fmaf(yv, so, to) > 0.f ? dp : 0.f;
+                } else {
+                    dz = (float)dyt[prow * PWH_LD + ch];
+                }
+                const float d = ok ? fmaf(cA, dz, fmaf(cB, yv, cC)) : 0.f;
+                dyt[prow * PWH_LD + ch] = (ww_bf16)d;
+            }
         }
         __syncthreads();
-        if (ti + gridDim.x < ntiles) issue(ti + gridDim.x);
         // ---- dX = dy . W
         {
-            const int rbase = 32 * rh;
             floatx16 acc = {0.f};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8 *>(dyt + (rbase + r) * PWH_LD + 16 * t + 8 * h);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wt[t], acc, 0, 0, 0);
+                const bf16x8 wt = tr_operand(wtile, 16 * t, 32 * n, lane);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wt, acc, 0, 0, 0);
             }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const float yv = (float)yit[prow * PWH_LD + 32 * n + r];
+                const float yv = (float)yit[prow * PWH_LD + ch];
                 const float d = A16::round1(fmaf(yv, sci, sfi) > 0.f ? acc[reg] : 0.f);
-                otile[prow * PW_LD + 32 * n + r] = d;
+                yit[prow * PWH_LD + ch] = (ww_bf16)d;
                 st1 += d;
                 st2 = fmaf(d, (yv - mui) * rsi, st2);
             }
@@ -386,13 +410,19 @@ __global__ __launch_bounds__(256) void k_pw_bwd_bf16(const ww_bf16 *__restrict__
         for (int i = 0; i < 4; ++i) {
             const int row = (tid >> 4) + 16 * i;
             if (p0 + row < M)
-                A16::st4(g_in + (size_t)(p0 + row) * 64 + 4 * c4, *reinterpret_cast<const float4 *>(otile + row * PW_LD + 4 * c4));
+                *reinterpret_cast<uint2 *>(g_in + (size_t)(p0 + row) * 64 + 4 * c4) =
+                    *reinterpret_cast<const uint2 *>(yit + row * PWH_LD + 4 * c4);
         }
+    };
+    issue(blockIdx.x, rg0, ri0, dpA0, dpB0);
+    for (long ti = blockIdx.x; ti < ntiles; ti += 2 * (long)gridDim.x) {
+        tile(ti, yit0, rg0, ri0, dpA0, dpB0);
+        if (ti + gridDim.x < ntiles) tile(ti + gridDim.x, yit1, rg0, ri0, dpA0, dpB0);
     }
     st1 += __shfl_xor(st1, 32);
     st2 += __shfl_xor(st2, 32);
     __syncthreads();
-    float *shs = otile;  // [wave][kind][32]
+    float *shs = reinterpret_cast<float *>(tiles);  // [wave][kind][32]
     if (h == 0) {
         shs[wv * 64 + r] = st1;
         shs[wv * 64 + 32 + r] = st2;
@@ -685,11 +715,11 @@ int launch_pw_bwd_bf16(ww_ctx *ctx, const void *g, const float *dpool, const voi
     ww_prof_scope ps_(ctx, WW_K_PW_BWD, st);
     if (g) {
         grid = ww_occupancy_grid((const void *)k_pw_bwd_bf16<false>, 256, 0, ntiles, WW_DW_SLAB_ROWS);
-        hipLaunchKernelGGL(k_pw_bwd_bf16<false>, dim3(grid), dim3(256), 0, st, (cp)g, dpool, (cp)y_out, ss_out, coef,
+        hipLaunchKernelGGL(k_pw_bwd_bf16<false>, dim3(grid), dim3(256), 0, st, (cp)g, dpool, ss_out, coef,
                            (cp)y_in, ss_in, mr_in, w, M, HW, (ww_bf16 *)g_in, stat, dwp);
     } else {
         grid = ww_occupancy_grid((const void *)k_pw_bwd_bf16<true>, 256, 0, ntiles, WW_DW_SLAB_ROWS);
-        hipLaunchKernelGGL(k_pw_bwd_bf16<true>, dim3(grid), dim3(256), 0, st, (cp)g, dpool, (cp)y_out, ss_out, coef,
+        hipLaunchKernelGGL(k_pw_bwd_bf16<true>, dim3(grid), dim3(256), 0, st, (cp)g, dpool, ss_out, coef,
                            (cp)y_in, ss_in, mr_in, w, M, HW, (ww_bf16 *)g_in, stat, dwp);
     }
     *grid_out = grid;

@@ -94,7 +94,7 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
 //   [0, 1024*128)            BN-statistics partials  (rows x [sum(64) | sumsq(64)])
 //   [1024*128, +256*4096)    weight-gradient partials (rows x up to 4096 cols)
 #define WW_STAT_SLAB_FLOATS (WW_MAX_PARTIALS * 128)
-#define WW_DW_SLAB_ROWS 512
+#define WW_DW_SLAB_ROWS 768
 #define WW_DW_SLAB_FLOATS (WW_DW_SLAB_ROWS * 4096)
 
 // finalize launchers (ww_reduce.hip)
