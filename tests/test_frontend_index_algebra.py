@@ -1,6 +1,7 @@
 """CPU: numpy emulation of k_logmel's FFT index algebra (wakeword_trainer_home_amd/csrc/ww_frontend.hip):
-1024 = 16 x 16 x 4 decomposition with 16 points per lane, the padded LDS slot map, the in-place passes 2/3,
-the fft16 output-slot permutation, and the separation of two real frames packed into one complex FFT.
+1024 = 16 x 16 x 4 decomposition with 16 points per lane, the padded LDS slot map, the in-place pass 2,
+the fft16 output-slot permutation, and pass 3 fused with the separation of two real frames packed into one complex FFT
+(butterfly pairs that hold X[k] and X[N-k] in one lane's registers).
 The HIP kernel transcribes exactly these index formulas; the GPU tests then check the arithmetic."""
 import numpy as np
 
@@ -59,21 +60,50 @@ def test_packed_1024_point_fft_index_algebra():
     assert touched_r == touched_w and len(touched_r) == 1024          # in place: each lane rewrites its own slots
     for kc in range(16):
         buf[kb2 * STRIDE + 4 * kc + q] = regs[slot(kc)] * W(16 * q * kc, 1, 1024)
-    # pass 3 (in place): radix-4 over the 4 consecutive slots of (kb, kc = (lane&3) + 4u)
-    for u in range(4):
-        base = kb2 * STRIDE + ((lane & 3) + 4 * u) * 4
-        o = fft4(buf[base], buf[base + 1], buf[base + 2], buf[base + 3])
-        for kd in range(4):
-            buf[base + kd] = o[kd]
-    # X[k] lives at [k&15][4*((k>>4)&15) + (k>>8)]
-    k = np.arange(N)
-    X = buf[(k & 15) * STRIDE + 4 * ((k >> 4) & 15) + (k >> 8)]
-    assert np.abs(X - np.fft.fft(xa + 1j * xb)).max() < 1e-10
-    # separation of the two real spectra + power, as in the kernel
-    kk = np.arange(513)
-    A, Bv = X[kk], X[(N - kk) & 1023]
-    pa = 0.25 * ((A.real + Bv.real) ** 2 + (A.imag - Bv.imag) ** 2)
-    pb = 0.25 * ((A.imag + Bv.imag) ** 2 + (A.real - Bv.real) ** 2)
+    # the factors of passes 1 and 2 come from six table entries: W^(base*k) = W^(4*base*a) * W^(base*b), k = 4a + b
+    for base in (int(lane[37]), 16 * 3):
+        for kk in range(16):
+            assert abs(W(base * 4 * (kk >> 2), 1, 1024) * W(base * (kk & 3), 1, 1024) - W(base * kk, 1, 1024)) < 1e-14
+    # pass 3 fused with the separation: 128 units = pairs of butterflies (kb, kc) / (16-kb, 15-kc) whose outputs are
+    # X[k] and X[N-k] (kd' = 3 - kd), plus one unit with the two self-paired butterflies (0,0) and (0,8)
+    PB = np.full((2, 548), np.nan)
+    written = []
+
+    def emit(X_, Y_, kbin):
+        j = kbin if kbin <= 512 else N - kbin
+        pj = j + (j >> 4)
+        assert pj < 548
+        written.append(j)
+        PB[0, pj] = 0.25 * ((X_.real + Y_.real) ** 2 + (X_.imag - Y_.imag) ** 2)
+        PB[1, pj] = 0.25 * ((X_.imag + Y_.imag) ** 2 + (X_.real - Y_.real) ** 2)
+
+    for idx in range(128):
+        if idx < 112:
+            kbA, kcA = 1 + (idx >> 4), idx & 15
+            kbB, kcB = 16 - kbA, 15 - kcA
+        elif idx < 120:
+            kbA, kcA = 8, idx - 112
+            kbB, kcB = 8, 15 - kcA
+        elif idx < 127:
+            kbA, kcA = 0, idx - 119
+            kbB, kcB = 0, 16 - kcA
+        else:
+            kbA, kcA, kbB, kcB = 0, 0, 0, 8
+        sa, sb = kbA * STRIDE + 4 * kcA, kbB * STRIDE + 4 * kcB
+        oa = fft4(buf[sa], buf[sa + 1], buf[sa + 2], buf[sa + 3])
+        ob = fft4(buf[sb], buf[sb + 1], buf[sb + 2], buf[sb + 3])
+        if idx != 127:
+            for kd in range(4):
+                emit(oa[kd], ob[3 - kd], 16 * kcA + kbA + 256 * kd)
+        else:
+            emit(oa[0], oa[0], 0)
+            emit(oa[1], oa[3], 256)
+            emit(oa[2], oa[2], 512)
+            emit(ob[0], ob[3], 128)
+            emit(ob[1], ob[2], 384)
+    assert sorted(written) == list(range(513))                         # every bin 0..512 exactly once
+    j = np.arange(513)
+    pa, pb = PB[0, j + (j >> 4)], PB[1, j + (j >> 4)]
     assert np.abs(pa - np.abs(np.fft.rfft(xa)) ** 2).max() < 1e-8
     assert np.abs(pb - np.abs(np.fft.rfft(xb)) ** 2).max() < 1e-8
 

@@ -6,13 +6,14 @@
 // access (6.4x frame overlap at hop 160) is served from LDS.  Each wavefront transforms TWO
 // real frames as one 1024-point complex FFT held 16 points/lane, decomposed 16 x 16 x 4:
 //   pass 1  radix-16 in registers over n2 (n = lane + 64*n2), twiddle W1024^(lane*kb) -> LDS
-//   pass 2  radix-16 in registers over m  (lane = kb*4+q, n1 = 4m+q), twiddle W64^(q*kc) -> LDS
-//   pass 3  four radix-4 butterflies per lane -> X[16kc + 256kd + kb] -> LDS (natural order)
-// (passes 2 and 3 run IN PLACE: each lane rewrites exactly the 16 LDS slots it read, so one 8.7 KB buffer per
-// wavefront suffices and two workgroups fit a CU).  Then the two real spectra are separated (X[k], conj X[N-k]),
-// |.|^2 goes to LDS, every mel band is summed by two adjacent lanes (half a band each, weights staged in LDS,
-// combined with one shuffle), and the 16 x F tile is transposed through LDS so the (B,1,F,T) output is
-// written in 64-byte runs along T.
+//   pass 2  radix-16 in registers over m  (lane = kb*4+q, n1 = 4m+q), twiddle W64^(q*kc) -> LDS (in place: each lane
+//           rewrites exactly the 16 slots it read, so one 8.7 KB buffer per wavefront suffices)
+//   pass 3  radix-4 butterflies X[16kc + 256kd + kb], run in PAIRS that produce X[k] and X[N-k] in the same lane: the two
+//           real spectra are separated in registers and |.|^2 goes straight to the power buffers (no return to LDS)
+// The window samples and the twiddle factors a lane needs are the same for every frame: they are loaded once into
+// registers (16 + 24 VGPRs; the kernel runs two workgroups per CU on its LDS footprint, so VGPRs are free).  Every mel
+// band is then summed by two adjacent lanes (half a band each, weights staged in LDS, combined with one shuffle), and the
+// 16 x F tile is transposed through LDS so the (B,1,F,T) output is written in 64-byte runs along T.
 // Index algebra verified against numpy (tests/test_frontend_index_algebra.py).
 #include "ww_internal.h"
 
@@ -21,6 +22,7 @@ namespace {
 constexpr int FR = WW_FRAMES_PER_BLOCK;
 constexpr int BUF_STRIDE = 68;               // float2 per kb row (64 + 4 pad)
 constexpr int BUF_ELEMS = 16 * BUF_STRIDE;   // 1088 float2 per buffer
+constexpr int PB_LD = 548;                   // floats per power spectrum: bin j sits at j + (j >> 4) (bank spreading)
 
 #include "ww_fft.h"
 
@@ -49,14 +51,42 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// v[F16_SLOT(k)] *= W^(base*k), k = 0..15, then store to dst(k).  The 15 factors come from SIX table entries (t1[b] =
+// W^(base*b), t4[a] = W^(4*base*a), a, b = 1..3) held in registers for the whole kernel (base depends on the lane only)
+// and one complex product each for the nine mixed ones.
+struct Tw6 { float2 t1[4], t4[4]; };
+__device__ __forceinline__ Tw6 load_tw6(const float2 *__restrict__ tw, int base) {
+    Tw6 t;
+    t.t1[0] = t.t4[0] = make_float2(1.f, 0.f);
+#pragma unroll
+    for (int b = 1; b < 4; ++b) {
+        t.t1[b] = tw[(base * b) & 1023];
+        t.t4[b] = tw[(base * 4 * b) & 1023];
+    }
+    return t;
+}
+template <typename Dst>
+__device__ __forceinline__ void twiddle_store16(float (&re)[16], float (&im)[16], const Tw6 &t, Dst dst) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float r = re[F16_SLOT(k)], i = im[F16_SLOT(k)];
+        const int a = k >> 2, b = k & 3;
+        float wr, wi;
+        if (a == 0) { wr = t.t1[b].x; wi = t.t1[b].y; }
+        else if (b == 0) { wr = t.t4[a].x; wi = t.t4[a].y; }
+        else { wr = t.t4[a].x; wi = t.t4[a].y; cmul_c(wr, wi, t.t1[b].x, t.t1[b].y); }
+        if (k) cmul_c(r, i, wr, wi);
+        *dst(k) = make_float2(r, i);
+    }
+}
+
 template <typename WaveT>
 __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ out,
                                                 int use_mask, ww_mask_params mp, int32_t *__restrict__ mask_idx) {
     extern __shared__ __align__(16) unsigned char smem[];
-    float2 *tw = reinterpret_cast<float2 *>(smem);                    // 1024
-    float2 *fbuf = tw + 1024;                                         // 4 waves x BUF_ELEMS
-    float *pb = reinterpret_cast<float *>(fbuf + 4 * BUF_ELEMS);      // 4 waves x 2 x 516 power spectra
-    float *lm = pb + 4 * 2 * 516;                                     // FR x M
+    float2 *fbuf = reinterpret_cast<float2 *>(smem);                  // 4 waves x BUF_ELEMS
+    float *pb = reinterpret_cast<float *>(fbuf + 4 * BUF_ELEMS);      // 4 waves x 2 x PB_LD power spectra
+    float *lm = pb + 4 * 2 * PB_LD;                                    // FR x M
     float *feat = lm + FR * a.M;                                      // FR x F (== lm when !use_dct)
     int *msk = reinterpret_cast<int *>(feat + (a.use_dct ? FR * a.F : 0));  // 2*WW_MAX_MASKS
     int *mtab = msk + 2 * WW_MAX_MASKS;                               // 3*M : start, len, offset
@@ -69,7 +99,6 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
     const WaveT *x = wave + (size_t)b * a.N;
 
     // ---- stage twiddles, SpecAugment masks and the sample span
-    for (int i = tid; i < 1024; i += 256) tw[i] = a.twiddle[i];
     for (int i = tid; i < a.M; i += 256) {
         mtab[3 * i] = a.mel_start[i];
         mtab[3 * i + 1] = a.mel_len[i];
@@ -100,7 +129,12 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
     __syncthreads();
 
     float2 *buf = fbuf + wv * BUF_ELEMS;
-    float *pbuf = pb + wv * 2 * 516;
+    float *pbuf = pb + wv * 2 * PB_LD;
+    // per-lane constants of both rounds: the window samples n = lane + 64 j and the twiddle factors of passes 1 and 2
+    float win[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) win[j] = a.window[lane + 64 * j];
+    const Tw6 tw1 = load_tw6(a.twiddle, lane), tw2 = load_tw6(a.twiddle, 16 * (lane & 3));
 
     for (int round = 0; round < 2; ++round) {
         const int fa = round * 8 + 2 * wv, fb = fa + 1;  // local frame indices of this wave's pair
@@ -109,18 +143,12 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int n = lane + 64 * j;
-            const float w = a.window[n];
+            const float w = win[j];
             re[j] = w * span[fa * a.hop + n];
             im[j] = w * span[fb * a.hop + n];
         }
         fft16(re, im);
-#pragma unroll
-        for (int kb = 0; kb < 16; ++kb) {
-            float r = re[F16_SLOT(kb)], i = im[F16_SLOT(kb)];
-            const float2 t = tw[(lane * kb) & 1023];
-            cmul_c(r, i, t.x, t.y);
-            buf[kb * BUF_STRIDE + lane] = make_float2(r, i);
-        }
+        twiddle_store16(re, im, tw1, [&](int kb) { return buf + kb * BUF_STRIDE + lane; });
         wave_sync();
         // ---- pass 2: lane = kb*4 + q ; radix-16 over m (n1 = 4m + q), twiddle W64^(q*kc)
         const int kb2 = lane >> 2, q = lane & 3;
@@ -131,39 +159,51 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
             im[m] = v.y;
         }
         fft16(re, im);
-#pragma unroll
-        for (int kc = 0; kc < 16; ++kc) {
-            float r = re[F16_SLOT(kc)], i = im[F16_SLOT(kc)];
-            const float2 t = tw[(16 * q * kc) & 1023];
-            cmul_c(r, i, t.x, t.y);
-            buf[kb2 * BUF_STRIDE + kc * 4 + q] = make_float2(r, i);
-        }
+        twiddle_store16(re, im, tw2, [&](int kc) { return buf + kb2 * BUF_STRIDE + kc * 4 + q; });
         wave_sync();
-        // ---- pass 3 (in place): radix-4 over q for (kb, kc = (lane&3) + 4u); slot [kb][4kc + kd] <- X[16kc + 256kd + kb]
+        // ---- pass 3 fused with the separation of the two real spectra.  Butterfly (kb, kc) turns slots [kb][4kc + q] into
+        // X[16kc + 256kd + kb], kd = 0..3; X[1024 - k] comes out of butterfly (16 - kb, 15 - kc) (kb = 0: (0, 16 - kc)) at
+        // kd' = 3 - kd, so a lane that runs both has each (X[k], X[N-k]) pair in registers and writes |.|^2 of both frames
+        // straight to the power buffers: the transform never returns to LDS.  128 units = 127 butterfly pairs + one unit
+        // holding the two self-paired butterflies (0,0) and (0,8); two units per lane.
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float2 *s4 = buf + kb2 * BUF_STRIDE + ((lane & 3) + 4 * u) * 4;
-            const float2 v0 = s4[0], v1 = s4[1], v2 = s4[2], v3 = s4[3];
-            float r0 = v0.x, i0 = v0.y, r1 = v1.x, i1 = v1.y, r2 = v2.x, i2 = v2.y, r3 = v3.x, i3 = v3.y;
-            fft4(r0, i0, r1, i1, r2, i2, r3, i3);
-            s4[0] = make_float2(r0, i0);
-            s4[1] = make_float2(r1, i1);
-            s4[2] = make_float2(r2, i2);
-            s4[3] = make_float2(r3, i3);
-        }
-        wave_sync();
-        // ---- separate the two real spectra, power -> pbuf[frame][k];  X[k] lives at [k&15][4*((k>>4)&15) + (k>>8)]
+        for (int u = 0; u < 2; ++u) {
+            const int idx = lane + 64 * u;
+            int kbA, kcA, kbB, kcB;
+            if (idx < 112) { kbA = 1 + (idx >> 4); kcA = idx & 15; kbB = 16 - kbA; kcB = 15 - kcA; }
+            else if (idx < 120) { kbA = 8; kcA = idx - 112; kbB = 8; kcB = 15 - kcA; }
+            else if (idx < 127) { kbA = 0; kcA = idx - 119; kbB = 0; kcB = 16 - kcA; }
+            else { kbA = 0; kcA = 0; kbB = 0; kcB = 8; }
+            const bool special = u == 1 && idx == 127;
+            float ar[4], ai[4], br[4], bi[4];
+            {
+                const float2 *sa = buf + kbA * BUF_STRIDE + 4 * kcA, *sb = buf + kbB * BUF_STRIDE + 4 * kcB;
 #pragma unroll
-        for (int u = 0; u < 9; ++u) {
-            const int k = lane + 64 * u;
-            if (k <= 512) {
-                const int kn = (1024 - k) & 1023;
-                const float2 A = buf[(k & 15) * BUF_STRIDE + 4 * ((k >> 4) & 15) + (k >> 8)];
-                const float2 Bv = buf[(kn & 15) * BUF_STRIDE + 4 * ((kn >> 4) & 15) + (kn >> 8)];
-                const float xr = A.x + Bv.x, xi = A.y - Bv.y;   // 2*Xa
-                const float yr = A.y + Bv.y, yi = A.x - Bv.x;   // 2*Xb (up to sign of imag)
-                pbuf[k] = 0.25f * (xr * xr + xi * xi);
-                pbuf[516 + k] = 0.25f * (yr * yr + yi * yi);
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float2 va = sa[qq], vb = sb[qq];
+                    ar[qq] = va.x; ai[qq] = va.y; br[qq] = vb.x; bi[qq] = vb.y;
+                }
+            }
+            fft4(ar[0], ai[0], ar[1], ai[1], ar[2], ai[2], ar[3], ai[3]);
+            fft4(br[0], bi[0], br[1], bi[1], br[2], bi[2], br[3], bi[3]);
+            const int kbase = 16 * kcA + kbA;
+            auto emit = [&](float xr_, float xi_, float yr_, float yi_, int k) {   // X = X[k], Y = X[N-k]
+                const int j = k <= 512 ? k : 1024 - k;
+                const int pj = j + (j >> 4);
+                const float pr = xr_ + yr_, pi = xi_ - yi_;     // 2 * spectrum of frame a
+                const float qr = xi_ + yi_, qi = xr_ - yr_;     // 2 * spectrum of frame b (up to the sign of its imaginary part)
+                pbuf[pj] = 0.25f * (pr * pr + pi * pi);
+                pbuf[PB_LD + pj] = 0.25f * (qr * qr + qi * qi);
+            };
+            if (!special) {
+#pragma unroll
+                for (int kd = 0; kd < 4; ++kd) emit(ar[kd], ai[kd], br[3 - kd], bi[3 - kd], kbase + 256 * kd);
+            } else {
+                emit(ar[0], ai[0], ar[0], ai[0], 0);
+                emit(ar[1], ai[1], ar[3], ai[3], 256);
+                emit(ar[2], ai[2], ar[2], ai[2], 512);
+                emit(br[0], bi[0], br[3], bi[3], 128);
+                emit(br[1], bi[1], br[2], bi[2], 384);
             }
         }
         wave_sync();
@@ -178,11 +218,14 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
             const int h0 = (L + 1) >> 1;
             const int j0 = half ? h0 : 0, j1 = half ? L : h0;
             const float *wp = mw + mtab[3 * m + 2];
-            const float *pp = pbuf + fr * 516 + s;
+            const float *pp = pbuf + fr * PB_LD;
             float acc = 0.f;
             if (act) {
 #pragma unroll 4
-                for (int j = j0; j < j1; ++j) acc = fmaf(wp[j], pp[j], acc);
+                for (int j = j0; j < j1; ++j) {
+                    const int bin = s + j;
+                    acc = fmaf(wp[j], pp[bin + (bin >> 4)], acc);
+                }
             }
             acc += __shfl_xor(acc, 1);
             if (act && half == 0) lm[(fa + fr) * a.M + m] = logf(acc + a.log_eps);
@@ -311,7 +354,7 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
         if ((rc = resolve_mask(sa, seed, step, sample_offset, &mp))) return rc;
         use_mask = (mp.n_f + mp.n_t) > 0;
     }
-    const size_t smem = 1024 * sizeof(float2) + (size_t)4 * BUF_ELEMS * sizeof(float2) + (size_t)4 * 2 * 516 * sizeof(float) +
+    const size_t smem = (size_t)4 * BUF_ELEMS * sizeof(float2) + (size_t)4 * 2 * PB_LD * sizeof(float) +
                         (size_t)FR * a.M * sizeof(float) + (a.use_dct ? (size_t)FR * a.F * sizeof(float) : 0) +
                         2 * WW_MAX_MASKS * sizeof(int) + (size_t)3 * a.M * sizeof(int) + (size_t)a.n_mel_w * sizeof(float) +
                         (size_t)a.span_len * sizeof(float);
