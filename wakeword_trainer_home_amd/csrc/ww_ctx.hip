@@ -185,29 +185,38 @@ extern "C" size_t ww_layer_scratch_bytes(void) {
 // ------------------------------------------------------------------------------------------
 
 // Column sums for ONE group of 8 channels: columns 8*cg..+7 (first statistic) and 64 + 8*cg..+7 (second statistic) of
-// partials[rows][128], by one 256-thread block: thread = (one of the 4 float4 of a row's 16 values, 1 of 64 row parts).
+// partials[rows][128], by one 1024-thread block: thread = (one of the 4 float4 of a row's 16 values, 1 of 256 row parts),
+// so a slab of <= 1024 rows is one round of loads; the 256 parts are then summed in a fixed two-level order (16 x 16).
 // The finalize kernels run 8 such blocks side by side instead of one block sweeping all 128 columns: the sweep of the
 // 512 KB slab by a single CU was the whole cost of a finalize launch (7 us); channels are independent.
-// tot[0..7] = first statistic, tot[8..15] = second, valid after the call in every thread.
-// (every thread of the block must call it -- it contains barriers; threads >= 256 of a larger block only wait)
+// tot[0..15]: [0..7] = first statistic, [8..15] = second, valid after the call in every thread of the 1024.
 __device__ __forceinline__ void ww_colgroup_sum(const float *__restrict__ partials, int rows, int cg, double (*sh)[16],
                                                 double *tot /*16, shared*/) {
     const int q = threadIdx.x & 3, part = threadIdx.x >> 2;
-    if (threadIdx.x < 256) {
+    {
         const int col = (q < 2 ? 8 * cg + 4 * q : 64 + 8 * cg + 4 * (q - 2));
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 8
-        for (int r = part; r < rows; r += 64) {
+#pragma unroll 4
+        for (int r = part; r < rows; r += 256) {
             const float4 v = *reinterpret_cast<const float4 *>(partials + (size_t)r * 128 + col);
             a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
         }
         sh[part][4 * q] = a0; sh[part][4 * q + 1] = a1; sh[part][4 * q + 2] = a2; sh[part][4 * q + 3] = a3;
     }
     __syncthreads();
+    const int c = threadIdx.x & 15, seg = (threadIdx.x >> 4) & 15;   // threads < 256: column c, parts 16*seg .. +15
+    double t2 = 0.0;
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t2 += sh[16 * seg + p][c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) sh[seg][c] = t2;
+    __syncthreads();
     if (threadIdx.x < 16) {
         double t = 0.0;
-#pragma unroll 8
-        for (int p = 0; p < 64; ++p) t += sh[p][threadIdx.x];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += sh[p][threadIdx.x];
         tot[threadIdx.x] = t;
     }
     __syncthreads();
@@ -215,10 +224,10 @@ __device__ __forceinline__ void ww_colgroup_sum(const float *__restrict__ partia
 
 // BatchNorm2d training forward statistics (torch semantics: biased var for normalisation,
 // unbiased for running_var, running = (1-m)*running + m*batch).  grid 8 (channel groups), block 256
-__global__ __launch_bounds__(256) void k_bn_fwd_finalize(const float *__restrict__ partials, int rows,
-                                                         double count, ww_bn_t bn, float *__restrict__ ss,
-                                                         float *__restrict__ mr) {
-    __shared__ double sh[64][16];
+__global__ __launch_bounds__(1024) void k_bn_fwd_finalize(const float *__restrict__ partials, int rows,
+                                                          double count, ww_bn_t bn, float *__restrict__ ss,
+                                                          float *__restrict__ mr) {
+    __shared__ double sh[256][16];
     __shared__ double tot[16];
     ww_colgroup_sum(partials, rows, blockIdx.x, sh, tot);
     if (threadIdx.x < 8) {
@@ -276,11 +285,11 @@ __device__ __forceinline__ void bn_bwd_finalize_group(const float *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float *__restrict__ partials, int rows,
-                                                         double count, const float *__restrict__ gamma,
-                                                         const float *__restrict__ mr, float *__restrict__ coef,
-                                                         float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    __shared__ double sh[64][16];
+__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float *__restrict__ partials, int rows,
+                                                          double count, const float *__restrict__ gamma,
+                                                          const float *__restrict__ mr, float *__restrict__ coef,
+                                                          float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ double sh[256][16];
     __shared__ double tot[16];
     bn_bwd_finalize_group(partials, rows, count, blockIdx.x, gamma, mr, coef, dgamma, dbeta, sh, tot);
 }
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(1024) void k_colsum(const float *__restrict__ parti
 }
 
 // one launch for a backward layer's two reductions: blocks 0..7 = BatchNorm-backward constants of the input layer (one
-// channel group each, their first 256 threads), blocks 8.. = column sums of the weight-gradient slab
+// channel group each), blocks 8.. = column sums of the weight-gradient slab
 __global__ __launch_bounds__(1024) void k_bwd_finalize(const float *__restrict__ stat, int rows, double count,
                                                        const float *__restrict__ gamma, const float *__restrict__ mr,
                                                        float *__restrict__ coef, float *__restrict__ dgamma,
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(1024) void k_bwd_finalize(const float *__restrict__
 
 int ww_launch_bn_fwd_finalize(const float *partials, int rows, double count, const ww_bn_t *bn, float *ss_out,
                               float *mr_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3(8), dim3(256), 0, st, partials, rows, count, *bn, ss_out, mr_out);
+    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3(8), dim3(1024), 0, st, partials, rows, count, *bn, ss_out, mr_out);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -346,7 +355,7 @@ int ww_launch_bn_eval_ss(const ww_bn_t *bn, float *ss_out, float *mr_out, hipStr
 }
 int ww_launch_bn_bwd_finalize(const float *partials, int rows, double count, const float *gamma,
                               const float *mr, float *coef_out, float *dgamma, float *dbeta, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(8), dim3(256), 0, st, partials, rows, count, gamma, mr, coef_out,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(8), dim3(1024), 0, st, partials, rows, count, gamma, mr, coef_out,
                        dgamma, dbeta);
     WW_LAUNCH_CHECK();
     return WW_OK;
