@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const T *__restrict__ g, cons
             const float4 yr = Act<T>::cvt4(ri[i]);
             float4 dz;
             if (FROM_POOL) {
-                const float4 dp = *reinterpret_cast<const float4 *>(dpool + (size_t)((ok ? p : M - 1) / HW) * 64 + 4 * c4);
+                const float4 dp = *reinterpret_cast<const float4 *>(dpool + (size_t)((uint32_t)(ok ? p : M - 1) / (uint32_t)HW) * 64 + 4 * c4);
                 dz.x = fmaf(yo.x, so.x, to.x) > 0.f ? dp.x : 0.f;
                 dz.y = fmaf(yo.y, so.y, to.y) > 0.f ? dp.y : 0.f;
                 dz.z = fmaf(yo.z, so.z, to.z) > 0.f ? dp.z : 0.f;
@@ -272,7 +272,9 @@ __device__ __forceinline__ bf16x8 tr_operand(const ww_bf16 *tile, int p0, int c0
 // The layer's own output y_out is NOT read back: it is recomputed from the a tile with the forward kernel's exact
 // MFMA chain (same operands, same k order, same RNE rounding to bf16 -> bit-identical to the tensor k_pw_fwd_bf16
 // stored), which trades one activation-tensor read (97 MB at the full batch) for 4 MFMAs per wave and a third barrier.
-template <bool FROM_POOL>
+// WIDE_IMG: an image has at least one tile of pixels (HW >= 64), so a tile touches at most two images and their pooled
+// gradients are two registers; the per-pixel lookup (a division per element) is compiled only into the other variant.
+template <bool FROM_POOL, bool WIDE_IMG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_pw_bwd_bf16(const ww_bf16 *__restrict__ g, const float *__restrict__ dpool,
                                                      const float *__restrict__ ss_out,
                                                      const float *__restrict__ coef, const ww_bf16 *__restrict__ y_in,
@@ -326,8 +328,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             ri[i] = A16::ldraw4(y_in + (size_t)p * 64 + 4 * c4);
             if (!FROM_POOL) rg[i] = A16::ldraw4(g + (size_t)p * 64 + 4 * c4);
         }
-        if (FROM_POOL && HW >= PWB_TILE) {
-            const long b0 = ti * PWB_TILE / HW;
+        if (FROM_POOL && WIDE_IMG) {
+            const long b0 = (long)((uint32_t)(ti * PWB_TILE) / (uint32_t)HW);   // M < 2^31 (checked on the host): 32-bit division
             ndpA = dpool[(size_t)b0 * 64 + ch];
             ndpB = dpool[(size_t)(b0 < last_img ? b0 + 1 : last_img) * 64 + ch];
         }
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const float a2 = !ok || z2 < 0.f ? 0.f : z2, a3 = !ok || z3 < 0.f ? 0.f : z3;
             *reinterpret_cast<uint2 *>(at + row * PWH_LD + 4 * c4) = make_uint2(A16::pack2(a0, a1), A16::pack2(a2, a3));
             *reinterpret_cast<uint2 *>(yit + row * PWH_LD + 4 * c4) = ok ? ri[i] : make_uint2(0u, 0u);
-            if (!FROM_POOL) *reinterpret_cast<uint2 *>(dyt + row * PWH_LD + 4 * c4) = rg[i];   // raw dz; dy in place below
+            if (!FROM_POOL) *reinterpret_cast<uint2 *>(dyt + row * PWH_LD + 4 * c4) = ok ? rg[i] : make_uint2(0u, 0u);   // raw dz; dy in place below
         }
         issue(ti + (long)gridDim.x, rg, ri, ndpA, ndpB);
         __syncthreads();
@@ -360,21 +362,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wtile + ch * PWH_LD + 16 * t + 8 * h);
                 yacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf, yacc, 0, 0, 0);
             }
-            const long bnd = FROM_POOL ? (p0 / HW + 1) * (long)HW : 0;
+            const int p0i = (int)p0, Mi = (int)M;
+            const int bnd = FROM_POOL ? (int)(((uint32_t)p0 / (uint32_t)HW + 1u) * (uint32_t)HW) : 0;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                const long p = p0 + prow;
-                const bool ok = p < M;
-                const float yv = A16::round1(yacc[reg]);
+                const int p = p0i + prow;                      // M < 2^31 (host check)
+                const float okf = p < Mi ? 1.f : 0.f;          // a factor, not a select: keeps the 16 LDS reads branch-free
+                const float yv = A16::round1(yacc[reg]);       // (rows >= M hold dz = 0, a = 0 -> y = 0: the product is finite)
                 float dz;
                 if (FROM_POOL) {
-                    const float dp = HW >= PWB_TILE ? (p >= bnd ? dpB : dpA) : dpool[(size_t)((ok ? p : M - 1) / HW) * 64 + ch];
+                    const float dp = WIDE_IMG ? (p >= bnd ? dpB : dpA) : dpool[(size_t)((uint32_t)min(p, Mi - 1) / (uint32_t)HW) * 64 + ch];
                     dz = fmaf(yv, so, to) > 0.f ? dp : 0.f;
                 } else {
                     dz = (float)dyt[prow * PWH_LD + ch];
                 }
-                const float d = ok ? fmaf(cA, dz, fmaf(cB, yv, cC)) : 0.f;
+                const float d = okf * fmaf(cA, dz, fmaf(cB, yv, cC));
                 dyt[prow * PWH_LD + ch] = (ww_bf16)d;
             }
         }
@@ -713,15 +716,14 @@ int launch_pw_bwd_bf16(ww_ctx *ctx, const void *g, const float *dpool, const voi
     const long ntiles = (M + PWB_TILE - 1) / PWB_TILE;
     int grid;
     ww_prof_scope ps_(ctx, WW_K_PW_BWD, st);
-    if (g) {
-        grid = ww_occupancy_grid((const void *)k_pw_bwd_bf16<false>, 256, 0, ntiles, WW_DW_SLAB_ROWS);
-        hipLaunchKernelGGL(k_pw_bwd_bf16<false>, dim3(grid), dim3(256), 0, st, (cp)g, dpool, ss_out, coef,
-                           (cp)y_in, ss_in, mr_in, w, M, HW, (ww_bf16 *)g_in, stat, dwp);
-    } else {
-        grid = ww_occupancy_grid((const void *)k_pw_bwd_bf16<true>, 256, 0, ntiles, WW_DW_SLAB_ROWS);
-        hipLaunchKernelGGL(k_pw_bwd_bf16<true>, dim3(grid), dim3(256), 0, st, (cp)g, dpool, ss_out, coef,
-                           (cp)y_in, ss_in, mr_in, w, M, HW, (ww_bf16 *)g_in, stat, dwp);
-    }
+    auto go = [&](auto kern) {
+        grid = ww_occupancy_grid((const void *)kern, 256, 0, ntiles, WW_DW_SLAB_ROWS);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, (cp)g, dpool, ss_out, coef, (cp)y_in, ss_in, mr_in, w, M, HW,
+                           (ww_bf16 *)g_in, stat, dwp);
+    };
+    if (g) go(k_pw_bwd_bf16<false, true>);
+    else if (HW >= PWB_TILE) go(k_pw_bwd_bf16<true, true>);
+    else go(k_pw_bwd_bf16<true, false>);
     *grid_out = grid;
     return WW_OK;
 }
@@ -785,6 +787,8 @@ extern "C" int ww_pwconv1x1_bwd(ww_ctx *ctx, int act_dtype, const void *g, const
                WW_E_INVALID, "ww_pwconv1x1_bwd: null argument");
     WW_REQUIRE(g || (dpool && ss_out), WW_E_INVALID, "ww_pwconv1x1_bwd: need g, or dpool + ss_out for the last layer");
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_pwconv1x1_bwd: bad shape (%d,%d,%d)", B, H, W);
+    WW_REQUIRE((long)B * H * W < (1L << 31), WW_E_UNSUPPORTED, "ww_pwconv1x1_bwd: B*H*W = %ld pixels exceed 2^31",
+               (long)B * H * W);
     int rc = check_act_b("ww_pwconv1x1_bwd", act_dtype);
     if (rc) return rc;
     const long M = (long)B * H * W;
