@@ -38,9 +38,9 @@ ALGO_BYTES = {
 }
 
 
-# HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01_j_pmc_summary.md), measured
+# HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01_o_pmc_summary.md), measured
 # on exactly this command at the default batch 512 / bf16.  Reported as roofline.traffic only for that configuration.
-TRAFFIC_BYTES_B512_BF16 = {"dwconv3x3_bwd": 412.8e6, "pwconv1x1_bwd": 382.8e6, "dwconv3x3_fwd": 205.8e6,
+TRAFFIC_BYTES_B512_BF16 = {"dwconv3x3_bwd": 412.8e6, "pwconv1x1_bwd": 287.6e6, "dwconv3x3_fwd": 205.8e6,
                            "pwconv1x1_fwd": 199.9e6, "conv_stem_bwd": 223.5e6, "conv_stem_fwd": 119.7e6, "gap_fwd": 100.1e6,
                            "logmel_specaug": 84.6e6}
 
