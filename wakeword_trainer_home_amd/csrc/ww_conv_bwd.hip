@@ -458,7 +458,7 @@ __device__ __forceinline__ void dwb_issue(const T *__restrict__ gimg, const T *_
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int wc = min(max(w0 - 1 + i, 0), W - 1);
-        const size_t o = ((size_t)hh * W + wc) * 64 + 2 * cl;
+        const uint32_t o = (uint32_t)((hh * W + wc) * 64 + 2 * cl);   // one image < 2^32 elements: 32-bit offsets
         rg[i] = Act<T>::ldraw2(gimg + o);
         ry[i] = Act<T>::ldraw2(yimg + o);
     }
@@ -485,7 +485,7 @@ __device__ __forceinline__ void dwb_issue_centre(const T *__restrict__ yin_img, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int wc = min(w0 + i, W - 1);
-        rc[i] = Act<T>::ldraw2(yin_img + ((size_t)hh * W + wc) * 64 + 2 * cl);
+        rc[i] = Act<T>::ldraw2(yin_img + (uint32_t)((hh * W + wc) * 64 + 2 * cl));
     }
 }
 
@@ -516,7 +516,7 @@ __device__ __forceinline__ void dwb_row(const typename Act<T>::raw2 (&yc)[4], T 
             }
             const float2 go = Act<T>::round2(make_float2(z0 > 0.f ? d0 : 0.f, z1 > 0.f ? d1 : 0.f));
             const float g0 = go.x, g1 = go.y;
-            Act<T>::st2(gin_img + ((size_t)h * W + w0 + i) * 64 + 2 * cl, go);
+            Act<T>::st2(gin_img + (uint32_t)((h * W + w0 + i) * 64 + 2 * cl), go);
             s1a += g0; s1b += g1;
             s2a = fmaf(g0, yv.x, s2a);      // sum g*y; turned into sum g*yhat once, after the loop (4 VGPRs less in it:
             s2b = fmaf(g1, yv.y, s2b);      // with them the bf16 kernel spilled, and a kernel with scratch pays ~6 us on
@@ -814,6 +814,7 @@ extern "C" int ww_dwconv3x3_bwd(ww_ctx *ctx, int act_dtype, const void *g, const
                    dgamma_in && dbeta_in && scratch,
                WW_E_INVALID, "ww_dwconv3x3_bwd: null argument");
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_dwconv3x3_bwd: bad shape (%d,%d,%d)", B, H, W);
+    WW_REQUIRE((long)H * W * 64 < (1L << 31), WW_E_UNSUPPORTED, "ww_dwconv3x3_bwd: one image of %d x %d x 64 exceeds 2^31 elements", H, W);
     int rc = check_act_b("ww_dwconv3x3_bwd", act_dtype);
     if (rc) return rc;
     DwGeom gm;

@@ -115,7 +115,7 @@ __device__ __forceinline__ void dw_issue_row(const T *__restrict__ img, int h, i
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int wc = min(max(w0 - 1 + i, 0), W - 1);
-        raw[i] = Act<T>::ldraw2(img + ((size_t)hh * W + wc) * 64 + 2 * cl);
+        raw[i] = Act<T>::ldraw2(img + (uint32_t)((hh * W + wc) * 64 + 2 * cl));   // one image < 2^32 elements: 32-bit offsets
     }
 }
 // BatchNorm+ReLU of a raw row; positions outside the image are the conv's zero padding (in activation space)
@@ -152,7 +152,7 @@ __device__ __forceinline__ void dw_out_row(T *__restrict__ oimg, int h, int w0, 
         }
         if (w0 + i < W) {
             const float2 o = Act<T>::round2(make_float2(a0, a1));
-            Act<T>::st2(oimg + ((size_t)h * W + w0 + i) * 64 + 2 * cl, o);
+            Act<T>::st2(oimg + (uint32_t)((h * W + w0 + i) * 64 + 2 * cl), o);
             s0 += o.x; s1 += o.y;
             q0 = fmaf(o.x, o.x, q0); q1 = fmaf(o.y, o.y, q1);
         }
@@ -598,6 +598,7 @@ extern "C" int ww_dwconv3x3_fwd(ww_ctx *ctx, int act_dtype, const void *y_in, co
                                 void *scratch, ww_stream_t stream) {
     WW_REQUIRE(ctx && y_in && ss_in && w && y, WW_E_INVALID, "ww_dwconv3x3_fwd: null argument");
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_dwconv3x3_fwd: bad shape (%d,%d,%d)", B, H, W);
+    WW_REQUIRE((long)H * W * 64 < (1L << 31), WW_E_UNSUPPORTED, "ww_dwconv3x3_fwd: one image of %d x %d x 64 exceeds 2^31 elements", H, W);
     int rc = check_bn("ww_dwconv3x3_fwd", bn, ss_out, mr_out, scratch);
     if (rc || (rc = check_act("ww_dwconv3x3_fwd", act_dtype))) return rc;
     DwGeom g;
