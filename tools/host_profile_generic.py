@@ -23,19 +23,20 @@ model = create_model(arch, dropout=0.3)
 with contextlib.redirect_stdout(sys.stderr):
     tr = Trainer(model, [], [], cfg, checkpoint_dir=Path(tempfile.mkdtemp()), device=dev)
 tr.model.train()
+step = tr._step_autograd_async if tr._async_autograd else tr._step_generic
 pool = [make_synthetic_batch(B, 24000, seed=i, device=dev) for i in range(2)]
 for i in range(3):
-    tr._step_generic(*pool[i % 2], i)
+    step(*pool[i % 2], i)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(10):
-    tr._step_generic(*pool[i % 2], i)
+    step(*pool[i % 2], i)
 torch.cuda.synchronize()
 print(f"{arch} B={B}: {1e3 * (time.perf_counter() - t0) / 10:.3f} ms/step")
 pr = cProfile.Profile()
 pr.enable()
 for i in range(10):
-    tr._step_generic(*pool[i % 2], i)
+    step(*pool[i % 2], i)
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(40)
