@@ -140,7 +140,8 @@ def test_state_dict_is_torch_compatible(kind):
 
 
 def test_large_bucket_path_and_argument_checks():
-    """n > 32768 takes the two-launch path (k_grad_norm_clip + grid-wide update): same numbers as torch."""
+    """n > 32768 takes the two-launch path (block partial sums of squares + a grid-wide clip/update that reduces them in
+    every block): same numbers as torch; a non-finite gradient skips the update and leaves the step count alone."""
     from wakeword_trainer_home_amd import _native as nat
     n = (1 << 17) + 12345
     g = torch.Generator().manual_seed(4)
@@ -160,6 +161,22 @@ def test_large_bucket_path_and_argument_checks():
         assert abs(norm.item() - tn.item()) <= 1e-5 * tn.item()
         assert (p.cpu() - q.detach()).abs().max().item() <= 2e-6
     assert state[1].item() == 3
+    bad = torch.randn(n, generator=g)
+    bad[n // 2] = float("inf")
+    before = p.clone()
+    stats = torch.zeros(nat.STEP_STATS_BYTES, dtype=torch.uint8, device=DEV)
+    nat.clip_optim_step_(cfg, p, bad.to(DEV), m, v, state, 1, norm_out=norm, stats=stats)
+    assert torch.equal(p, before) and state[0].item() == 3
+    assert stats.view(torch.float32)[nat.FOUND_INF_FLOAT_INDEX].item() == 1.0
+    # the stand-alone clip entry point on a large bucket (block partials + grid-wide apply)
+    gl = torch.randn(n, generator=g) * 3
+    gd = gl.to(DEV)
+    qq = torch.nn.Parameter(torch.zeros(n))
+    qq.grad = gl.clone()
+    tn = torch.nn.utils.clip_grad_norm_([qq], 2.0)
+    got = nat.grad_norm_clip_(gd, 2.0)
+    assert abs(float(got) - tn.item()) <= 1e-5 * tn.item()
+    assert (gd.cpu() - qq.grad).abs().max().item() <= 1e-6
     with pytest.raises(ValueError, match="Learning rate must be positive"):
         nat.clip_optim_step_(nat.OptimCfg(nat.OPT_ADAMW, 0.0, 0.9, 0.999, 1e-8, 0.0, 0.0, 0.0), p, p.clone(), m, v, state, 0)
     with pytest.raises(ValueError, match="Betas must be in"):

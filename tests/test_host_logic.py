@@ -309,3 +309,41 @@ def test_library_exports_the_whole_c_abi():
                                                                                   np.array([5, 6], np.uint64))]
     for p in (0.0, 0.3, 0.5, 1.0):
         assert _native.prob_threshold(float(np.float32(p))) == prob_threshold(p)
+
+
+def test_flat_buckets_mixin_on_cpu():
+    """models/flat_buckets.py (device-agnostic host logic): parameters become views of one flat tensor in parameters()
+    order, state_dict round-trips through the views, gather_grads fills missing gradients with zeros, _apply rebuilds."""
+    import torch.nn as nn
+    from wakeword_trainer_home_amd.models.flat_buckets import FlatBuckets
+
+    class Net(FlatBuckets, nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = nn.Linear(3, 4), nn.Linear(4, 2)
+
+    torch.manual_seed(0)
+    net = Net()
+    ref = {k: v.clone() for k, v in net.state_dict().items()}
+    flat = net.flat_param
+    assert flat.numel() == sum(p.numel() for p in net.parameters()) == 3 * 4 + 4 + 4 * 2 + 2
+    off = 0
+    for p in net.parameters():                                     # views, in order, values preserved
+        assert p.data_ptr() == flat.data_ptr() + 4 * off
+        off += p.numel()
+    assert all(torch.equal(v, ref[k]) for k, v in net.state_dict().items())
+    flat.mul_(2.0)                                                 # an update of the bucket is an update of the model
+    assert torch.equal(net.a.weight, 2 * ref["a.weight"])
+    net.load_state_dict(ref)                                       # ... and load_state_dict writes through the views
+    assert torch.equal(flat[:12].view(4, 3), ref["a.weight"]) and net.flat_param.data_ptr() == flat.data_ptr()
+    out = net.b(torch.relu(net.a(torch.ones(5, 3)))).sum()
+    out.backward()
+    net.b.bias.grad = None                                         # a parameter without gradient -> zeros in its slot
+    net.flat_grad.fill_(7.0)
+    g = net.gather_grads()
+    assert torch.equal(g[:12].view(4, 3), net.a.weight.grad) and torch.equal(g[-2:], torch.zeros(2))
+    assert not net.grads_in_bucket()
+    net.to("cpu", torch.float32)                                   # _apply -> rebuilt lazily
+    assert net._fb_param is None and net.flat_param.numel() == flat.numel()
+    with pytest.raises(ValueError, match="float32"):
+        Net().double().flat_param

@@ -131,3 +131,41 @@ def test_reference_architecture_smoke_shapes():
         assert out.shape == (4, 2) and torch.isfinite(out).all(), arch
         out.sum().backward()
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters()), arch
+
+
+def test_trainer_step_uses_flat_buckets_and_fused_optimizer(tmp_path):
+    """MobileNetV3 through the Trainer: parameters live in one flat bucket (state_dict keys unchanged), the optimizer is the
+    fused clip+update kernel, and one training step equals clip_grad_norm_ + torch.optim.AdamW applied to a copy of the
+    model fed the same gradients."""
+    from wakeword_trainer_home_amd.config import get_preset
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    from wakeword_trainer_home_amd.training.optimizer_factory import FlatFusedOptimizer
+    cfg = get_preset("cnn_small_logmel40")
+    cfg.training.batch_size, cfg.optimizer.warmup_epochs = 4, 0
+    torch.manual_seed(3)
+    model = create_model("mobilenetv3", dropout=0.0)
+    keys = list(model.state_dict().keys())
+    tr = Trainer(model, [], [], cfg, checkpoint_dir=tmp_path, device=DEV)
+    assert isinstance(tr.optimizer, FlatFusedOptimizer) and tr._async_autograd
+    assert list(model.state_dict().keys()) == keys and len(keys) == 244
+    assert model.flat_param.numel() == sum(p.numel() for p in model.parameters()) == 1519618
+    before = [p.detach().clone() for p in model.parameters()]
+    x = torch.randn(4, 1, 40, 151, generator=torch.Generator().manual_seed(1)).to(DEV)
+    y = torch.tensor([0, 1, 1, 0])
+    model.train()
+    tr._step_autograd_async(x, y, 0)
+    done = tr._flush_pending()
+    assert len(done) == 1 and np.isfinite(done[0][1])
+    grads = [p.grad.detach().clone() for p in model.parameters()]     # autograd's (unclipped) gradients of that step
+    ref = [torch.nn.Parameter(b.clone()) for b in before]
+    for r, g in zip(ref, grads):
+        r.grad = g.clone()
+    o = cfg.optimizer
+    topt = torch.optim.AdamW(ref, lr=tr.optimizer.param_groups[0]["lr"], betas=tr.optimizer.param_groups[0]["betas"],
+                             weight_decay=tr.optimizer.param_groups[0]["weight_decay"])
+    tn = torch.nn.utils.clip_grad_norm_(ref, float(tr.gradient_clip))
+    topt.step()
+    assert abs(tr.last_grad_norm - tn.item()) <= 1e-4 * tn.item()
+    for p, r in zip(model.parameters(), ref):
+        assert (p.detach() - r.detach()).abs().max().item() <= 5e-6

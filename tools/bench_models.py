@@ -40,7 +40,7 @@ for arch, B, act in CONFIGS:
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
-    n = 8
+    n = 30 if B <= 1024 else 12
     t0 = time.perf_counter()
     for i in range(n):
         step(3 + i)

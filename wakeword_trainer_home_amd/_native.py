@@ -165,10 +165,13 @@ def _check(rc, what):
 
 def ctx(device) -> int:
     """Per-device ww_ctx handle (created on first use)."""
-    lib = load()
-    idx = torch.device(device).index
+    idx = device.index if isinstance(device, torch.device) else torch.device(device).index
     if idx is None:
         idx = torch.cuda.current_device()
+    h = _ctx.get(idx)
+    if h is not None:
+        return h
+    lib = load()
     if idx not in _ctx:
         h = _vp()
         with torch.cuda.device(idx):
@@ -230,7 +233,30 @@ def act_torch_dtype(code):
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    """Raw handle of torch's current stream on `dev` (the C-ABI launches on it).  torch.cuda.current_stream(dev).cuda_stream
+    builds a Stream object per call (4 us); the raw getter is the same value."""
+    idx = dev.index if isinstance(dev, torch.device) else torch.device(dev).index
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice() if idx is None else idx)
+
+
+class _NullGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL_GUARD = _NullGuard()
+
+
+def _guard(dev):
+    """Device guard around a C-ABI call: a no-op when `dev` is already the current device (one process per GPU: always),
+    torch.cuda.device(dev) otherwise."""
+    idx = dev.index if isinstance(dev, torch.device) else torch.device(dev).index
+    if idx is None or idx == torch._C._cuda_getDevice():
+        return _NULL_GUARD
+    return torch.cuda.device(dev)
 
 
 def num_frames(n, hop):
@@ -278,7 +304,7 @@ def logmel_fwd(wave, cfg: FeatCfg, specaug: SpecAugCfg = None, seed=0, step=0, s
     idx = None
     if want_idx and specaug is not None:
         idx = torch.zeros((B, specaug.n_freq_masks + specaug.n_time_masks, 2), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_logmel_fwd(ctx(dev), _p(wave), dt, B, N, C.byref(cfg), _p(out),
                                     C.byref(specaug) if specaug is not None else None, seed, step, sample_offset,
                                     _p(idx), _stream(dev)), "ww_logmel_fwd")
@@ -294,7 +320,7 @@ def specaug_apply_(x, specaug: SpecAugCfg, seed=0, step=0, sample_offset=0, want
     idx = None
     if want_idx:
         idx = torch.zeros((B, specaug.n_freq_masks + specaug.n_time_masks, 2), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_specaug_apply(ctx(dev), _p(x), B, F, T, C.byref(specaug), seed, step, sample_offset, _p(idx),
                                        _stream(dev)), "ww_specaug_apply")
     return idx
@@ -308,7 +334,7 @@ def audio_rir_spectra(rirs):
     R, L = rirs.shape
     nbytes = load().ww_audio_rir_spectra_bytes(R)
     spectra = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_audio_rir_spectra(ctx(dev), _p(rirs), R, L, _p(spectra), nbytes, _stream(dev)),
                "ww_audio_rir_spectra")
     return spectra
@@ -332,7 +358,7 @@ def audio_augment(wave, rirs, noises, rir_prob, noise_prob, snr_min_db, snr_max_
     scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     choices = torch.empty((B, 4), dtype=torch.int32, device=dev) if want_choices else None
     cfg = AudioAugCfg(rir_prob, noise_prob, snr_min_db, snr_max_db)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_audio_augment(ctx(dev), _p(wave), _p(out), B, N, _p(rirs), R, L, _p(rir_spectra), _p(noises), K, Nn, C.byref(cfg),
                                        seed, step, sample_offset, _p(choices), _p(scratch), nbytes, _stream(dev)),
                "ww_audio_augment")
@@ -356,7 +382,7 @@ def linear_mfma_fwd(x, w, bias=None, act=LIN_NONE, dropout_p=0.0, seed=0, step=0
     y = torch.empty((M, N), dtype=torch.float32, device=dev)
     pre = torch.empty((M, N), dtype=torch.float32, device=dev) if want_pre else None
     epi = LinearEpi(act, dropout_p, seed, step, sample_offset)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_linear_mfma_fwd(ctx(dev), act_code(mode), _p(x.contiguous()), _p(w.contiguous()), _p(bias), M, K, N,
                                          C.byref(epi), _p(pre), _p(y), _stream(dev)), "ww_linear_mfma_fwd")
     return (y, pre) if want_pre else y
@@ -377,7 +403,7 @@ def linear_mfma_bwd(x, w, pre, dy, act=LIN_NONE, dropout_p=0.0, seed=0, step=0, 
     nbytes = load().ww_linear_mfma_bwd_scratch_bytes(M, K, N)
     scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     epi = LinearEpi(act, dropout_p, seed, step, sample_offset)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_linear_mfma_bwd(ctx(dev), act_code(mode), _p(x.contiguous()), _p(w.contiguous()), _p(pre),
                                          _p(dy.contiguous()), M, K, N, C.byref(epi), _p(dx), _p(dw), _p(db), _p(scratch), nbytes,
                                          _stream(dev)), "ww_linear_mfma_bwd")
@@ -398,7 +424,7 @@ def dropout_bt(x, p, seed=0, step=0, sample_offset=0, stream_id=0, out=None):
     B, T, Cc = x.shape
     if out is None:
         out = torch.empty((B, T, Cc), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_dropout_bt(ctx(dev), _p(x), ldx, B, T, Cc, p, seed, step, sample_offset, stream_id, _p(out),
                                     _bt_rows(out, "out"), _stream(dev)), "ww_dropout_bt")
     return out
@@ -424,7 +450,7 @@ def bn_act_fwd(x, bn: BN, act, Cn):
     y = torch.empty_like(x)
     ss = torch.empty(2 * Cn, dtype=torch.float32, device=dev)
     mr = torch.empty(2 * Cn, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_bn_act_fwd(ctx(dev), _p(x), M, Cn, C.byref(bn), act, _p(y), _p(ss), _p(mr), _p(nhwc_scratch(Cn, dev)),
                                     _stream(dev)), "ww_bn_act_fwd")
     return y, ss, mr
@@ -436,7 +462,7 @@ def bn_act_bwd(x, da, ss, mr, act, training, Cn):
     dx = torch.empty_like(x)
     dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
     dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_bn_act_bwd(ctx(dev), _p(x), _p(da), M, Cn, _p(ss), _p(mr), act, int(training), _p(dx), _p(dgamma),
                                     _p(dbeta), _p(nhwc_scratch(Cn, dev)), _stream(dev)), "ww_bn_act_bwd")
     return dx, dgamma, dbeta
@@ -447,7 +473,7 @@ def dwconv_nhwc_fwd(x, w, k, stride):
     B, H, W, Cn = x.shape
     Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
     y = torch.empty((B, Ho, Wo, Cn), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_dwconv_nhwc_fwd(ctx(dev), _p(x), _p(w), B, H, W, Cn, k, stride, _p(y), _stream(dev)), "ww_dwconv_nhwc_fwd")
     return y
 
@@ -457,7 +483,7 @@ def dwconv_nhwc_bwd(x, w, dy, k, stride, need_dx=True):
     B, H, W, Cn = x.shape
     dx = torch.empty_like(x) if need_dx else None
     dw = torch.empty_like(w)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_dwconv_nhwc_bwd(ctx(dev), _p(x), _p(w), _p(dy), B, H, W, Cn, k, stride, _p(dx), _p(dw),
                                          _p(nhwc_scratch(Cn, dev)), _stream(dev)), "ww_dwconv_nhwc_bwd")
     return dx, dw
@@ -467,7 +493,7 @@ def pool_hw_fwd(x):
     dev = _dev(x)
     B, HW, Cn = x.shape
     s = torch.empty((B, Cn), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_pool_hw_fwd(ctx(dev), _p(x), B, HW, Cn, _p(s), _stream(dev)), "ww_pool_hw_fwd")
     return s
 
@@ -476,7 +502,7 @@ def scale_bc_fwd(x, gate):
     dev = _dev(x, gate)
     B, HW, Cn = x.shape
     y = torch.empty_like(x)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_scale_bc_fwd(ctx(dev), _p(x), _p(gate), B, HW, Cn, _p(y), _stream(dev)), "ww_scale_bc_fwd")
     return y
 
@@ -485,7 +511,7 @@ def scale_bc_bwd_gate(x, dy):
     dev = _dev(x, dy)
     B, HW, Cn = x.shape
     dg = torch.empty((B, Cn), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_scale_bc_bwd_gate(ctx(dev), _p(x), _p(dy), B, HW, Cn, _p(dg), _stream(dev)), "ww_scale_bc_bwd_gate")
     return dg
 
@@ -495,7 +521,7 @@ def scale_pool_bwd(dy, gate, dpool, shape):
     dev = _dev(dy, gate, dpool)
     B, HW, Cn = shape
     dx = torch.empty(shape, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_scale_pool_bwd(ctx(dev), _p(dy), _p(gate), _p(dpool), B, HW, Cn, _p(dx), _stream(dev)),
                "ww_scale_pool_bwd")
     return dx
@@ -506,7 +532,7 @@ def im2col3x3s2(x):
     dev = _dev(x)
     B, H, W = x.shape
     cols = torch.empty((B * ((H + 1) // 2) * ((W + 1) // 2), 9), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_im2col3x3s2(ctx(dev), _p(x), B, H, W, _p(cols), _stream(dev)), "ww_im2col3x3s2")
     return cols
 
@@ -514,7 +540,7 @@ def im2col3x3s2(x):
 def add_f32(a, b):
     dev = _dev(a, b)
     y = torch.empty_like(a)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_add_f32(ctx(dev), _p(a), _p(b), a.numel(), _p(y), _stream(dev)), "ww_add_f32")
     return y
 
@@ -536,7 +562,7 @@ def gru_fwd(x, w_ih, w_hh, b_ih, b_hh, y, ws, h0=None, reverse=False, mode=torch
     if tuple(w_ih.shape) != (3 * H, I) or tuple(w_hh.shape) != (3 * H, H) or tuple(y.shape) != (B, T, H):
         raise ValueError("GRU parameter / output shapes do not match (w_ih (3H,I), w_hh (3H,H), y (B,T,H))")
     h_n = torch.empty((B, H), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_gru_fwd(ctx(dev), act_code(mode), _p(x), ldx, _p(w_ih.contiguous()), _p(w_hh.contiguous()), _p(b_ih), _p(b_hh), _p(h0),
                                  B, T, I, H, int(reverse), _p(y), ldy, _p(h_n), _p(ws), ws.numel() * 4, _stream(dev)),
                "ww_gru_fwd")
@@ -556,7 +582,7 @@ def gru_bwd(x, w_ih, w_hh, dy, dh_n, ws, reverse=False, dx=None, accumulate_dx=F
     db_ih = torch.empty(3 * H, dtype=torch.float32, device=dev)
     db_hh = torch.empty(3 * H, dtype=torch.float32, device=dev)
     dh0 = torch.empty((B, H), dtype=torch.float32, device=dev) if want_dh0 else None
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_gru_bwd(ctx(dev), act_code(mode), _p(x), ldx, _p(w_ih.contiguous()), _p(w_hh.contiguous()), _p(dy), ldy, _p(dh_n),
                                  B, T, I, H, int(reverse), _p(ws), ws.numel() * 4, _p(dx), lddx, int(accumulate_dx),
                                  _p(dw_ih), _p(dw_hh), _p(db_ih), _p(db_hh), _p(dh0), _stream(dev)), "ww_gru_bwd")
@@ -574,7 +600,7 @@ def clip_optim_step_(cfg: OptimCfg, flat_params, flat_grads, exp_avg, exp_avg_sq
         raise ValueError("parameter and gradient buckets must be float32 and of equal length")
     if step_state.dtype != torch.int64 or step_state.numel() != 2:
         raise ValueError("step_state must be an int64 tensor of two elements")
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_clip_optim_step(ctx(dev), C.byref(cfg), _p(flat_params), _p(flat_grads), _p(exp_avg), _p(exp_avg_sq),
                                          flat_params.numel(), _p(step_state), parity, _p(norm_out), _p(stats),
                                          None if stats_host is None else C.c_void_p(stats_host.data_ptr()), _stream(dev)),
@@ -596,7 +622,7 @@ def conv_stem_fwd(x, w, bn: BN, scratch, act=torch.float32):
     y = torch.empty((B, Ho, Wo, 64), dtype=act, device=dev)
     ss = torch.empty(128, dtype=torch.float32, device=dev)
     mr = torch.empty(128, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_conv_stem_fwd(ctx(dev), act_code(act), _p(x), _p(w), B, Hin, Win, _p(y), C.byref(bn), _p(ss), _p(mr),
                                        _p(scratch), _stream(dev)), "ww_conv_stem_fwd")
     return y, ss, mr
@@ -610,7 +636,7 @@ def _conv_fwd(name, y_in, ss_in, w, bn, scratch):
     y = torch.empty_like(y_in)
     ss = torch.empty(128, dtype=torch.float32, device=dev)
     mr = torch.empty(128, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(getattr(load(), name)(ctx(dev), act_code(y_in.dtype), _p(y_in), _p(ss_in), _p(w), B, H, W, _p(y), C.byref(bn), _p(ss), _p(mr),
                                      _p(scratch), _stream(dev)), name)
     return y, ss, mr
@@ -628,7 +654,7 @@ def gap_fwd(y, ss, mr):
     dev = _dev(y, ss, mr)
     B, H, W, _ = y.shape
     pool = torch.empty((B, 3, 64), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_gap_fwd(ctx(dev), act_code(y.dtype), _p(y), _p(ss), _p(mr), B, H, W, _p(pool), _stream(dev)),
                "ww_gap_fwd")
     return pool
@@ -639,7 +665,7 @@ def head_fwd(pool, HW, fc_w, fc_b, dropout_p=0.0, training=True, seed=0, step=0,
     B = pool.shape[0]
     pd = torch.empty((B, 64), dtype=torch.float32, device=dev)
     logits = torch.empty((B, 2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_head_fwd(ctx(dev), _p(pool), B, HW, _p(fc_w), _p(fc_b), dropout_p, int(training), seed, step,
                                   sample_offset, _p(pd), _p(logits), _stream(dev)), "ww_head_fwd")
     return pd, logits
@@ -653,7 +679,7 @@ def head_bwd(dlogits, pd, pool, HW, fc_w, gamma_last, mr_last, dropout_p=0.0, tr
     dfc_w, dfc_b = torch.empty((2, 64), **f32), torch.empty(2, **f32)
     dpool, coef = torch.empty((B, 64), **f32), torch.empty(192, **f32)
     dgamma, dbeta = torch.empty(64, **f32), torch.empty(64, **f32)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_head_bwd(ctx(dev), _p(dlogits), _p(pd), _p(pool), B, HW, _p(fc_w), dropout_p, int(training),
                                   seed, step, sample_offset, _p(gamma_last), _p(mr_last), _p(dfc_w), _p(dfc_b),
                                   _p(dpool), _p(coef), _p(dgamma), _p(dbeta), _stream(dev)), "ww_head_bwd")
@@ -666,7 +692,7 @@ def pwconv1x1_bwd(g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, gamma_in, w
     f32 = dict(dtype=torch.float32, device=dev)
     g_in, dw = torch.empty_like(y_in), torch.empty((64, 64), **f32)
     coef_in, dgamma, dbeta = torch.empty(192, **f32), torch.empty(64, **f32), torch.empty(64, **f32)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_pwconv1x1_bwd(ctx(dev), act_code(y_out.dtype), _p(g), _p(dpool), _p(y_out), _p(ss_out), _p(coef), _p(y_in), _p(ss_in),
                                        _p(mr_in), _p(gamma_in), _p(w), B, H, W, _p(g_in), _p(dw), _p(coef_in),
                                        _p(dgamma), _p(dbeta), _p(scratch), _stream(dev)), "ww_pwconv1x1_bwd")
@@ -679,7 +705,7 @@ def dwconv3x3_bwd(g, y_out, coef, y_in, ss_in, mr_in, gamma_in, w, scratch):
     f32 = dict(dtype=torch.float32, device=dev)
     g_in, dw = torch.empty_like(y_in), torch.empty((64, 1, 3, 3), **f32)
     coef_in, dgamma, dbeta = torch.empty(192, **f32), torch.empty(64, **f32), torch.empty(64, **f32)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_dwconv3x3_bwd(ctx(dev), act_code(y_out.dtype), _p(g), _p(y_out), _p(coef), _p(y_in), _p(ss_in), _p(mr_in),
                                        _p(gamma_in), _p(w), B, H, W, _p(g_in), _p(dw), _p(coef_in), _p(dgamma),
                                        _p(dbeta), _p(scratch), _stream(dev)), "ww_dwconv3x3_bwd")
@@ -690,7 +716,7 @@ def conv_stem_bwd(g, y_out, coef, x, scratch):
     dev = _dev(g, y_out, coef, x, scratch)
     B, Hin, Win = x.shape[0], x.shape[-2], x.shape[-1]
     dw = torch.empty((64, 1, 3, 3), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_conv_stem_bwd(ctx(dev), act_code(y_out.dtype), _p(g), _p(y_out), _p(coef), _p(x), B, Hin, Win, _p(dw), _p(scratch),
                                        _stream(dev)), "ww_conv_stem_bwd")
     return dw
@@ -711,7 +737,7 @@ def cnn_small_fwd(params, x, ws, logits, training, bn_momentum=0.1, bn_eps=1e-5,
                   sample_offset=0, act=ACT_F32):
     dev = _dev(x, ws, logits)
     B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_cnn_small_fwd(ctx(dev), act, params, _p(x), B, F, T, int(training), bn_momentum, bn_eps, dropout_p,
                                        seed, step, sample_offset, _p(ws), ws.numel() * ws.element_size(), _p(logits),
                                        _stream(dev)), "ww_cnn_small_fwd")
@@ -720,7 +746,7 @@ def cnn_small_fwd(params, x, ws, logits, training, bn_momentum=0.1, bn_eps=1e-5,
 def cnn_small_bwd(params, grads, x, dlogits, ws, dropout_p=0.0, seed=0, step=0, sample_offset=0, act=ACT_F32):
     dev = _dev(x, ws, dlogits)
     B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_cnn_small_bwd(ctx(dev), act, params, grads, _p(x), _p(dlogits), B, F, T, dropout_p, seed, step,
                                        sample_offset, _p(ws), ws.numel() * ws.element_size(), _stream(dev)),
                "ww_cnn_small_bwd")
@@ -729,7 +755,7 @@ def cnn_small_bwd(params, grads, x, dlogits, ws, dropout_p=0.0, seed=0, step=0, 
 def cnn_front_fwd(params, x, ws, seq, training, bn_momentum=0.1, bn_eps=1e-5, act=ACT_F32):
     dev = _dev(x, ws, seq)
     B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_cnn_front_fwd(ctx(dev), act, params, _p(x), B, F, T, int(training), bn_momentum, bn_eps, _p(ws),
                                        ws.numel() * ws.element_size(), _p(seq), _stream(dev)), "ww_cnn_front_fwd")
 
@@ -737,7 +763,7 @@ def cnn_front_fwd(params, x, ws, seq, training, bn_momentum=0.1, bn_eps=1e-5, ac
 def cnn_front_bwd(params, grads, x, dseq, ws, act=ACT_F32):
     dev = _dev(x, ws, dseq)
     B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_cnn_front_bwd(ctx(dev), act, params, grads, _p(x), _p(dseq), B, F, T, _p(ws),
                                        ws.numel() * ws.element_size(), _stream(dev)), "ww_cnn_front_bwd")
 
@@ -755,7 +781,7 @@ def ce2_loss_fwd_bwd(logits, targets, kind=LOSS_CE, label_smoothing=0.0, focal_a
     dl = torch.empty_like(logits)
     if stats is None:
         stats = torch.zeros(STEP_STATS_BYTES, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_ce2_loss_fwd_bwd(ctx(dev), _p(logits), _p(targets), B, kind, label_smoothing, focal_alpha,
                                           focal_gamma, _p(loss), _p(dl), _p(stats), _stream(dev)),
                "ww_ce2_loss_fwd_bwd")
@@ -768,7 +794,7 @@ def grad_norm_clip_(flat, max_norm, norm_out=None, stats=None):
     dev = _dev(flat, norm_out, stats)
     if norm_out is None and stats is None:
         norm_out = torch.empty(1, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _check(load().ww_grad_norm_clip(ctx(dev), _p(flat), flat.numel(), float(max_norm), _p(norm_out), _p(stats),
                                         _stream(dev)), "ww_grad_norm_clip")
     return norm_out

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "ww_internal.h"
+#include <algorithm>
 
 static thread_local char g_err[512] = "";
 
@@ -49,6 +50,7 @@ extern "C" int ww_ctx_create(int device, ww_ctx **out) {
     c->tables = nullptr;
     c->prof_mask = 0;
     c->tw16k = nullptr;
+    c->norm_partials = nullptr;
     c->prof_recs = new std::vector<ww_prof_rec>();
     c->prof_free = new std::vector<ww_prof_rec>();
     *out = c;
@@ -74,6 +76,7 @@ extern "C" int ww_ctx_destroy(ww_ctx *ctx) {
     if (!ctx) return WW_OK;
     free_tables(ctx->tables);
     if (ctx->tw16k) (void)hipFree(ctx->tw16k);
+    if (ctx->norm_partials) (void)hipFree(ctx->norm_partials);
     for (auto *v : {ctx->prof_recs, ctx->prof_free}) {
         for (auto &r : *v) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         delete v;
@@ -375,8 +378,8 @@ int ww_launch_colsum(const float *partials, int rows, int cols, float *out, hipS
 }
 
 // ------------------------------------------------------------------------------------------
-// clip_grad_norm_ on one flat bucket (single block: n is ~2e4 for cnn_small, ~1.5e6 for
-// MobileNetV3-small; deterministic fixed-order reduction)
+// clip_grad_norm_ on one flat bucket: a single block up to 65536 gradients (cnn_small: ~2.5e4), block partials + a
+// grid-wide apply above that; deterministic fixed-order reductions
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_grad_norm_clip(float *__restrict__ g, size_t n, float max_norm,
                                                          float *__restrict__ norm_out,
@@ -414,12 +417,70 @@ __global__ __launch_bounds__(1024) void k_grad_norm_clip(float *__restrict__ g, 
         for (size_t i = threadIdx.x; i < n; i += 1024) g[i] *= c;
 }
 
+// ---- large buckets (MobileNetV3-small: 1.5e6 gradients): block partial sums in a fixed partition, then every block of
+// the consumer reduces the <= 256 partials in the same order (deterministic, no atomics)
+__global__ __launch_bounds__(1024) void k_sumsq_partials(const float *__restrict__ g, size_t n, double *__restrict__ parts) {
+    __shared__ double sh[1024];
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    double acc = 0.0;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        const double v = g[i];
+        acc += v * v;
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) parts[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void k_norm_clip_apply(float *__restrict__ g, size_t n, const double *__restrict__ parts,
+                                                         int nparts, float max_norm, float *__restrict__ norm_out,
+                                                         ww_step_stats *__restrict__ stats) {
+    double t = 0.0;
+    for (int i = 0; i < nparts; ++i) t += parts[i];          // same order in every thread
+    const float norm = (float)sqrt(t);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (norm_out) *norm_out = norm;
+        if (stats) {
+            stats->grad_norm = norm;
+            if (!isfinite(norm)) stats->found_inf = 1.0f;
+        }
+    }
+    if (!(max_norm > 0.f)) return;
+    float c = max_norm / (norm + 1e-6f);
+    if (c > 1.0f) c = 1.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] *= c;
+}
+
+int ww_launch_sumsq_partials(ww_ctx *ctx, const float *g, size_t n, int *parts_out, hipStream_t st) {
+    if (!ctx->norm_partials) WW_HIP(hipMalloc((void **)&ctx->norm_partials, WW_NORM_PARTS * sizeof(double)));
+    const int parts = (int)std::min<size_t>(WW_NORM_PARTS, (n + 4095) / 4096);
+    hipLaunchKernelGGL(k_sumsq_partials, dim3(parts), dim3(1024), 0, st, g, n, ctx->norm_partials);
+    WW_LAUNCH_CHECK();
+    *parts_out = parts;
+    return WW_OK;
+}
+
 extern "C" int ww_grad_norm_clip(ww_ctx *ctx, float *flat_grads, size_t n, float max_norm, float *norm_out,
                                  ww_step_stats *stats, ww_stream_t stream) {
     WW_REQUIRE(ctx && flat_grads, WW_E_INVALID, "ww_grad_norm_clip: null argument");
     if (n == 0) return WW_OK;
-    ww_prof_scope ps_(ctx, WW_K_CLIP, (hipStream_t)stream);
-    hipLaunchKernelGGL(k_grad_norm_clip, dim3(1), dim3(1024), 0, (hipStream_t)stream, flat_grads, n, max_norm,
+    hipStream_t st = (hipStream_t)stream;
+    ww_prof_scope ps_(ctx, WW_K_CLIP, st);
+    if (n <= (size_t)1 << 16) {
+        hipLaunchKernelGGL(k_grad_norm_clip, dim3(1), dim3(1024), 0, st, flat_grads, n, max_norm, norm_out, stats);
+        WW_LAUNCH_CHECK();
+        return WW_OK;
+    }
+    int parts = 0;
+    const int rc = ww_launch_sumsq_partials(ctx, flat_grads, n, &parts, st);
+    if (rc) return rc;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(k_norm_clip_apply, dim3(grid), dim3(256), 0, st, flat_grads, n, ctx->norm_partials, parts, max_norm,
                        norm_out, stats);
     WW_LAUNCH_CHECK();
     return WW_OK;

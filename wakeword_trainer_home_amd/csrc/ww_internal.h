@@ -12,6 +12,7 @@
 #define WW_MAX_MASKS 16
 #define WW_FRAMES_PER_BLOCK 16
 #define WW_MAX_HOP 512
+#define WW_NORM_PARTS 256
 
 void ww_set_error(const char *fmt, ...);
 
@@ -68,6 +69,7 @@ struct ww_ctx {
     int device;
     ww_feat_tables *tables;
     float2 *tw16k;                         // (1024) exp(-2 pi i m / 16384), ww_audio.hip's FFT convolution; lazy
+    double *norm_partials;                 // (WW_NORM_PARTS) block sums of squares of a large gradient bucket; lazy
     uint32_t prof_mask;
     std::vector<ww_prof_rec> *prof_recs;   // recorded, not yet collected
     std::vector<ww_prof_rec> *prof_free;   // event pairs ready for reuse
@@ -115,6 +117,8 @@ int ww_colsum_rows(const float *a, long rows, int cols, float *out, float *part,
 int ww_colsum_pair(const float *a, int rows, int cols, float *out0, float *out1, hipStream_t st);
 int ww_colsum_rows_small(const float *a, int rows, int cols, float *out, hipStream_t st);
 int ww_occupancy_grid(const void *fn, int block, size_t smem, long want, int cap);
+// ww_ctx.hip: block sums of squares of g[0..n) into ctx->norm_partials (fixed partition -> deterministic); returns the count
+int ww_launch_sumsq_partials(ww_ctx *ctx, const float *g, size_t n, int *parts_out, hipStream_t st);
 
 // ---- Philox4x32-10 (host + device), must match oracle/philox.py bit for bit
 #define WW_TAG_SPECAUG 0u

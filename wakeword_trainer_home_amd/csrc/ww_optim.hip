@@ -117,24 +117,47 @@ __global__ __launch_bounds__(1024) void k_clip_optim_small(OptimArgs a, float *_
     }
 }
 
-// grid-wide update for large buckets (the gradient was clipped by k_grad_norm_clip, which also set found_inf)
-__global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__restrict__ p, const float *__restrict__ g,
+// grid-wide clip + update for large buckets: every block reduces the block partials of the squared norm (k_sumsq_partials)
+// in the same order, so all agree on the norm, the clip coefficient and the skip decision without another launch
+__global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__restrict__ p, float *__restrict__ g,
                                                       float *__restrict__ m, float *__restrict__ v, size_t n,
                                                       long long *__restrict__ step_state, int parity,
-                                                      const ww_step_stats *__restrict__ stats,
+                                                      const double *__restrict__ parts, int nparts,
+                                                      float *__restrict__ norm_out, ww_step_stats *__restrict__ stats,
                                                       ww_step_stats *__restrict__ stats_host) {
-    const bool skip = stats && stats->found_inf != 0.0f;
+    double t = 0.0;
+    for (int i = 0; i < nparts; ++i) t += parts[i];
+    const float norm = (float)sqrt(t);
+    const bool skip = (stats && stats->found_inf != 0.0f) || !isfinite(norm);
     const long long t0 = step_state[parity];
+    const bool clip = a.max_norm > 0.f;
+    float c = 1.f;
+    if (clip) {
+        c = a.max_norm / (norm + 1e-6f);
+        if (c > 1.f) c = 1.f;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         step_state[parity ^ 1] = skip ? t0 : t0 + 1;
-        if (stats && stats_host) *stats_host = *stats;
+        if (norm_out) *norm_out = norm;
+        if (stats) {
+            stats->grad_norm = norm;
+            if (!isfinite(norm)) stats->found_inf = 1.0f;
+            if (stats_host) {
+                ww_step_stats s = *stats;
+                s.grad_norm = norm;
+                if (!isfinite(norm)) s.found_inf = 1.0f;
+                *stats_host = s;
+            }
+        }
     }
-    if (skip) return;
     float step_size, bc2_sqrt;
     bias_terms(a, t0 + 1, step_size, bc2_sqrt);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float gi = g[i];
+        if (clip) { gi *= c; g[i] = gi; }           // clip_grad_norm_ leaves the clipped gradients behind
+        if (skip) continue;
         float pi = p[i], mi = m ? m[i] : 0.f, vi = v ? v[i] : 0.f;
-        optim_update(a, pi, g[i], mi, vi, step_size, bc2_sqrt);
+        optim_update(a, pi, gi, mi, vi, step_size, bc2_sqrt);
         p[i] = pi;
         if (m) m[i] = mi;
         if (v) v[i] = vi;
@@ -177,11 +200,13 @@ extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *f
         WW_LAUNCH_CHECK();
         return WW_OK;
     }
-    int rc = ww_grad_norm_clip(ctx, flat_grads, n, cfg->max_norm, norm_out, stats, stream);
+    ww_prof_scope ps_(ctx, WW_K_CLIP, st);
+    int parts = 0;
+    const int rc = ww_launch_sumsq_partials(ctx, flat_grads, n, &parts, st);
     if (rc) return rc;
     const int grid = (int)std::min<size_t>((n + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(k_optim_update, dim3(grid), dim3(256), 0, st, a, flat_params, flat_grads, exp_avg, exp_avg_sq, n,
-                       (long long *)step_state, parity, stats, stats_host_dev);
+                       (long long *)step_state, parity, ctx->norm_partials, parts, norm_out, stats, stats_host_dev);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

@@ -1,0 +1,82 @@
+"""Flat fp32 parameter / gradient buckets for HIP-backed models whose backward runs through autograd.
+
+``CNNSmallWakeword`` builds its own buckets (its backward writes gradients straight into them).  Models composed of
+autograd nodes (``MobileNetV3Wakeword``) get the same contract from this mixin -- ``flat_param``, ``flat_grad``,
+``grads_in_bucket()`` -- so ``create_optimizer`` hands them the fused clip+optimizer kernel (``FlatFusedOptimizer``) and
+data-parallel training all-reduces ONE tensor instead of one per parameter: at ~140 parameter tensors
+``clip_grad_norm_`` + the torch optimizer cost 1.5 ms of host time per step."""
+import torch
+
+
+class FlatBuckets:
+    """Mixin for an nn.Module (list it BEFORE nn.Module).  Parameters become views of one flat fp32 tensor in
+    ``parameters()`` order, built lazily on first use and rebuilt after ``.to()`` / ``.cuda()`` (``_apply``)."""
+
+    _fb_param = None
+    _fb_grad = None
+    _fb_plist = None
+    _fb_views = None
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._fb_param = self._fb_grad = self._fb_plist = self._fb_views = None
+        return r
+
+    def _fb_build(self):
+        plist = list(self.parameters())
+        if not plist:
+            raise ValueError("FlatBuckets: the module has no parameters")
+        dev = plist[0].device
+        for t in plist:
+            if t.dtype != torch.float32 or t.device != dev:
+                raise ValueError("FlatBuckets: parameters must be float32 on one device")
+        flat = torch.empty(sum(t.numel() for t in plist), dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for t in plist:
+                view = flat[off:off + t.numel()].view_as(t)
+                view.copy_(t.data)
+                t.data = view                       # state_dict() / load_state_dict() go through the views
+                off += t.numel()
+        self._fb_param, self._fb_plist = flat, plist
+        self._fb_grad = torch.zeros_like(flat)
+        views, off = [], 0
+        for t in plist:
+            views.append(self._fb_grad[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        self._fb_views = views
+
+    @property
+    def flat_param(self):
+        if self._fb_param is None:
+            self._fb_build()
+        return self._fb_param
+
+    @property
+    def flat_grad(self):
+        if self._fb_param is None:
+            self._fb_build()
+        return self._fb_grad
+
+    def grads_in_bucket(self) -> bool:
+        """autograd hands every parameter a fresh gradient tensor: they are gathered (``gather_grads``), never in place."""
+        return False
+
+    @torch.no_grad()
+    def gather_grads(self):
+        """Copy every ``.grad`` into its slot of ``flat_grad`` (two multi-tensor launches); a parameter without a
+        gradient contributes zeros, as it would to ``clip_grad_norm_`` and the optimizer."""
+        if self._fb_param is None:
+            self._fb_build()
+        dst, src, missing = [], [], []
+        for p, v in zip(self._fb_plist, self._fb_views):
+            if p.grad is None:
+                missing.append(v)
+            else:
+                dst.append(v)
+                src.append(p.grad)
+        if missing:
+            torch._foreach_zero_(missing)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        return self._fb_grad

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native as nat
+from .flat_buckets import FlatBuckets
 from .heads import MobileNetV3Head
 
 SMALL_CONF = ((16, 3, 16, 16, True, "RE", 2), (16, 3, 72, 24, False, "RE", 2), (24, 3, 88, 24, False, "RE", 1),
@@ -289,7 +290,7 @@ class _MobileNet(nn.Module):
                                           dropout_seed=dropout_seed)
 
 
-class MobileNetV3Wakeword(nn.Module):
+class MobileNetV3Wakeword(FlatBuckets, nn.Module):
     hip_backed = True
 
     def __init__(self, num_classes: int = 2, pretrained: bool = False, dropout: float = 0.3, input_channels: int = 1,

@@ -96,10 +96,10 @@ class FlatFusedOptimizer(optim.Optimizer):
                                   max_norm)
 
     @torch.no_grad()
-    def step(self, closure=None, max_norm: float = 0.0, stats=None, stats_host=None):
+    def step(self, closure=None, max_norm: float = 0.0, stats=None, stats_host=None, gathered: bool = False):
         """``max_norm > 0`` also clips (clip_grad_norm_ semantics, in place on the bucket); ``stats`` is the step's
         device ``ww_step_stats`` (found_inf gate, grad_norm output); ``stats_host`` a pinned 48-byte tensor the kernel
-        copies it to."""
+        copies it to; ``gathered``: ``flat_grad`` already holds this step's (all-reduced) gradients."""
         if closure is not None:
             raise ValueError("FlatFusedOptimizer does not support closures")
         model = self._model
@@ -108,7 +108,12 @@ class FlatFusedOptimizer(optim.Optimizer):
                                         "(model.to(...) / dtype change): create the optimizer afterwards")
         if model.flat_grad is None or all(p.grad is None for p in self.param_groups[0]["params"]):
             return None                                      # nothing to do, like torch's optimizers
-        if not model.grads_in_bucket():                      # gradients were accumulated outside the bucket: gather
+        if gathered:                                         # the caller gathered (and all-reduced) flat_grad already
+            pass
+        elif hasattr(model, "gather_grads"):
+            if not model.grads_in_bucket():
+                model.gather_grads()
+        elif not model.grads_in_bucket():                    # gradients were accumulated outside the bucket: gather
             off = 0
             for p in self.param_groups[0]["params"]:
                 n = p.numel()

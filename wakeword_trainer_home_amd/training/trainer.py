@@ -306,24 +306,37 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.criterion(self.model(inputs), targets)
         loss.backward()
-        self._allreduce_grads()
         stats = self.criterion.last_stats
-        sv = stats.view(torch.float32)
-        if self.gradient_clip > 0:
-            norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), float(self.gradient_clip), foreach=True)
-            sv[1] = norm                                                               # ww_step_stats.grad_norm
-            sv[nat.FOUND_INF_FLOAT_INDEX] = torch.maximum(sv[nat.FOUND_INF_FLOAT_INDEX], (~torch.isfinite(norm)).float())
-        self.optimizer.grad_scale = None
-        self.optimizer.found_inf = sv[nat.FOUND_INF_FLOAT_INDEX]
-        try:
-            self.optimizer.step()
-        finally:
-            del self.optimizer.grad_scale, self.optimizer.found_inf
         if self._host_bufs is None:
             self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
         buf = self._host_bufs[self._buf_i]
         self._buf_i ^= 1
-        buf.copy_(stats, non_blocking=True)
+        if self._fused_optimizer:
+            # flat buckets (models/flat_buckets.py): gather the autograd gradients, ONE all-reduce, then clip + skip +
+            # update + the 48-byte statistics record in one launch -- as the native cnn_small step does
+            flat = self.model.gather_grads()
+            if self._dist:
+                if self._dist.get_backend() == "nccl":
+                    self._dist.all_reduce(flat, op=self._dist.ReduceOp.AVG)
+                else:
+                    self._dist.all_reduce(flat)
+                    flat.div_(self.world_size)
+            self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats, stats_host=buf, gathered=True)
+        else:
+            self._allreduce_grads()
+            sv = stats.view(torch.float32)
+            if self.gradient_clip > 0:
+                norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), float(self.gradient_clip), foreach=True)
+                sv[1] = norm                                                               # ww_step_stats.grad_norm
+                sv[nat.FOUND_INF_FLOAT_INDEX] = torch.maximum(sv[nat.FOUND_INF_FLOAT_INDEX],
+                                                              (~torch.isfinite(norm)).float())
+            self.optimizer.grad_scale = None
+            self.optimizer.found_inf = sv[nat.FOUND_INF_FLOAT_INDEX]
+            try:
+                self.optimizer.step()
+            finally:
+                del self.optimizer.grad_scale, self.optimizer.found_inf
+            buf.copy_(stats, non_blocking=True)
         event = torch.cuda.Event()
         event.record()
         launched = (batch_idx, buf, event)
