@@ -35,6 +35,17 @@ constexpr int HS_LD = GH + 4;    // LDS row strides: lane (row i, k) -> bank 4i 
 constexpr int DG_LD = 3 * GH + 4;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// bf16 matrix mode: v_exp_f32 + v_rcp_f32 forms (1 ulp reciprocal, absolute error ~2e-7 -- far below what the bf16 operands
+// of that mode cost); the IEEE division and libm tanhf of the parity mode are ~50 of the ~80 instructions of a gate cell,
+// and the recurrence is VALU-issue-bound (2 waves per SIMD, no other work to hide behind)
+template <bool FAST> __device__ __forceinline__ float gate_sigmoid(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+    else return sigmoidf_(x);
+}
+template <bool FAST> __device__ __forceinline__ float gate_tanh(float x) {
+    if constexpr (FAST) return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)), 1.0f);
+    else return tanhf(x);
+}
 
 struct GruSaved { float *r, *z, *n, *hn, *hp; };    // (B*T, 128) each: gates, W_hn h + b_hn, h_{t-1}
 
@@ -44,9 +55,14 @@ template <bool BF16>
 __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, const float *__restrict__ w_hh,
                                                  const float *__restrict__ b_hh, const float *__restrict__ h0, int B, int T,
                                                  int reverse, float *__restrict__ y, long ldy, long bsy,
-                                                 float *__restrict__ hn_out, GruSaved sv) {
-    __shared__ float hs[2][GBT][HS_LD];
+                                                 float *__restrict__ hn_out, GruSaved sv, int y_vec) {
+    __shared__ __align__(16) float hs[2][GBT][HS_LD];
     __shared__ __align__(16) ww_bf16 hb[BF16 ? 2 : 1][BF16 ? GBT : 1][HB_LD];
+    // what the backward needs of a step (r, z, n, W_hn h + b_hn, h_{t-1}) is parked in LDS in the MFMA result layout (a lane
+    // holds 4 ROWS of one unit) and written out one step later as float4 along the UNIT axis by thread (row, 4 units):
+    // 6 vector stores per thread and step instead of 24 scalar ones -- the store issue, not the MFMAs, bounded a step.
+    // Two parities: a tile is rewritten two steps after it was filled, with a barrier in between.
+    extern __shared__ __align__(16) float gru_sav[];           // [2][5][GBT][HS_LD]
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
     const int b0 = blockIdx.x * GBT, u = 16 * w + j;
     float wreg[BF16 ? 1 : 3][BF16 ? 1 : 32];      // fp32: B operand of k-step kk, gate g: W_hh[g*128 + u][4kk + kq]
@@ -75,15 +91,48 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
         if constexpr (BF16) hb[0][row][c] = (ww_bf16)hv;
     }
     __syncthreads();
-    for (int it = 0; it < T; ++it) {
-        const int t = reverse ? T - 1 - it : it, cur = it & 1;
-        float gir[4], giz[4], gin[4];          // this step's projections: in flight under the MFMAs below
+    // input projections of a step are loaded TWO steps ahead (register sets A / B, alternating): a step is ~0.5 us of
+    // MFMA + gate work, an HBM/L2 round trip 1-2 us -- loaded at the top of the step that needs them (first version) the
+    // latency was most of the step
+    const float *gbase[4];                       // row (b, t = 0) of this lane's four batch rows, at its unit
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) gbase[reg] = gi + (size_t)min(b0 + 4 * kq + reg, B - 1) * T * (3 * GH) + u;
+    auto load_gi = [&](int it, float (&gr)[4], float (&gz)[4], float (&gn)[4]) {
+        if (it >= T) return;
+        const size_t toff = (size_t)(reverse ? T - 1 - it : it) * (3 * GH);      // wave-uniform
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int b = min(b0 + 4 * kq + reg, B - 1);
-            const float *g3 = gi + ((size_t)b * T + t) * (3 * GH);
-            gir[reg] = g3[u]; giz[reg] = g3[GH + u]; gin[reg] = g3[2 * GH + u];
+            const float *g3 = gbase[reg] + toff;
+            gr[reg] = g3[0]; gz[reg] = g3[GH]; gn[reg] = g3[2 * GH];
         }
+    };
+    const int frow = tid >> 5, fc0 = 4 * (tid & 31);
+    const bool frow_ok = b0 + frow < B;
+    const size_t fm0 = (size_t)(b0 + frow) * T * GH + fc0;                 // element (b, t = 0, fc0) of the (B*T, 128) tensors
+    float *const fy0 = y + (size_t)(b0 + frow) * bsy + fc0;
+    const float *const fs0 = gru_sav + frow * HS_LD + fc0;
+    auto flush = [&](int it) {                  // step `it` is complete (barrier passed): its tiles -> HBM
+        if (!frow_ok) return;
+        const int t = reverse ? T - 1 - it : it, par = it & 1;
+        const size_t m = fm0 + (size_t)t * GH;
+        const float *sp = fs0 + (size_t)par * 5 * GBT * HS_LD;
+        *reinterpret_cast<float4 *>(sv.r + m) = *reinterpret_cast<const float4 *>(sp);
+        *reinterpret_cast<float4 *>(sv.z + m) = *reinterpret_cast<const float4 *>(sp + GBT * HS_LD);
+        *reinterpret_cast<float4 *>(sv.n + m) = *reinterpret_cast<const float4 *>(sp + 2 * GBT * HS_LD);
+        *reinterpret_cast<float4 *>(sv.hn + m) = *reinterpret_cast<const float4 *>(sp + 3 * GBT * HS_LD);
+        *reinterpret_cast<float4 *>(sv.hp + m) = *reinterpret_cast<const float4 *>(sp + 4 * GBT * HS_LD);
+        const float4 h4 = *reinterpret_cast<const float4 *>(&hs[par ^ 1][frow][fc0]);
+        float *yo = fy0 + (size_t)t * ldy;
+        if (y_vec) *reinterpret_cast<float4 *>(yo) = h4;
+        else { yo[0] = h4.x; yo[1] = h4.y; yo[2] = h4.z; yo[3] = h4.w; }
+    };
+    auto step = [&](int it, float (&sr)[4], float (&sz)[4], float (&sn)[4]) {
+        const int cur = it & 1;
+        float gir[4], giz[4], gin[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) { gir[reg] = sr[reg]; giz[reg] = sz[reg]; gin[reg] = sn[reg]; }
+        load_gi(it + 2, sr, sz, sn);            // the set is free again: refill it for the step after next
+        if (it > 0) flush(it - 1);
         floatx4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if constexpr (BF16) {
 #pragma unroll
@@ -102,22 +151,29 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
         }
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {     // D[row = 4kq + reg][unit u]
-            const int row = 4 * kq + reg, b = b0 + row;
-            if (b < B) {
-                const size_t m = (size_t)b * T + t;
-                const float hnv = acc[2][reg] + bhn;
-                const float r = sigmoidf_(gir[reg] + acc[0][reg] + bhr);
-                const float z = sigmoidf_(giz[reg] + acc[1][reg] + bhz);
-                const float n = tanhf(gin[reg] + r * hnv);
-                const float hp = hs[cur][row][u];
-                const float h = (1.0f - z) * n + z * hp;
-                hs[cur ^ 1][row][u] = h;
-                if constexpr (BF16) hb[cur ^ 1][row][u] = (ww_bf16)h;
-                sv.r[m * GH + u] = r; sv.z[m * GH + u] = z; sv.n[m * GH + u] = n; sv.hn[m * GH + u] = hnv; sv.hp[m * GH + u] = hp;
-                y[(size_t)b * bsy + (size_t)t * ldy + u] = h;
-            }
+            const int row = 4 * kq + reg;
+            const float hnv = acc[2][reg] + bhn;
+            const float r = gate_sigmoid<BF16>(gir[reg] + acc[0][reg] + bhr);
+            const float z = gate_sigmoid<BF16>(giz[reg] + acc[1][reg] + bhz);
+            const float n = gate_tanh<BF16>(gin[reg] + r * hnv);
+            const float hp = hs[cur][row][u];
+            const float h = (1.0f - z) * n + z * hp;
+            hs[cur ^ 1][row][u] = h;
+            if constexpr (BF16) hb[cur ^ 1][row][u] = (ww_bf16)h;
+            float *sp = gru_sav + (size_t)cur * 5 * GBT * HS_LD + row * HS_LD + u;
+            sp[0] = r; sp[GBT * HS_LD] = z; sp[2 * GBT * HS_LD] = n; sp[3 * GBT * HS_LD] = hnv; sp[4 * GBT * HS_LD] = hp;
         }
         __syncthreads();
+    };
+    {
+        float ar[4], az[4], an[4], br[4], bz[4], bn[4];
+        load_gi(0, ar, az, an);
+        load_gi(1, br, bz, bn);
+        for (int it = 0; it < T; it += 2) {
+            step(it, ar, az, an);
+            if (it + 1 < T) step(it + 1, br, bz, bn);
+        }
+        flush(T - 1);
     }
     if (hn_out)
         for (int e = tid; e < GBT * GH; e += 512) {
@@ -156,20 +212,26 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
         dhs[row][c] = (dhn && b0 + row < B) ? dhn[(size_t)(b0 + row) * GH + c] : 0.f;
     }
     __syncthreads();
-    float pr[4], pz[4], pn[4], phn[4], php[4], pdy[4];      // saved values of the step about to be processed
-    auto prefetch = [&](int t) {
+    // saved gates of a step are loaded TWO steps ahead (register sets A / B, alternating), as in the forward kernel
+    struct Saved { float r[4], z[4], n[4], hn[4], hp[4], dy[4]; };
+    auto prefetch = [&](int it, Saved &S) {
+        if (it >= T) return;
+        const int t = reverse ? it : T - 1 - it;        // the forward pass's time order, backwards
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int e = tid + 512 * q, row = e >> 7, c = e & 127, b = min(b0 + row, B - 1);
             const size_t i = ((size_t)b * T + t) * GH + c;
-            pr[q] = sv.r[i]; pz[q] = sv.z[i]; pn[q] = sv.n[i]; phn[q] = sv.hn[i]; php[q] = sv.hp[i];
-            pdy[q] = dy ? dy[(size_t)b * bsy + (size_t)t * ldy + c] : 0.f;
+            S.r[q] = sv.r[i]; S.z[q] = sv.z[i]; S.n[q] = sv.n[i]; S.hn[q] = sv.hn[i]; S.hp[q] = sv.hp[i];
+            S.dy[q] = dy ? dy[(size_t)b * bsy + (size_t)t * ldy + c] : 0.f;
         }
     };
-    prefetch(reverse ? 0 : T - 1);
     float sar = 0.f, saz = 0.f, san = 0.f, shn = 0.f;      // bias-gradient partials of column c = tid & 127 (rows: 4 per thread)
-    for (int it = 0; it < T; ++it) {
-        const int t = reverse ? it : T - 1 - it;        // the forward pass's time order, backwards
+    auto step = [&](int it, Saved &S) {
+        const int t = reverse ? it : T - 1 - it;
+        float pr[4], pz[4], pn[4], phn[4], php[4], pdy[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { pr[q] = S.r[q]; pz[q] = S.z[q]; pn[q] = S.n[q]; phn[q] = S.hn[q]; php[q] = S.hp[q]; pdy[q] = S.dy[q]; }
+        prefetch(it + 2, S);                            // the set is free again
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                   // elementwise part: 16 x 128 cells over 512 threads
             const int e = tid + 512 * q, row = e >> 7, c = e & 127, b = b0 + row;
@@ -198,7 +260,6 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
             dhs[row][c] = keep;                          // read and written by this thread only
         }
         __syncthreads();
-        if (it + 1 < T) prefetch(reverse ? it + 1 : T - 2 - it);      // in flight under the MFMAs
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
         if constexpr (BF16) {
 #pragma unroll
@@ -213,6 +274,15 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) dhs[4 * kq + reg][u] += acc[reg];
         __syncthreads();
+    };
+    {
+        Saved A, Bs;
+        prefetch(0, A);
+        prefetch(1, Bs);
+        for (int it = 0; it < T; it += 2) {
+            step(it, A);
+            if (it + 1 < T) step(it + 1, Bs);
+        }
     }
     if (dh0)
         for (int e = tid; e < GBT * GH; e += 512) {
@@ -326,12 +396,15 @@ extern "C" int ww_gru_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
     // Gi[(b,t)][3H] = x[(b,t)][:] W_ih^T + b_ih for all time steps at once
     rc = ww_gemm(mode, x, ldx, 1, B * T, w_ih, I, 1, 3 * GH, I, (float *)(w + L.gi), 3 * GH, b_ih, 0, 1, nullptr, st);
     if (rc) return rc;
-    if (mode == WW_ACT_BF16)
-        hipLaunchKernelGGL(k_gru_fwd<true>, dim3((B + GBT - 1) / GBT), dim3(512), 0, st, (const float *)(w + L.gi), w_hh, b_hh, h0,
-                           B, T, reverse, y, ldy, (long)T * ldy, h_n, saved(w, L));
-    else
-        hipLaunchKernelGGL(k_gru_fwd<false>, dim3((B + GBT - 1) / GBT), dim3(512), 0, st, (const float *)(w + L.gi), w_hh, b_hh, h0,
-                           B, T, reverse, y, ldy, (long)T * ldy, h_n, saved(w, L));
+    const size_t smem = (size_t)2 * 5 * GBT * HS_LD * sizeof(float);
+    const int y_vec = (ldy % 4 == 0) && (((uintptr_t)y & 15) == 0);
+    auto go = [&](auto kern) -> int {
+        WW_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3((B + GBT - 1) / GBT), dim3(512), smem, st, (const float *)(w + L.gi), w_hh, b_hh, h0, B, T,
+                           reverse, y, ldy, (long)T * ldy, h_n, saved(w, L), y_vec);
+        return WW_OK;
+    };
+    if ((rc = mode == WW_ACT_BF16 ? go(k_gru_fwd<true>) : go(k_gru_fwd<false>))) return rc;
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
