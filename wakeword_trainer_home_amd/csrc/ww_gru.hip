@@ -187,9 +187,9 @@ template <bool BF16>
 __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh, const float *__restrict__ dy, long ldy,
                                                  long bsy, const float *__restrict__ dhn, int B, int T, int reverse,
                                                  GruSaved sv, float *__restrict__ dgi, float *__restrict__ dgh,
-                                                 float *__restrict__ dh0, float *__restrict__ bias_part) {
-    __shared__ float dhs[GBT][HS_LD];
-    __shared__ float dg[BF16 ? 8 : GBT][DG_LD];      // fp32 operand tile (bf16 mode: only the bias-gradient reduction uses it)
+                                                 float *__restrict__ dh0, float *__restrict__ bias_part, int dy_vec) {
+    __shared__ __align__(16) float dhs[GBT][HS_LD];
+    __shared__ __align__(16) float dg[BF16 ? 1 : GBT][DG_LD];      // fp32 operand tile
     __shared__ __align__(16) ww_bf16 dgb[BF16 ? GBT : 1][DGB_LD];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
     const int b0 = blockIdx.x * GBT, u = 16 * w + j;
@@ -212,53 +212,74 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
         dhs[row][c] = (dhn && b0 + row < B) ? dhn[(size_t)(b0 + row) * GH + c] : 0.f;
     }
     __syncthreads();
-    // saved gates of a step are loaded TWO steps ahead (register sets A / B, alternating), as in the forward kernel
-    struct Saved { float r[4], z[4], n[4], hn[4], hp[4], dy[4]; };
+    // elementwise part: thread = (batch row, 4 consecutive units) -> every tensor moves as ONE float4 per thread and step
+    // (5 saved gates + dy in, dGi / dGh (3 gates each) out: 12 vector accesses instead of 48 scalar ones; the recurrence
+    // is VALU-issue-bound and two thirds of its instructions were address arithmetic and scalar memory operations).
+    // The saved gates of a step are loaded TWO steps ahead (register sets A / B, alternating), as in the forward kernel.
+    const int erow = tid >> 5, ec0 = 4 * (tid & 31);
+    const int eb = min(b0 + erow, B - 1);
+    const bool erow_ok = b0 + erow < B;
+    const size_t em0 = (size_t)eb * T * GH + ec0;                        // (b, t = 0, ec0) of the (B*T, 128) tensors
+    const float *const edy0 = dy ? dy + (size_t)eb * bsy + ec0 : nullptr;
+    struct Saved { float4 r, z, n, hn, hp, dy; };
     auto prefetch = [&](int it, Saved &S) {
         if (it >= T) return;
         const int t = reverse ? it : T - 1 - it;        // the forward pass's time order, backwards
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = tid + 512 * q, row = e >> 7, c = e & 127, b = min(b0 + row, B - 1);
-            const size_t i = ((size_t)b * T + t) * GH + c;
-            S.r[q] = sv.r[i]; S.z[q] = sv.z[i]; S.n[q] = sv.n[i]; S.hn[q] = sv.hn[i]; S.hp[q] = sv.hp[i];
-            S.dy[q] = dy ? dy[(size_t)b * bsy + (size_t)t * ldy + c] : 0.f;
+        const size_t i = em0 + (size_t)t * GH;
+        S.r = *reinterpret_cast<const float4 *>(sv.r + i);
+        S.z = *reinterpret_cast<const float4 *>(sv.z + i);
+        S.n = *reinterpret_cast<const float4 *>(sv.n + i);
+        S.hn = *reinterpret_cast<const float4 *>(sv.hn + i);
+        S.hp = *reinterpret_cast<const float4 *>(sv.hp + i);
+        if (edy0) {
+            const float *p = edy0 + (size_t)t * ldy;
+            S.dy = dy_vec ? *reinterpret_cast<const float4 *>(p) : make_float4(p[0], p[1], p[2], p[3]);
+        } else {
+            S.dy = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    float sar = 0.f, saz = 0.f, san = 0.f, shn = 0.f;      // bias-gradient partials of column c = tid & 127 (rows: 4 per thread)
+    float sar[4] = {0.f, 0.f, 0.f, 0.f}, saz[4] = {0.f, 0.f, 0.f, 0.f}, san[4] = {0.f, 0.f, 0.f, 0.f}, shn[4] = {0.f, 0.f, 0.f, 0.f};
     auto step = [&](int it, Saved &S) {
         const int t = reverse ? it : T - 1 - it;
-        float pr[4], pz[4], pn[4], phn[4], php[4], pdy[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { pr[q] = S.r[q]; pz[q] = S.z[q]; pn[q] = S.n[q]; phn[q] = S.hn[q]; php[q] = S.hp[q]; pdy[q] = S.dy[q]; }
+        const float pr[4] = {S.r.x, S.r.y, S.r.z, S.r.w}, pz[4] = {S.z.x, S.z.y, S.z.z, S.z.w};
+        const float pn[4] = {S.n.x, S.n.y, S.n.z, S.n.w}, phn[4] = {S.hn.x, S.hn.y, S.hn.z, S.hn.w};
+        const float php[4] = {S.hp.x, S.hp.y, S.hp.z, S.hp.w}, pdy[4] = {S.dy.x, S.dy.y, S.dy.z, S.dy.w};
         prefetch(it + 2, S);                            // the set is free again
+        const float4 dh4 = *reinterpret_cast<const float4 *>(&dhs[erow][ec0]);
+        const float dhv[4] = {dh4.x, dh4.y, dh4.z, dh4.w};
+        float dar[4], daz[4], dan[4], dhn_[4], keep[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                   // elementwise part: 16 x 128 cells over 512 threads
-            const int e = tid + 512 * q, row = e >> 7, c = e & 127, b = b0 + row;
-            float dar = 0.f, daz = 0.f, dan = 0.f, dhn_ = 0.f, keep = 0.f;
-            if (b < B) {
-                const size_t m = (size_t)b * T + t;
-                const float dh = dhs[row][c] + pdy[q];
-                const float r = pr[q], z = pz[q], n = pn[q], hnv = phn[q], hp = php[q];
-                const float dn = dh * (1.0f - z), dz = dh * (hp - n);
-                dan = dn * (1.0f - n * n);
-                dar = dan * hnv * r * (1.0f - r);
-                daz = dz * z * (1.0f - z);
-                dhn_ = dan * r;
-                keep = dh * z;
-                float *o = dgi + m * (3 * GH);
-                o[c] = dar; o[GH + c] = daz; o[2 * GH + c] = dan;
-                float *p = dgh + m * (3 * GH);
-                p[c] = dar; p[GH + c] = daz; p[2 * GH + c] = dhn_;
-                sar += dar; saz += daz; san += dan; shn += dhn_;
-            }
-            if constexpr (BF16) {
-                dgb[row][c] = (ww_bf16)dar; dgb[row][GH + c] = (ww_bf16)daz; dgb[row][2 * GH + c] = (ww_bf16)dhn_;
-            } else {
-                dg[row][c] = dar; dg[row][GH + c] = daz; dg[row][2 * GH + c] = dhn_;
-            }
-            dhs[row][c] = keep;                          // read and written by this thread only
+        for (int q = 0; q < 4; ++q) {
+            const float dh = erow_ok ? dhv[q] + pdy[q] : 0.f;
+            const float r = pr[q], z = pz[q], n = pn[q], hnv = phn[q], hp = php[q];
+            const float dn = dh * (1.0f - z), dz = dh * (hp - n);
+            dan[q] = dn * (1.0f - n * n);
+            dar[q] = dan[q] * hnv * r * (1.0f - r);
+            daz[q] = dz * z * (1.0f - z);
+            dhn_[q] = dan[q] * r;
+            keep[q] = dh * z;
+            sar[q] += dar[q]; saz[q] += daz[q]; san[q] += dan[q]; shn[q] += dhn_[q];
         }
+        if (erow_ok) {
+            const size_t m3 = ((size_t)(b0 + erow) * T + t) * (3 * GH) + ec0;
+            *reinterpret_cast<float4 *>(dgi + m3) = make_float4(dar[0], dar[1], dar[2], dar[3]);
+            *reinterpret_cast<float4 *>(dgi + m3 + GH) = make_float4(daz[0], daz[1], daz[2], daz[3]);
+            *reinterpret_cast<float4 *>(dgi + m3 + 2 * GH) = make_float4(dan[0], dan[1], dan[2], dan[3]);
+            *reinterpret_cast<float4 *>(dgh + m3) = make_float4(dar[0], dar[1], dar[2], dar[3]);
+            *reinterpret_cast<float4 *>(dgh + m3 + GH) = make_float4(daz[0], daz[1], daz[2], daz[3]);
+            *reinterpret_cast<float4 *>(dgh + m3 + 2 * GH) = make_float4(dhn_[0], dhn_[1], dhn_[2], dhn_[3]);
+        }
+        if constexpr (BF16) {
+            typedef Act<ww_bf16> A16;
+            *reinterpret_cast<uint2 *>(&dgb[erow][ec0]) = make_uint2(A16::pack2(dar[0], dar[1]), A16::pack2(dar[2], dar[3]));
+            *reinterpret_cast<uint2 *>(&dgb[erow][GH + ec0]) = make_uint2(A16::pack2(daz[0], daz[1]), A16::pack2(daz[2], daz[3]));
+            *reinterpret_cast<uint2 *>(&dgb[erow][2 * GH + ec0]) = make_uint2(A16::pack2(dhn_[0], dhn_[1]), A16::pack2(dhn_[2], dhn_[3]));
+        } else {
+            *reinterpret_cast<float4 *>(&dg[erow][ec0]) = make_float4(dar[0], dar[1], dar[2], dar[3]);
+            *reinterpret_cast<float4 *>(&dg[erow][GH + ec0]) = make_float4(daz[0], daz[1], daz[2], daz[3]);
+            *reinterpret_cast<float4 *>(&dg[erow][2 * GH + ec0]) = make_float4(dhn_[0], dhn_[1], dhn_[2], dhn_[3]);
+        }
+        *reinterpret_cast<float4 *>(&dhs[erow][ec0]) = make_float4(keep[0], keep[1], keep[2], keep[3]);   // this thread's cells only
         __syncthreads();
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
         if constexpr (BF16) {
@@ -289,20 +310,25 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
             const int row = e >> 7, c = e & 127;
             if (b0 + row < B) dh0[(size_t)(b0 + row) * GH + c] = dhs[row][c];
         }
-    // bias gradients: this block's column sums over its rows and all time steps -> bias_part[block][db_ih(384) | db_hh(384)]
-    __syncthreads();
+    // bias gradients: this block's column sums over its 16 rows and all time steps -> bias_part[block][db_ih(384) | db_hh(384)]
+    // (thread (row, 4 columns) holds the time sums of its cells; one pass through dhs per gate, rows added in a fixed order)
     {
-        const int c = tid & 127, part = tid >> 7;
-        dg[part][c] = sar; dg[part][GH + c] = saz; dg[part][2 * GH + c] = san; dg[4 + part][c] = shn;
-        __syncthreads();
-        if (tid < 128) {
-            const float ar = dg[0][c] + dg[1][c] + dg[2][c] + dg[3][c];
-            const float az = dg[0][GH + c] + dg[1][GH + c] + dg[2][GH + c] + dg[3][GH + c];
-            const float an = dg[0][2 * GH + c] + dg[1][2 * GH + c] + dg[2][2 * GH + c] + dg[3][2 * GH + c];
-            const float hn = dg[4][c] + dg[5][c] + dg[6][c] + dg[7][c];
-            float *o = bias_part + (size_t)blockIdx.x * (6 * GH);
-            o[c] = ar; o[GH + c] = az; o[2 * GH + c] = an;
-            o[3 * GH + c] = ar; o[4 * GH + c] = az; o[5 * GH + c] = hn;
+        float *o = bias_part + (size_t)blockIdx.x * (6 * GH);
+        const float *src[4] = {sar, saz, san, shn};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            __syncthreads();
+            *reinterpret_cast<float4 *>(&dhs[erow][ec0]) = make_float4(src[k][0], src[k][1], src[k][2], src[k][3]);
+            __syncthreads();
+            if (tid < 128) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < GBT; ++r) t += dhs[r][tid];
+                if (k == 0) { o[tid] = t; o[3 * GH + tid] = t; }
+                else if (k == 1) { o[GH + tid] = t; o[4 * GH + tid] = t; }
+                else if (k == 2) o[2 * GH + tid] = t;
+                else o[5 * GH + tid] = t;
+            }
         }
     }
 }
@@ -426,12 +452,13 @@ extern "C" int ww_gru_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
     const GruSaved sv = saved(w, L);
     float *bpart = part + (size_t)GRU_SPLITS * 3 * GH * std::max(I, GH);
     const int nblk = (B + GBT - 1) / GBT;
+    const int dy_vec = dy && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0);
     if (mode == WW_ACT_BF16)
         hipLaunchKernelGGL(k_gru_bwd<true>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
-                           dgh, dh0, bpart);
+                           dgh, dh0, bpart, dy_vec);
     else
         hipLaunchKernelGGL(k_gru_bwd<false>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
-                           dgh, dh0, bpart);
+                           dgh, dh0, bpart, dy_vec);
     WW_LAUNCH_CHECK();
     const int M = B * T;
     const int splits = M >= 4096 ? GRU_SPLITS : 1;
