@@ -259,3 +259,41 @@ def test_native_resume_continues_like_an_uninterrupted_run(tmp_path):
     assert tail_loss == full_loss[6:]
     for k in full_sd:
         assert torch.equal(full_sd[k], tail_sd[k]), k
+
+
+def test_ragged_batches_through_the_native_step(tmp_path):
+    """A DataLoader's last batch is short (drop_last=False in the reference): batch sizes 8, 8, 5 and a single-sample batch
+    go through the same native step (workspaces are per shape) and track the oracle pipeline step by step."""
+    from wakeword_trainer_home_amd.config import get_preset
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    from wakeword_trainer_home_amd.data import make_synthetic_batch
+    from oracle.cnn_small import CNNSmallOracle
+    from oracle.train_step import TorchLoss, frontend, train_step
+    cfg = get_preset("cnn_small_logmel40")
+    cfg.training.epochs, cfg.optimizer.warmup_epochs, cfg.training.batch_size = 1, 0, 8
+    torch.manual_seed(8)
+    model = create_model("cnn_small", dropout=0.0)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    wave, y = make_synthetic_batch(22, 24000, seed=9)
+    y[::2] = 1
+    cuts = [(0, 8), (8, 16), (16, 21), (21, 22)]
+    batches = [(wave[a:b], y[a:b]) for a, b in cuts]
+    t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=tmp_path, device=DEV)
+    rec = _Rec()
+    t.add_callback(rec)
+    loss, acc = t.train_epoch(0)
+    assert len(rec.loss) == 4 and np.isfinite(loss) and 0.0 <= acc <= 1.0
+    oracle = CNNSmallOracle(dropout=0.0)
+    oracle.load_state_dict(sd)
+    oracle.train()
+    opt = torch.optim.AdamW(oracle.parameters(), lr=cfg.training.learning_rate, weight_decay=cfg.optimizer.weight_decay)
+    a = cfg.augmentation
+    spec = dict(freq_mask_param=a.freq_mask_param, time_mask_param=a.time_mask_param, n_freq_masks=a.n_freq_masks,
+                n_time_masks=a.n_time_masks, freq_mask_prob=a.freq_mask_prob, time_mask_prob=a.time_mask_prob)
+    for i, (w, yy) in enumerate(batches):
+        x, _ = frontend(w.numpy(), spec, seed=a.seed, step=i)
+        r = train_step(oracle, TorchLoss("cross_entropy", eps=cfg.loss.label_smoothing), opt, x, yy, 1.0)
+        assert abs(r["loss"] - rec.loss[i]) < 2e-3, (i, r["loss"], rec.loss[i])
+    # the epoch's sample-weighted accuracy counts every sample of every batch once
+    assert t.train_metrics_tracker.compute().total_samples == 22
