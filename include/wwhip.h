@@ -169,7 +169,9 @@ int ww_head_bwd(ww_ctx *ctx, const float *dlogits, const float *pd, const float 
                 uint64_t sample_offset, const float *gamma_last, const float *mr_last, float *dfc_w,
                 float *dfc_b, float *dpool, float *coef_last, float *dgamma_last, float *dbeta_last,
                 ww_stream_t stream);
-/* g == NULL -> this is the last conv layer: dz = dpool[b][c] * [z>0] (dpool carries 1/HW) */
+/* g == NULL -> this is the last conv layer: dz = dpool[b][c] * [z>0] (dpool carries 1/HW).
+ * WW_ACT_BF16: y_out is not read -- the kernel recomputes it from y_in with the forward's MFMA chain and rounding
+ * (bit-identical to the stored tensor); it must still be passed (fp32 mode reads it).  B*H*W < 2^31.            */
 int ww_pwconv1x1_bwd(ww_ctx *ctx, int act_dtype, const void *g, const float *dpool, const void *y_out,
                      const float *ss_out, const float *coef, const void *y_in, const float *ss_in, const float *mr_in,
                      const float *gamma_in, const float *w, int B, int H, int W, void *g_in, float *dw,
