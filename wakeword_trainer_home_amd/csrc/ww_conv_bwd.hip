@@ -624,10 +624,15 @@ __global__ __launch_bounds__(256, Act<T>::is_f32 ? 2 : 3) void k_dw_bwd(const T 
 }
 
 // ------------------------------------------------------------------------------------- stem
-template <typename T>
+// RECOMP: the layer's own output is recomputed from the input rows that sit in LDS for the weight gradient anyway (the
+// forward kernel's nine fmaf in the same order, then its rounding: bit-identical to the stored tensor) instead of read
+// back -- the stem reads 2A -> 1A per launch.  Needs the stem weights, which the stand-alone C entry point does not get
+// (its signature predates this): the whole-model path passes them, ww_conv_stem_bwd reads y_out.
+template <typename T, bool RECOMP>
 __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const T *__restrict__ y_out,
-                                                  const float *__restrict__ coef, const float *__restrict__ x, int B,
-                                                  int Hin, int Win, int Ho, int Wo, float *__restrict__ dw_partials) {
+                                                  const float *__restrict__ w, const float *__restrict__ coef,
+                                                  const float *__restrict__ x, int B, int Hin, int Win, int Ho, int Wo,
+                                                  float *__restrict__ dw_partials) {
     __shared__ float sh[8 * 576];
     extern __shared__ float xs[];            // [3][Win + 2] zero-padded input rows (see k_stem_fwd)
     const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
@@ -635,9 +640,13 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const
     const float2 cA = *reinterpret_cast<const float2 *>(coef + 2 * cl);
     const float2 cB = *reinterpret_cast<const float2 *>(coef + 64 + 2 * cl);
     const float2 cC = *reinterpret_cast<const float2 *>(coef + 128 + 2 * cl);
-    float dwa[9], dwb[9];
+    float dwa[9], dwb[9], w0[9], w1[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) dwa[t] = dwb[t] = 0.f;
+    for (int t = 0; t < 9; ++t) {
+        dwa[t] = dwb[t] = 0.f;
+        w0[t] = RECOMP ? w[(2 * cl) * 9 + t] : 0.f;
+        w1[t] = RECOMP ? w[(2 * cl + 1) * 9 + t] : 0.f;
+    }
     const long nrows = (long)B * Ho;
     for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int b = (int)(row / Ho), oh = (int)(row - (long)b * Ho);
@@ -652,17 +661,30 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const
         for (int ow = slot; ow < Wo; ow += 8) {
             const size_t o = ((size_t)row * Wo + ow) * 64 + 2 * cl;
             const float2 gz = Act<T>::cvt2(Act<T>::ldraw2(g + o));
-            const float2 yo = Act<T>::cvt2(Act<T>::ldraw2(y_out + o));
-            const float d0 = fmaf(cA.x, gz.x, fmaf(cB.x, yo.x, cC.x));
-            const float d1 = fmaf(cA.y, gz.y, fmaf(cB.y, yo.y, cC.y));
+            float v[9];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const float v = xs[kh * ld + 2 * ow + kw];
-                    dwa[kh * 3 + kw] = fmaf(d0, v, dwa[kh * 3 + kw]);
-                    dwb[kh * 3 + kw] = fmaf(d1, v, dwb[kh * 3 + kw]);
+                for (int kw = 0; kw < 3; ++kw) v[kh * 3 + kw] = xs[kh * ld + 2 * ow + kw];
+            float2 yo;
+            if constexpr (RECOMP) {
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {            // k_stem_fwd's accumulation order
+                    a0 = fmaf(v[t], w0[t], a0);
+                    a1 = fmaf(v[t], w1[t], a1);
                 }
+                yo = Act<T>::round2(make_float2(a0, a1));
+            } else {
+                yo = Act<T>::cvt2(Act<T>::ldraw2(y_out + o));
+            }
+            const float d0 = fmaf(cA.x, gz.x, fmaf(cB.x, yo.x, cC.x));
+            const float d1 = fmaf(cA.y, gz.y, fmaf(cB.y, yo.y, cC.y));
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                dwa[t] = fmaf(d0, v[t], dwa[t]);
+                dwb[t] = fmaf(d1, v[t], dwb[t]);
+            }
         }
     }
 #pragma unroll
@@ -762,17 +784,21 @@ int launch_dw_bwd(ww_ctx *ctx, const void *g, const void *y_out, const float *co
 }
 
 template <typename T>
-int launch_stem_bwd(ww_ctx *ctx, const void *g, const void *y_out, const float *coef, const float *x, int B, int Hin,
-                    int Win, float *dwp, int *grid_out, hipStream_t st) {
+int launch_stem_bwd(ww_ctx *ctx, const void *g, const void *y_out, const float *w, const float *coef, const float *x, int B,
+                    int Hin, int Win, float *dwp, int *grid_out, hipStream_t st) {
     const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
     const long nrows = (long)B * Ho;
     const size_t smem = (size_t)3 * (Win + 2) * sizeof(float);
-    // only the weight-gradient slab is used (576 columns): room for 2048 rows -> full occupancy
-    const int grid = ww_occupancy_grid((const void *)k_stem_bwd<T>, 256, smem, nrows, 2048);
     ww_prof_scope ps_(ctx, WW_K_STEM_BWD, st);
-    hipLaunchKernelGGL(k_stem_bwd<T>, dim3(grid), dim3(256), smem, st, (const T *)g, (const T *)y_out, coef, x, B, Hin, Win,
-                       Ho, Wo, dwp);
-    *grid_out = grid;
+    auto go = [&](auto kern) {
+        // only the weight-gradient slab is used (576 columns): room for 2048 rows -> full occupancy
+        const int grid = ww_occupancy_grid((const void *)kern, 256, smem, nrows, 2048);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, (const T *)g, (const T *)y_out, w, coef, x, B, Hin, Win, Ho,
+                           Wo, dwp);
+        *grid_out = grid;
+    };
+    if (w) go(k_stem_bwd<T, true>);
+    else go(k_stem_bwd<T, false>);
     return WW_OK;
 }
 }  // namespace
@@ -836,9 +862,9 @@ extern "C" int ww_dwconv3x3_bwd(ww_ctx *ctx, int act_dtype, const void *g, const
                                   dw, st);
 }
 
-extern "C" int ww_conv_stem_bwd(ww_ctx *ctx, int act_dtype, const void *g, const void *y_out, const float *coef,
-                                const float *x, int B, int Hin, int Win, float *dw, void *scratch,
-                                ww_stream_t stream) {
+// w != NULL: recompute y_out from x (see k_stem_bwd); the whole-model backward (ww_model.hip) comes in here with the weights
+int ww_stem_bwd_impl(ww_ctx *ctx, int act_dtype, const void *g, const void *y_out, const float *w, const float *coef,
+                     const float *x, int B, int Hin, int Win, float *dw, void *scratch, ww_stream_t stream) {
     WW_REQUIRE(ctx && g && y_out && coef && x && dw && scratch, WW_E_INVALID, "ww_conv_stem_bwd: null argument");
     WW_REQUIRE(B >= 1 && Hin >= 1 && Win >= 1, WW_E_INVALID, "ww_conv_stem_bwd: bad shape (%d,%d,%d)", B, Hin, Win);
     int rc = check_act_b("ww_conv_stem_bwd", act_dtype);
@@ -846,10 +872,16 @@ extern "C" int ww_conv_stem_bwd(ww_ctx *ctx, int act_dtype, const void *g, const
     hipStream_t st = (hipStream_t)stream;
     float *dwp = (float *)scratch + WW_STAT_SLAB_FLOATS;
     int grid = 0;
-    rc = act_dtype == WW_ACT_BF16 ? launch_stem_bwd<ww_bf16>(ctx, g, y_out, coef, x, B, Hin, Win, dwp, &grid, st)
-                                  : launch_stem_bwd<float>(ctx, g, y_out, coef, x, B, Hin, Win, dwp, &grid, st);
+    rc = act_dtype == WW_ACT_BF16 ? launch_stem_bwd<ww_bf16>(ctx, g, y_out, w, coef, x, B, Hin, Win, dwp, &grid, st)
+                                  : launch_stem_bwd<float>(ctx, g, y_out, w, coef, x, B, Hin, Win, dwp, &grid, st);
     if (rc) return rc;
     WW_LAUNCH_CHECK();
     ww_prof_scope pf_(ctx, WW_K_FINALIZE, st);
     return ww_launch_colsum(dwp, grid, 576, dw, st);
+}
+
+extern "C" int ww_conv_stem_bwd(ww_ctx *ctx, int act_dtype, const void *g, const void *y_out, const float *coef,
+                                const float *x, int B, int Hin, int Win, float *dw, void *scratch,
+                                ww_stream_t stream) {
+    return ww_stem_bwd_impl(ctx, act_dtype, g, y_out, nullptr, coef, x, B, Hin, Win, dw, scratch, stream);
 }

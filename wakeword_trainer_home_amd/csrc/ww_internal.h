@@ -117,6 +117,9 @@ int ww_colsum_rows(const float *a, long rows, int cols, float *out, float *part,
 int ww_colsum_pair(const float *a, int rows, int cols, float *out0, float *out1, hipStream_t st);
 int ww_colsum_rows_small(const float *a, int rows, int cols, float *out, hipStream_t st);
 int ww_occupancy_grid(const void *fn, int block, size_t smem, long want, int cap);
+// ww_conv_bwd.hip: ww_conv_stem_bwd with the stem weights (w != NULL: y_out is recomputed from x instead of read)
+int ww_stem_bwd_impl(ww_ctx *ctx, int act_dtype, const void *g, const void *y_out, const float *w, const float *coef,
+                     const float *x, int B, int Hin, int Win, float *dw, void *scratch, ww_stream_t stream);
 // ww_ctx.hip: block sums of squares of g[0..n) into ctx->norm_partials (fixed partition -> deterministic); returns the count
 int ww_launch_sumsq_partials(ww_ctx *ctx, const float *g, size_t n, int *parts_out, hipStream_t st);
 

@@ -119,7 +119,8 @@ int conv_stack_bwd(ww_ctx *ctx, int act_dtype, void *const *params, void *const 
         if (rc) return rc;
         cur ^= 1;
     }
-    return ww_conv_stem_bwd(ctx, act_dtype, w + L.g[cur], w + L.y[0], Fp(L.coef[0]), x, B, F, T, G(0), scratch, stream);
+    return ww_stem_bwd_impl(ctx, act_dtype, w + L.g[cur], w + L.y[0], (const float *)params[0], Fp(L.coef[0]), x, B, F, T, G(0),
+                            scratch, stream);
 }
 
 // ---- frequency pooling between the conv stack and a recurrent layer (CRNN): seq[b][w][c] = mean_h relu(bn(y8[b][h][w][c]))
