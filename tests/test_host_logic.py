@@ -345,5 +345,9 @@ def test_flat_buckets_mixin_on_cpu():
     assert not net.grads_in_bucket()
     net.to("cpu", torch.float32)                                   # _apply -> rebuilt lazily
     assert net._fb_param is None and net.flat_param.numel() == flat.numel()
+    import copy
+    twin = copy.deepcopy(net)                                      # tensors are copied one by one: the twin rebuilds its bucket
+    assert twin.flat_param.data_ptr() != net.flat_param.data_ptr()
+    assert twin.a.weight.data_ptr() == twin.flat_param.data_ptr() and torch.equal(twin.flat_param, net.flat_param)
     with pytest.raises(ValueError, match="float32"):
         Net().double().flat_param

@@ -46,16 +46,19 @@ class FlatBuckets:
             off += t.numel()
         self._fb_views = views
 
+    def _fb_ready(self):
+        # rebuilt when missing or when the parameters no longer sit in the bucket (copy.deepcopy copies tensors one by one)
+        if self._fb_param is None or self._fb_plist[0].data_ptr() != self._fb_param.data_ptr():
+            self._fb_build()
+
     @property
     def flat_param(self):
-        if self._fb_param is None:
-            self._fb_build()
+        self._fb_ready()
         return self._fb_param
 
     @property
     def flat_grad(self):
-        if self._fb_param is None:
-            self._fb_build()
+        self._fb_ready()
         return self._fb_grad
 
     def grads_in_bucket(self) -> bool:
@@ -66,8 +69,7 @@ class FlatBuckets:
     def gather_grads(self):
         """Copy every ``.grad`` into its slot of ``flat_grad`` (two multi-tensor launches); a parameter without a
         gradient contributes zeros, as it would to ``clip_grad_norm_`` and the optimizer."""
-        if self._fb_param is None:
-            self._fb_build()
+        self._fb_ready()
         dst, src, missing = [], [], []
         for p, v in zip(self._fb_plist, self._fb_views):
             if p.grad is None:
