@@ -130,6 +130,7 @@ class Trainer:
         self.deferred_metrics = (bool(getattr(config.training, "deferred_metrics", True))
                                  and (self.native or self._async_autograd) and self._native_loss and self._skip_on_device)
         self._pending = None
+        self._dp_pack = None               # (key, flat buffer, views) of the packed gradient all-reduce
         self._host_bufs, self._buf_i = None, 0
         self._in_stream = None
         self.audio_augmentation = None     # data.augmentation.AudioAugmentation; applied to (B,N) training batches
@@ -186,17 +187,37 @@ class Trainer:
         return nat.decode_stats(self._stats_host)
 
     def _allreduce_grads(self):
+        """Average the gradients over the ranks with ONE collective: the native model's flat bucket as it is, any other
+        model's gradients packed into a persistent flat buffer (two multi-tensor copies around the all-reduce instead of
+        one latency-bound collective per parameter tensor -- 45 of them for the CRNN)."""
         if not self._dist:
             return
-        avg = self._dist.ReduceOp.AVG if self._dist.get_backend() == "nccl" else None   # RCCL averages in-kernel
-        tensors = [self.model.flat_grad] if self.native else [p.grad for p in self.model.parameters()
-                                                              if p.grad is not None]
-        for t in tensors:
-            if avg is not None:
-                self._dist.all_reduce(t, op=avg)
-            else:                                      # gloo (CPU tests) has no AVG
-                self._dist.all_reduce(t)
-                t.div_(self.world_size)
+        if self.native:
+            flat, grads = self.model.flat_grad, None
+        else:
+            grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+            if not grads:
+                return
+            if len(grads) == 1:
+                flat, grads = grads[0], None
+            else:
+                key = tuple(g.numel() for g in grads) + (grads[0].device, grads[0].dtype)
+                if self._dp_pack is None or self._dp_pack[0] != key:
+                    buf = torch.empty(sum(key[:-2]), dtype=grads[0].dtype, device=grads[0].device)
+                    views, off = [], 0
+                    for g in grads:
+                        views.append(buf[off:off + g.numel()].view_as(g))
+                        off += g.numel()
+                    self._dp_pack = (key, buf, views)
+                _, flat, views = self._dp_pack
+                torch._foreach_copy_(views, grads)
+        if self._dist.get_backend() == "nccl":
+            self._dist.all_reduce(flat, op=self._dist.ReduceOp.AVG)      # RCCL averages in-kernel
+        else:                                                            # gloo (CPU tests) has no AVG
+            self._dist.all_reduce(flat)
+            flat.div_(self.world_size)
+        if grads is not None:
+            torch._foreach_copy_(grads, self._dp_pack[2])
 
     # ------------------------------------------------------------------------------- inner steps
     def _launch_step_index(self) -> int:
