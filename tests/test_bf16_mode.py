@@ -105,8 +105,9 @@ def test_conv_bwd_layers_bf16(nat, kind, B, H, W):
     assert rel_err(dgamma.cpu(), (gi * yhat_in).sum(dim=(0, 1, 2))) < 1e-4
 
 
-@pytest.mark.parametrize("B,Fd,T,p", [(4, 40, 151, 0.3), (6, 13, 50, 0.0)])
-def test_cnn_small_bf16_close_to_fp32_oracle(nat, B, Fd, T, p):
+@pytest.mark.parametrize("B,Fd,T,p,min_cos", [(4, 40, 151, 0.3, 0.995), (6, 13, 50, 0.0, 0.995),
+                                              (5, 8, 12, 0.0, 0.98)])   # last: 4 x 6 maps (HW < one pixel tile), 120 pixels per channel
+def test_cnn_small_bf16_close_to_fp32_oracle(nat, B, Fd, T, p, min_cos):
     """whole model in bf16 storage vs the float64 oracle: logits within 3e-2 of their scale, gradient direction
     cos > 0.995 (9 layers x 2 roundings per value of 2^-9 relative each)."""
     from oracle.cnn_small import CNNSmallOracle
@@ -128,7 +129,11 @@ def test_cnn_small_bf16_close_to_fp32_oracle(nat, B, Fd, T, p):
     gn = torch.cat([q.grad.flatten().cpu().double() for q in model.parameters()])
     go = torch.cat([q.grad.flatten() for q in oracle.parameters()])
     cos = (gn @ go / (gn.norm() * go.norm())).item()
-    assert cos > 0.995, cos
+    assert cos > min_cos, cos
+    # the last pointwise layer's weight gradient comes straight out of the pooled-gradient variant of the backward kernel
+    # (per-pixel image lookup when an image is smaller than a tile): 0.993 at every size measured
+    ga, gb = model.blocks[3].pw.weight.grad.flatten().cpu().double(), oracle.blocks[3].pw.weight.grad.flatten()
+    assert (ga @ gb / (ga.norm() * gb.norm())).item() > 0.99
     model.eval()
     oracle.eval()
     with torch.no_grad():
