@@ -343,7 +343,8 @@ __global__ __launch_bounds__(256) void k_pw_fwd_bf16(const ww_bf16 *__restrict__
                                                      float *__restrict__ partials) {
     extern __shared__ __align__(16) unsigned char pwh_lds[];
     ww_bf16 *atile = reinterpret_cast<ww_bf16 *>(pwh_lds);                       // [128][72] bf16
-    float *otile = reinterpret_cast<float *>(pwh_lds + PW_TILE * PWH_LD * 2);    // [128][68] fp32
+    ww_bf16 *otile = atile + PW_TILE * PWH_LD;                                   // [128][72] bf16: the output as it is stored
+    // (36.9 KB together: 4 workgroups per CU, what the 96 VGPRs allow; an fp32 staging tile capped it at 3)
     typedef Act<ww_bf16> A16;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void k_pw_fwd_bf16(const ww_bf16 *__restrict__
             for (int reg = 0; reg < 16; ++reg) {
                 const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 const float v = A16::round1(acc[reg]);
-                otile[prow * PW_LD + 32 * n + r] = v;
+                otile[prow * PWH_LD + 32 * n + r] = (ww_bf16)v;
                 s1 += v;
                 s2 = fmaf(v, v, s2);
             }
@@ -408,14 +409,15 @@ __global__ __launch_bounds__(256) void k_pw_fwd_bf16(const ww_bf16 *__restrict__
         for (int i = 0; i < 8; ++i) {
             const int row = (tid >> 4) + 16 * i;
             if (p0 + row < M)
-                A16::st4(y + (size_t)(p0 + row) * 64 + 4 * c4, *reinterpret_cast<const float4 *>(otile + row * PW_LD + 4 * c4));
+                *reinterpret_cast<uint2 *>(y + (size_t)(p0 + row) * 64 + 4 * c4) =
+                    *reinterpret_cast<const uint2 *>(otile + row * PWH_LD + 4 * c4);
         }
     }
     if (partials) {
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         __syncthreads();
-        float *sh = otile;  // [wave][kind][32]
+        float *sh = reinterpret_cast<float *>(otile);  // [wave][kind][32]
         if (h == 0) {
             sh[wv * 64 + r] = s1;
             sh[wv * 64 + 32 + r] = s2;
@@ -547,7 +549,7 @@ int launch_dw_fwd(ww_ctx *ctx, const void *y_in, const float *ss_in, const float
 int launch_pw_fwd_bf16(ww_ctx *ctx, const void *y_in, const float *ss_in, const float *w, long M, void *y,
                        float *partials, int *grid_out, hipStream_t st) {
     const long ntiles = (M + PW_TILE - 1) / PW_TILE;
-    const size_t smem = (size_t)PW_TILE * PWH_LD * 2 + (size_t)PW_TILE * PW_LD * sizeof(float);
+    const size_t smem = (size_t)2 * PW_TILE * PWH_LD * 2;
     const int grid = ww_occupancy_grid((const void *)k_pw_fwd_bf16, 256, smem, ntiles, WW_MAX_PARTIALS);
     {
         ww_prof_scope ps_(ctx, WW_K_PW_FWD, st);
