@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the wakeword training inner loop on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1 without a launcher: this process starts the N ranks itself (``python -m torch.distributed.run``) BEFORE anything
+touches the GPU and relays rank 0's JSON line; under ``torch.distributed.run`` (the driver's command) it is a rank.
 
 One "step" = the whole hot path on one batch of synthetic 16 kHz x 1.5 s clips already resident in HBM:
 fused log-mel(40)+SpecAugment -> cnn_small forward -> 2-class loss -> backward -> [RCCL all-reduce of the flat
@@ -38,11 +41,38 @@ ALGO_BYTES = {
 }
 
 
-# HBM bytes per launch from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01_o_pmc_summary.md), measured
-# on exactly this command at the default batch 512 / bf16.  Reported as roofline.traffic only for that configuration.
-TRAFFIC_BYTES_B512_BF16 = {"dwconv3x3_bwd": 412.8e6, "pwconv1x1_bwd": 287.6e6, "dwconv3x3_fwd": 205.8e6,
-                           "pwconv1x1_fwd": 199.9e6, "conv_stem_bwd": 223.5e6, "conv_stem_fwd": 119.7e6, "gap_fwd": 100.1e6,
-                           "logmel_specaug": 84.6e6}
+# HBM bytes per launch come from the PMC passes of THIS command (separate rocprofv3 --pmc runs: FETCH_SIZE x2 on gfx950 +
+# WRITE_SIZE, aggregated by tools/pmc_traffic.py into profiles/pmc_traffic.json together with the batch / dtype / source
+# digest they were measured on).  bench.py cannot collect counters itself; it reports the file's figure only when the file
+# describes the running configuration AND the kernel sources it was measured on, and null otherwise.
+TRAFFIC_FILE = ROOT / "profiles" / "pmc_traffic.json"
+LOGMEL_FLOPS = 4.41e6        # per clip: 151 frames x (rFFT-1024 + power + sparse mel), SURVEY.md §8d
+VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak, MI355X_MICROARCH.md
+
+
+def kernel_source_digest():
+    """sha1 over csrc/*.hip|*.h: ties a PMC traffic figure to the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted((ROOT / "wakeword_trainer_home_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:12]
+
+
+def measured_traffic(kernel, batch, dtype):
+    """-> (bytes per launch | None, provenance string)."""
+    try:
+        t = json.loads(TRAFFIC_FILE.read_text())
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    if t.get("batch") != batch or t.get("dtype") != dtype:
+        return None, f"{TRAFFIC_FILE.name} was measured at batch {t.get('batch')} / {t.get('dtype')}"
+    src = f"{TRAFFIC_FILE.name} ({t.get('label')}, csrc digest {t.get('csrc_digest')})"
+    if t.get("csrc_digest") != kernel_source_digest():
+        return None, src + " is stale: the kernel sources changed since that PMC pass"
+    v = t.get("bytes_per_launch", {}).get(kernel)
+    return (None if v is None else float(v)), src
 
 
 def algo_bytes(kernel, esz):
@@ -127,7 +157,28 @@ def main():
                     help="BASELINE config 4's input stage: on-GPU RIR convolution + background mix ahead of the log-mel "
                          "(rir_prob 0.25, noise prob 0.5, SNR 5-20 dB: src/config/defaults.py:82-87); not the headline line")
     ap.add_argument("--rir-len", type=int, default=4000, help="RIR taps for --augment (0.25 s at 16 kHz)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as a captured HIP graph (Trainer.enable_hip_graph; not the headline line)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks from here.  Nothing in this process has touched HIP (torch is not even imported),
+        # so the children are fresh processes; rank 0's JSON line is relayed as this process's only stdout line.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        for ln in proc.stdout.splitlines():
+            if ln not in lines[-1:]:
+                print(ln, file=sys.stderr)
+        if lines:
+            print(lines[-1], flush=True)
+        raise SystemExit(proc.returncode if proc.returncode else (0 if lines else 1))
 
     import torch
     import torch.distributed as dist
@@ -135,8 +186,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with nproc-per-node {args.gpus} "
-                         f"(WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -211,19 +261,25 @@ def main():
         step(i)
     fence()
     warm = nat.prof_collect(dev)
-    # the roofline kernel is the largest class on the step's critical path (the main stream); the input stage (log-mel,
-    # waveform augmentation) runs a batch ahead on the side stream, where event timings include the time it spends
-    # sharing CUs with the conv kernels -- it is listed in kernel_ms_per_step_warmup but not eligible here
+    # the roofline kernel is the largest class on the step's critical path (the main stream).  The input stage (log-mel,
+    # waveform augmentation) runs a batch ahead on the side stream and is reported separately as roofline.side_stream:
+    # its event spans include the time it shares CUs with the conv kernels, and it is timed alone below as well.
     side = ("logmel_specaug", "audio_augment")
     main_classes = {k: v for k, v in warm.items() if k not in side}
     dominant = max(main_classes, key=lambda k: main_classes[k][0]) if main_classes else "dwconv3x3_bwd"
-    nat.prof_enable(dev, [dominant])
+
+    # the input-stage kernel alone on an idle GPU (north_star: "achieved HBM GB/s for STFT/mel")
+    nat.prof_enable(dev, ["logmel_specaug"])
+    for i in range(5):
+        trainer._features(pool[i % len(pool)][0], training=True, step=i)
+    fence()
+    alone = nat.prof_collect(dev).get("logmel_specaug", (0.0, 0))
+    nat.prof_enable(dev, [dominant, "logmel_specaug"])
 
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    t_issue = time.perf_counter() - t0                 # host time to enqueue the K steps (diagnostic: host- vs GPU-bound)
     for done in trainer._flush_pending():
         last_done[0] = done
     fence()
@@ -231,10 +287,14 @@ def main():
     dt = time.perf_counter() - t0
     prof = nat.prof_collect(dev)
     nat.prof_enable(dev, [])
+    devices = [torch.cuda.get_device_name(local_rank) + f" (cuda:{local_rank})"]
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
 
     if rank == 0:
         total = args.batch * world * args.steps
@@ -243,6 +303,17 @@ def main():
         per_launch_s = (ms / launches) * 1e-3 if launches else float("nan")
         algo = algo_bytes(dominant, esz) * args.batch
         achieved = algo / per_launch_s / 1e9 if launches else float("nan")
+        traffic, traffic_src = measured_traffic(dominant, args.batch, args.dtype)
+
+        def logmel_leg(ms_n, where):
+            if not ms_n[1]:
+                return None
+            sec = ms_n[0] / ms_n[1] * 1e-3
+            gbs = ALGO_BYTES["logmel_specaug"] * args.batch / sec / 1e9
+            tf = LOGMEL_FLOPS * args.batch / sec / 1e12
+            return {"where": where, "launch_us": round(sec * 1e6, 2), "launches_timed": ms_n[1],
+                    "achieved_GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4),
+                    "achieved_TFLOPs": round(tf, 2), "frac_valu_f32": round(tf / VALU_PEAK_TFLOPS, 4)}
         out = {
             "metric": "training samples/sec (16kHz x 1.5s clips)", "value": round(value, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -253,16 +324,27 @@ def main():
                        "activation_storage": args.dtype, "arithmetic": "f32",
                        "global_batch": args.batch * world, "n_samples": N_SAMPLES,
                        "parallelism": f"dp{world}" if world > 1 else "single",
+                       "ranks_seen": dist.get_world_size() if use_dist else 1, "devices": devices,
+                       "collective": (f"{dist.get_backend()} all-reduce (AVG) of the flat gradient bucket in 2 buckets, first "
+                                      "one under the early layers' backward") if use_dist else None,
+                       "hip_graph": bool(args.graph),
                        "last_loss": None if last is None else round(last[0], 6)},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (TRAFFIC_BYTES_B512_BF16.get(dominant) if (args.batch == 512 and args.dtype == "bf16")
-                                     else None),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": launches,
                          "algorithmic_bytes_per_launch": algo,
-                         "step_frac_of_hbm_roofline": round(value / world * step_algo_bytes(esz) / (HBM_PEAK_GBS * 1e9), 4)},
-            "host_issue_ms_per_step": round(t_issue / args.steps * 1e3, 4),
-            "kernel_ms_per_step_warmup": {k: round(v[0] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
+                         "step_frac_of_hbm_roofline": round(value / world * step_algo_bytes(esz) / (HBM_PEAK_GBS * 1e9), 4),
+                         # the input stage: NOT on the critical path (side stream, one batch ahead), far from both of its
+                         # rooflines -- latency/LDS-bound FFT; algorithmic 120 160 B and 4.41 MFLOP per clip
+                         "side_stream": {"kernel": "logmel_specaug",
+                                         "algorithmic_bytes_per_launch": ALGO_BYTES["logmel_specaug"] * args.batch,
+                                         "alone": logmel_leg(alone, "idle GPU, before the timed region"),
+                                         "in_step": logmel_leg(prof.get("logmel_specaug", (0.0, 0)),
+                                                               "timed region, sharing the CUs with the conv kernels")}},
+            # HIP-event SPANS around each class's launches during the warm-up steps (all classes on): they include queue
+            # gaps and the stretch of running beside the other stream, so they do not add up to ms_per_step
+            "event_span_ms_per_step_warmup": {k: round(v[0] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},
         }
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (bounded sample, rank 0)
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)

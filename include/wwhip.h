@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 4
+#define WW_ABI_VERSION 5
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -197,10 +197,16 @@ size_t ww_cnn_small_workspace_bytes(int B, int F, int T, int act_dtype);
 int ww_cnn_small_fwd(ww_ctx *ctx, int act_dtype, void *const *params, const float *x, int B, int F, int T, int training,
                      float bn_momentum, float bn_eps, float dropout_p, uint64_t seed, uint64_t step,
                      uint64_t sample_offset, void *ws, size_t ws_bytes, float *logits, ww_stream_t stream);
-/* must follow a training-mode ww_cnn_small_fwd on the same ws/x */
+/* must follow a training-mode ww_cnn_small_fwd on the same ws/x.  part: WW_BWD_ALL, or the backward in two calls --
+ * WW_BWD_LATE (classifier + blocks 3, 2: gradient slots 25..46) then WW_BWD_EARLY (blocks 1, 0 + stem: slots 0..24) -- so a
+ * data-parallel caller can start the all-reduce of the late layers' gradients while the early layers' backward runs
+ * (the reference is single-GPU, README.md:253-254). */
+#define WW_BWD_ALL 0
+#define WW_BWD_LATE 1
+#define WW_BWD_EARLY 2
 int ww_cnn_small_bwd(ww_ctx *ctx, int act_dtype, void *const *params, void *const *grads, const float *x, const float *dlogits,
                      int B, int F, int T, float dropout_p, uint64_t seed, uint64_t step, uint64_t sample_offset,
-                     void *ws, size_t ws_bytes, ww_stream_t stream);
+                     void *ws, size_t ws_bytes, int part, ww_stream_t stream);
 
 /* ------------------------------------------------------------------ loss + step glue
  * Replaces LabelSmoothingCrossEntropy.forward (src/models/losses.py:66-98), the eps==0
@@ -222,9 +228,12 @@ typedef struct {
                            (trainer.py:177-179) needs no host round trip before optimizer.step(). */
     int32_t reserved;
 } ww_step_stats;
+/* found_inf_out (nullable): receives stats->found_inf as a float of its own -- a data-parallel caller points it at the
+ * spare last element of its flat gradient bucket, so the all-reduce of the gradients also tells every rank that SOME rank
+ * must skip this batch (ww_clip_optim_step's found_inf_extra reads it back). */
 int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64_t *targets, int B, int loss_kind,
                         float label_smoothing, float focal_alpha, float focal_gamma, float *loss_out,
-                        float *dlogits, ww_step_stats *stats, ww_stream_t stream);
+                        float *dlogits, ww_step_stats *stats, float *found_inf_out, ww_stream_t stream);
 /* Replaces clip_gradients -> torch.nn.utils.clip_grad_norm_
  * (src/training/optimizer_factory.py:446-452) on one flat gradient bucket.  max_norm <= 0:
  * only the norm is computed.  norm_out (nullable) receives the pre-clip L2 norm.          */
@@ -330,7 +339,20 @@ typedef struct {
 int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *flat_params, float *flat_grads, float *exp_avg,
                        float *exp_avg_sq, size_t n, int64_t *step_state, int parity, float *norm_out,
                        ww_step_stats *stats /* nullable */, ww_step_stats *stats_host /* nullable */,
+                       const float *found_inf_extra /* nullable: != 0 -> skip (another rank's verdict) */,
                        ww_stream_t stream);
+
+/* ------------------------------------------------------------------ collectives: deliberately NOT in this ABI
+ * SURVEY.md §8b sketched ww_comm_init(ctx, nccl_unique_id, rank, world) / ww_allreduce_f32(ctx, buf, n, avg, comm_stream).
+ * They are waived: the exchange step of this path is ONE averaged all-reduce of the flat fp32 gradient bucket (two
+ * ranges of it, see WW_BWD_LATE/EARLY above), and the host side of the boundary is Python on PyTorch-ROCm, whose
+ * torch.distributed "nccl" backend IS RCCL over xGMI -- a second communicator owned by this library would duplicate
+ * rendezvous, stream ordering and error handling that the host already has, and would add nothing on the device side
+ * (RCCL's kernels are the collective; there is no fused reduce+clip kernel to hide behind an entry point).  What the ABI
+ * does provide for data parallelism: gradients in one contiguous bucket (`grads` table -> flat buffer), the backward in
+ * two calls so the first range can be reduced under the second, the found_inf slot that travels with the gradients
+ * (ww_ce2_loss_fwd_bwd / ww_clip_optim_step), and Philox streams addressed by GLOBAL sample index (sample_offset).
+ * The reference itself is single-GPU (README.md:253-254).                                                            */
 
 /* ------------------------------------------------------------------ measurement
  * Opt-in timing of kernel classes with hipEvents recorded on the launch stream around the

@@ -96,3 +96,51 @@ def test_two_rank_gloo_matches_ddp_emulation(tmp_path):
         # Adam turns round-off-level gradient differences (2-thread workers vs this process's conv reduction
         # order) into lr-sized (1e-3) parameter differences on near-zero-gradient weights; 2 steps => 3e-4
         np.testing.assert_allclose(w.numpy(), v.numpy(), atol=3e-4, err_msg=k)
+
+
+def _worker_bad_batch(rank, world, port, out_dir):
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import wakeword_trainer_home_amd.training.trainer as T
+    from wakeword_trainer_home_amd.config import WakewordConfig
+    from oracle.cnn_small import CNNSmallOracle
+    from oracle.train_step import TorchLoss
+    T.enforce_cuda = lambda: None
+    cfg = WakewordConfig()
+    cfg.training.epochs, cfg.optimizer.warmup_epochs, cfg.training.batch_size = 1, 0, 8
+    torch.manual_seed(100)
+    model = CNNSmallOracle(dropout=0.0)
+    x, y = _data()
+    xs, ys = x[rank * 16:(rank + 1) * 16].clone(), y[rank * 16:(rank + 1) * 16]
+    if rank == 1:
+        xs[3, 0, 2, 5] = float("nan")                   # rank 1's FIRST batch is poisoned; rank 0's is fine
+    batches = [(xs[i:i + 8], ys[i:i + 8]) for i in (0, 8)]
+    t = T.Trainer(model, batches, batches[1:], cfg, checkpoint_dir=Path(out_dir) / f"ckpt{rank}", device="cpu",
+                  criterion=TorchLoss("cross_entropy", eps=0.05))
+    done = []
+    t.add_callback(type("R", (), {"on_batch_end": lambda self, i, l, a: done.append(i)})())
+    t.train_epoch(0)
+    torch.save({"sd": model.state_dict(), "done": done, "launched": t.launched_steps, "global": t.state.global_step},
+               Path(out_dir) / f"rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_skip_is_a_global_decision(tmp_path):
+    """One rank's non-finite loss: the reference skips that batch (trainer.py:177-179).  Data parallel, EVERY rank must skip
+    it -- before the gradient all-reduce, or the healthy rank would wait in it alone (hang) or apply an update its peer did
+    not (silent divergence).  Both ranks end with identical parameters, one applied step, two launched."""
+    port = _free_port()
+    mp.start_processes(_worker_bad_batch, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
+    assert r0["done"] == [1] and r1["done"] == [1]                  # batch 0 skipped on BOTH ranks, batch 1 trained
+    assert r0["launched"] == r1["launched"] == 2 and r0["global"] == r1["global"] == 1
+    for k in r0["sd"]:
+        if "running" in k or "num_batches" in k:
+            continue
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+        assert torch.isfinite(r0["sd"][k]).all(), k

@@ -156,3 +156,73 @@ def test_generic_models_train_data_parallel(tmp_path, arch):
         if "running" in k or "num_batches" in k:
             continue
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+
+
+def _worker_bad_target(rank, world, port, out_dir, arch):
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    cfg = _cfg()
+    torch.manual_seed(50)
+    model = create_model(arch, dropout=cfg.model.dropout, dropout_seed=5)
+    wave, y = _data()
+    y = y.clone()
+    batches = [[wave[16 * s + 8 * rank:16 * s + 8 * rank + 8], y[16 * s + 8 * rank:16 * s + 8 * rank + 8].clone()] for s in range(2)]
+    if rank == 1:
+        batches[0][1][2] = 7                           # an invalid target in rank 1's FIRST batch only
+    t = Trainer(model, [tuple(b) for b in batches], [tuple(batches[1])], cfg, checkpoint_dir=Path(out_dir) / f"ck{rank}",
+                device="cuda:0")
+    done = []
+    t.add_callback(type("R", (), {"on_batch_end": lambda self, i, l, a: done.append(i)})())
+    t.train_epoch(0)
+    torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "done": done, "launched": t.launched_steps,
+                "applied": t.optimizer.step_count() if hasattr(t.optimizer, "step_count") else None},
+               Path(out_dir) / f"r{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("arch", ["cnn_small", "mobilenetv3", "crnn"])
+def test_bad_batch_on_one_rank_is_skipped_by_all(tmp_path, arch):
+    """The skip decision of the sync-free steps is per-step device state (found_inf).  It rides in the spare last element of
+    the gradient bucket through the same all-reduce, so a bad target on ONE rank (finite gradients there, because bad
+    targets are clamped) makes EVERY rank's fused optimizer skip: replicas stay identical and nothing hangs."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    port = _free_port()
+    mp.start_processes(_worker_bad_target, args=(2, port, str(tmp_path), arch), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "r1.pt", weights_only=False)
+    assert r0["done"] == [1] and r1["done"] == [1], (r0["done"], r1["done"])
+    assert r0["launched"] == r1["launched"] == 2
+    if r0["applied"] is not None:
+        assert r0["applied"] == r1["applied"] == 1     # one update applied, one skipped -- on both ranks
+    for k in r0["sd"]:
+        if "running" in k or "num_batches" in k:
+            continue
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+        assert torch.isfinite(r0["sd"][k]).all(), k
+
+
+@pytest.mark.timeout(600)
+def test_bench_one_rank_rccl_plumbing():
+    """bench.py --force-dist: the step with the RCCL process group initialised (backend nccl, ReduceOp.AVG on the two
+    gradient buckets, the found_inf slot) on the one GPU of this box -- the code path the driver's 2/4/8-GPU runs take."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--force-dist", "--steps", "4", "--warmup", "2", "--batch", "64",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=540)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                                   # stdout carries exactly ONE JSON line
+    out = json.loads(lines[0])
+    assert out["config"]["ranks_seen"] == 1 and out["config"]["collective"].startswith("nccl")
+    assert out["value"] > 0 and np.isfinite(out["config"]["last_loss"])

@@ -89,7 +89,8 @@ def test_trainer_reproduces_reference_trace_on_cpu(golden_dir, tmp_path, no_gpu_
     # checkpoints: same files, same key set, same TrainingState fields (G5)
     assert sorted(p.name for p in tmp_path.iterdir()) == meta["files"]
     ck = torch.load(tmp_path / "best_model.pt", map_location="cpu", weights_only=False)
-    assert sorted(ck.keys()) == meta["ckpt_keys"]
+    # the reference's key set plus the build's one documented extension (the Philox launched-step counter)
+    assert sorted(set(ck.keys()) - {"launched_steps"}) == meta["ckpt_keys"] and "launched_steps" in ck
     assert sorted(vars(ck["state"]).keys()) == meta["state_fields"]
     # final parameters equal the reference run's.  Adam divides by sqrt(v): on weights whose gradient is at
     # round-off level, a 1e-9 difference in the gradient (oracle focal restatement vs the reference's
@@ -351,3 +352,21 @@ def test_flat_buckets_mixin_on_cpu():
     assert twin.a.weight.data_ptr() == twin.flat_param.data_ptr() and torch.equal(twin.flat_param, net.flat_param)
     with pytest.raises(ValueError, match="float32"):
         Net().double().flat_param
+
+
+def test_bench_self_launch_spawns_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus 2` without a launcher starts its own ranks (torch.distributed.run children).  Here, without
+    a GPU, each child must refuse loudly (no CPU fallback) and the parent must relay the failure: non-zero exit, nothing on
+    stdout -- never a JSON line from a path that did not run the HIP kernels."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check of the launcher")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "needs an MI355X" in r.stderr

@@ -13,7 +13,8 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 4
+ABI_VERSION = 5
+BWD_ALL, BWD_LATE, BWD_EARLY = 0, 1, 2
 ACT_F32, ACT_BF16 = 0, 1
 LOSS_CE, LOSS_FOCAL = 0, 1
 WAVE_F32, WAVE_I16 = 0, 1
@@ -102,7 +103,7 @@ _SIGS = {
     "ww_gru_fwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_long, _vp, _vp, _sz, _vp]),
     "ww_gru_bwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, C.c_long, _i,
                              _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp]),
+    "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ww_layer_scratch_bytes": (_sz, []),
     "ww_conv_stem_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
     "ww_dwconv3x3_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
@@ -120,8 +121,8 @@ _SIGS = {
     "ww_cnn_front_fwd": (C.c_int, [_vp, _i, C.POINTER(_vp), _vp, _i, _i, _i, _i, _f, _f, _vp, _sz, _vp, _vp]),
     "ww_cnn_front_bwd": (C.c_int, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "ww_cnn_small_bwd": (C.c_int, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i, _i, _i, _f, _u64, _u64, _u64,
-                                   _vp, _sz, _vp]),
-    "ww_ce2_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
+                                   _vp, _sz, _i, _vp]),
+    "ww_ce2_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ww_grad_norm_clip": (C.c_int, [_vp, _vp, _sz, _f, _vp, _vp, _vp]),
     "ww_prof_num_classes": (C.c_int, []),
     "ww_prof_class_name": (C.c_char_p, [_i]),
@@ -590,10 +591,11 @@ def gru_bwd(x, w_ih, w_hh, dy, dh_n, ws, reverse=False, dx=None, accumulate_dx=F
 
 
 def clip_optim_step_(cfg: OptimCfg, flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, parity, norm_out=None,
-                     stats=None, stats_host=None):
+                     stats=None, stats_host=None, found_inf_extra=None):
     """In place: clip flat_grads to cfg.max_norm, then one Adam/AdamW/SGD step on flat_params (skipped on found_inf).
-    ``stats_host``: pinned uint8[48] host tensor the kernel copies the step's ww_step_stats into."""
-    dev = _dev(flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, norm_out, stats)
+    ``stats_host``: pinned uint8[48] host tensor the kernel copies the step's ww_step_stats into.
+    ``found_inf_extra``: float32[1] device tensor; non-zero also skips the step (data parallel: some rank's bad batch)."""
+    dev = _dev(flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, norm_out, stats, found_inf_extra)
     if stats_host is not None and not (stats_host.is_pinned() and stats_host.numel() * stats_host.element_size() >= STEP_STATS_BYTES):
         raise ValueError("stats_host must be a pinned host tensor of at least 48 bytes")
     if flat_params.dtype != torch.float32 or flat_grads.dtype != torch.float32 or flat_params.numel() != flat_grads.numel():
@@ -603,8 +605,8 @@ def clip_optim_step_(cfg: OptimCfg, flat_params, flat_grads, exp_avg, exp_avg_sq
     with _guard(dev):
         _check(load().ww_clip_optim_step(ctx(dev), C.byref(cfg), _p(flat_params), _p(flat_grads), _p(exp_avg), _p(exp_avg_sq),
                                          flat_params.numel(), _p(step_state), parity, _p(norm_out), _p(stats),
-                                         None if stats_host is None else C.c_void_p(stats_host.data_ptr()), _stream(dev)),
-               "ww_clip_optim_step")
+                                         None if stats_host is None else C.c_void_p(stats_host.data_ptr()),
+                                         _p(found_inf_extra), _stream(dev)), "ww_clip_optim_step")
 
 
 def layer_scratch(dev):
@@ -743,12 +745,13 @@ def cnn_small_fwd(params, x, ws, logits, training, bn_momentum=0.1, bn_eps=1e-5,
                                        _stream(dev)), "ww_cnn_small_fwd")
 
 
-def cnn_small_bwd(params, grads, x, dlogits, ws, dropout_p=0.0, seed=0, step=0, sample_offset=0, act=ACT_F32):
+def cnn_small_bwd(params, grads, x, dlogits, ws, dropout_p=0.0, seed=0, step=0, sample_offset=0, act=ACT_F32,
+                  part=BWD_ALL):
     dev = _dev(x, ws, dlogits)
     B, F, T = x.shape[0], x.shape[-2], x.shape[-1]
     with _guard(dev):
         _check(load().ww_cnn_small_bwd(ctx(dev), act, params, grads, _p(x), _p(dlogits), B, F, T, dropout_p, seed, step,
-                                       sample_offset, _p(ws), ws.numel() * ws.element_size(), _stream(dev)),
+                                       sample_offset, _p(ws), ws.numel() * ws.element_size(), part, _stream(dev)),
                "ww_cnn_small_bwd")
 
 
@@ -769,9 +772,10 @@ def cnn_front_bwd(params, grads, x, dseq, ws, act=ACT_F32):
 
 
 def ce2_loss_fwd_bwd(logits, targets, kind=LOSS_CE, label_smoothing=0.0, focal_alpha=0.25, focal_gamma=2.0,
-                     stats=None):
-    """-> (loss (1,) f32, dlogits (B,2) f32, stats uint8[STEP_STATS_BYTES])."""
-    dev = _dev(logits, targets, stats)
+                     stats=None, found_inf_out=None):
+    """-> (loss (1,) f32, dlogits (B,2) f32, stats uint8[STEP_STATS_BYTES]).  ``found_inf_out``: float32[1] device tensor
+    that also receives the step's found_inf flag (the spare slot of a data-parallel gradient bucket)."""
+    dev = _dev(logits, targets, stats, found_inf_out)
     if logits.dim() != 2 or logits.shape[1] != 2 or logits.dtype != torch.float32:
         raise ValueError(f"native loss needs float32 logits of shape (B,2), got {logits.dtype} {tuple(logits.shape)}")
     if targets.dim() != 1 or targets.shape[0] != logits.shape[0] or targets.dtype != torch.int64:
@@ -783,7 +787,7 @@ def ce2_loss_fwd_bwd(logits, targets, kind=LOSS_CE, label_smoothing=0.0, focal_a
         stats = torch.zeros(STEP_STATS_BYTES, dtype=torch.uint8, device=dev)
     with _guard(dev):
         _check(load().ww_ce2_loss_fwd_bwd(ctx(dev), _p(logits), _p(targets), B, kind, label_smoothing, focal_alpha,
-                                          focal_gamma, _p(loss), _p(dl), _p(stats), _stream(dev)),
+                                          focal_gamma, _p(loss), _p(dl), _p(stats), _p(found_inf_out), _stream(dev)),
                "ww_ce2_loss_fwd_bwd")
     return loss, dl, stats
 

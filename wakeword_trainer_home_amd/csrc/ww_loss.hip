@@ -12,7 +12,7 @@ namespace {
 __global__ __launch_bounds__(1024) void k_ce2_loss(const float *__restrict__ logits, const int64_t *__restrict__ targets,
                                                    int B, int kind, float eps, float alpha, float gamma,
                                                    float *__restrict__ loss_out, float *__restrict__ dlogits,
-                                                   ww_step_stats *__restrict__ stats) {
+                                                   ww_step_stats *__restrict__ stats, float *__restrict__ found_inf_out) {
     __shared__ double shl[1024];
     __shared__ int shc[6][1024];
     const float invB = 1.0f / (float)B;
@@ -80,6 +80,9 @@ __global__ __launch_bounds__(1024) void k_ce2_loss(const float *__restrict__ log
     if (threadIdx.x == 0) {
         const float loss = (float)(shl[0] / (double)B);
         if (loss_out) *loss_out = loss;
+        // data parallel: the skip decision travels with the gradients (one extra float at the end of the flat bucket that the
+        // all-reduce sums), so every rank skips the step when any rank saw a bad batch
+        if (found_inf_out) *found_inf_out = (!isfinite(loss) || shc[5][0]) ? 1.0f : 0.0f;
         if (stats) {
             stats->loss = loss;
             stats->correct = shc[0][0]; stats->tp = shc[1][0]; stats->tn = shc[2][0];
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(1024) void k_ce2_loss(const float *__restrict__ log
 
 extern "C" int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64_t *targets, int B, int loss_kind,
                                    float label_smoothing, float focal_alpha, float focal_gamma, float *loss_out,
-                                   float *dlogits, ww_step_stats *stats, ww_stream_t stream) {
+                                   float *dlogits, ww_step_stats *stats, float *found_inf_out, ww_stream_t stream) {
     WW_REQUIRE(ctx && logits && targets && dlogits, WW_E_INVALID, "ww_ce2_loss_fwd_bwd: null argument");
     WW_REQUIRE(B >= 1, WW_E_INVALID, "ww_ce2_loss_fwd_bwd: B=%d", B);
     WW_REQUIRE(loss_kind == WW_LOSS_CE || loss_kind == WW_LOSS_FOCAL, WW_E_INVALID,
@@ -110,7 +113,7 @@ extern "C" int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64
     WW_REQUIRE(focal_gamma >= 0.f, WW_E_INVALID, "Gamma must be non-negative, got %g", focal_gamma);
     ww_prof_scope ps_(ctx, WW_K_HEAD_LOSS, (hipStream_t)stream);
     hipLaunchKernelGGL(k_ce2_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, targets, B, loss_kind,
-                       label_smoothing, focal_alpha, focal_gamma, loss_out, dlogits, stats);
+                       label_smoothing, focal_alpha, focal_gamma, loss_out, dlogits, stats, found_inf_out);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

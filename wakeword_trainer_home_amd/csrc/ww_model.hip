@@ -93,14 +93,18 @@ int conv_stack_fwd(ww_ctx *ctx, int act_dtype, void *const *params, const float 
 
 // backward of the conv stack.  from_pool: layer 8's dL/dz is synthesised from the pooled gradient (cnn_small's GAP head);
 // otherwise it has been written to g[0] together with coef[8] (the CRNN's frequency pooling)
+// part: WW_BWD_ALL, or WW_BWD_LATE (blocks 3, 2) / WW_BWD_EARLY (blocks 1, 0 and the stem) -- the two halves of a
+// data-parallel step whose first gradient bucket is all-reduced while the second half runs
 int conv_stack_bwd(ww_ctx *ctx, int act_dtype, void *const *params, void *const *grads, const float *x, int B, int F, int T,
-                   const Layout &L, char *w, bool from_pool, ww_stream_t stream) {
+                   const Layout &L, char *w, bool from_pool, ww_stream_t stream, int part = WW_BWD_ALL) {
     auto Fp = [&](size_t off) { return (float *)(w + off); };
     auto G = [&](int i) { return (float *)grads[i]; };
     void *scratch = w + L.scratch;
     int rc;
-    int cur = 0;  // g[cur] holds dL/dz of the layer about to be processed (unused for layer 8 when from_pool)
-    for (int i = 3; i >= 0; --i) {
+    const int i_hi = part == WW_BWD_EARLY ? 1 : 3, i_lo = part == WW_BWD_LATE ? 2 : 0;
+    // g[cur] holds dL/dz of the layer about to be processed (unused for layer 8 when from_pool); every block flips it twice
+    int cur = (from_pool && i_hi != 3) ? 1 : 0;
+    for (int i = i_hi; i >= i_lo; --i) {
         const int ld = 1 + 2 * i, lp = 2 + 2 * i;
         const bool pooled = from_pool && lp == 8;
         const void *gp = pooled ? nullptr : w + L.g[cur];
@@ -119,6 +123,7 @@ int conv_stack_bwd(ww_ctx *ctx, int act_dtype, void *const *params, void *const 
         if (rc) return rc;
         cur ^= 1;
     }
+    if (part == WW_BWD_LATE) return WW_OK;
     return ww_stem_bwd_impl(ctx, act_dtype, w + L.g[cur], w + L.y[0], (const float *)params[0], Fp(L.coef[0]), x, B, F, T, G(0),
                             scratch, stream);
 }
@@ -213,10 +218,12 @@ extern "C" int ww_cnn_small_fwd(ww_ctx *ctx, int act_dtype, void *const *params,
 
 extern "C" int ww_cnn_small_bwd(ww_ctx *ctx, int act_dtype, void *const *params, void *const *grads, const float *x,
                                 const float *dlogits, int B, int F, int T, float dropout_p, uint64_t seed, uint64_t step,
-                                uint64_t sample_offset, void *ws, size_t ws_bytes, ww_stream_t stream) {
+                                uint64_t sample_offset, void *ws, size_t ws_bytes, int part, ww_stream_t stream) {
     int rc = check_common("ww_cnn_small_bwd", ctx, act_dtype, params, x, B, F, T, ws, ws_bytes);
     if (rc) return rc;
     WW_REQUIRE(grads && dlogits, WW_E_INVALID, "ww_cnn_small_bwd: null argument");
+    WW_REQUIRE(part == WW_BWD_ALL || part == WW_BWD_LATE || part == WW_BWD_EARLY, WW_E_INVALID,
+               "ww_cnn_small_bwd: unknown part %d", part);
     const Layout L = make_layout(B, F, T, act_dtype);
     char *w = (char *)ws;
     auto Fp = [&](size_t off) { return (float *)(w + off); };
@@ -227,11 +234,13 @@ extern "C" int ww_cnn_small_bwd(ww_ctx *ctx, int act_dtype, void *const *params,
     }
     WW_REQUIRE(grads[45] && grads[46], WW_E_INVALID, "ww_cnn_small_bwd: missing classifier gradient buffers");
     const int HW = L.Ho * L.Wo;
-    rc = ww_head_bwd(ctx, dlogits, Fp(L.pd), Fp(L.pool), B, HW, (const float *)params[45], dropout_p, 1, seed, step,
-                     sample_offset, (const float *)params[bnidx(8)], Fp(L.mr[8]), G(45), G(46), Fp(L.dpool),
-                     Fp(L.coef[8]), G(bnidx(8)), G(bnidx(8) + 1), stream);
-    if (rc) return rc;
-    return conv_stack_bwd(ctx, act_dtype, params, grads, x, B, F, T, L, w, /*from_pool=*/true, stream);
+    if (part != WW_BWD_EARLY) {
+        rc = ww_head_bwd(ctx, dlogits, Fp(L.pd), Fp(L.pool), B, HW, (const float *)params[45], dropout_p, 1, seed, step,
+                         sample_offset, (const float *)params[bnidx(8)], Fp(L.mr[8]), G(45), G(46), Fp(L.dpool),
+                         Fp(L.coef[8]), G(bnidx(8)), G(bnidx(8) + 1), stream);
+        if (rc) return rc;
+    }
+    return conv_stack_bwd(ctx, act_dtype, params, grads, x, B, F, T, L, w, /*from_pool=*/true, stream, part);
 }
 
 // ------------------------------------------------------------------ conv front-end of the CRNN

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(1024) void k_clip_optim_small(OptimArgs a, float *_
                                                            float *__restrict__ m, float *__restrict__ v, size_t n,
                                                            long long *__restrict__ step_state, int parity,
                                                            float *__restrict__ norm_out, ww_step_stats *__restrict__ stats,
-                                                           ww_step_stats *__restrict__ stats_host) {
+                                                           ww_step_stats *__restrict__ stats_host,
+                                                           const float *__restrict__ found_inf_extra) {
     __shared__ double sh[1024];
     __shared__ float coef_sh, ss_sh, bc_sh;
     __shared__ int skip_sh;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(1024) void k_clip_optim_small(OptimArgs a, float *_
     if (threadIdx.x == 0) {
         const float norm = (float)sqrt(sh[0]);
         if (norm_out) *norm_out = norm;
-        bool skip = !isfinite(norm);
+        bool skip = !isfinite(norm) || (found_inf_extra && *found_inf_extra != 0.0f);   // extra: another rank's bad batch
         if (stats) {
             stats->grad_norm = norm;
             if (skip) stats->found_inf = 1.0f;
@@ -124,11 +125,13 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
                                                       long long *__restrict__ step_state, int parity,
                                                       const double *__restrict__ parts, int nparts,
                                                       float *__restrict__ norm_out, ww_step_stats *__restrict__ stats,
-                                                      ww_step_stats *__restrict__ stats_host) {
+                                                      ww_step_stats *__restrict__ stats_host,
+                                                      const float *__restrict__ found_inf_extra) {
     double t = 0.0;
     for (int i = 0; i < nparts; ++i) t += parts[i];
     const float norm = (float)sqrt(t);
-    const bool skip = (stats && stats->found_inf != 0.0f) || !isfinite(norm);
+    const bool extra = found_inf_extra && *found_inf_extra != 0.0f;
+    const bool skip = (stats && stats->found_inf != 0.0f) || !isfinite(norm) || extra;
     const long long t0 = step_state[parity];
     const bool clip = a.max_norm > 0.f;
     float c = 1.f;
@@ -141,11 +144,11 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
         if (norm_out) *norm_out = norm;
         if (stats) {
             stats->grad_norm = norm;
-            if (!isfinite(norm)) stats->found_inf = 1.0f;
+            if (!isfinite(norm) || extra) stats->found_inf = 1.0f;
             if (stats_host) {
                 ww_step_stats s = *stats;
                 s.grad_norm = norm;
-                if (!isfinite(norm)) s.found_inf = 1.0f;
+                if (!isfinite(norm) || extra) s.found_inf = 1.0f;
                 *stats_host = s;
             }
         }
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
 extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *flat_params, float *flat_grads,
                                   float *exp_avg, float *exp_avg_sq, size_t n, int64_t *step_state, int parity,
                                   float *norm_out, ww_step_stats *stats, ww_step_stats *stats_host,
-                                  ww_stream_t stream) {
+                                  const float *found_inf_extra, ww_stream_t stream) {
     WW_REQUIRE(ctx && cfg && flat_params && flat_grads && step_state, WW_E_INVALID, "ww_clip_optim_step: null argument");
     ww_step_stats *stats_host_dev = nullptr;
     if (stats_host) {
@@ -196,7 +199,7 @@ extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *f
     if (n <= (size_t)OPT_EPT * 1024) {
         ww_prof_scope ps_(ctx, WW_K_CLIP, st);
         hipLaunchKernelGGL(k_clip_optim_small, dim3(1), dim3(1024), 0, st, a, flat_params, flat_grads, exp_avg, exp_avg_sq,
-                           n, (long long *)step_state, parity, norm_out, stats, stats_host_dev);
+                           n, (long long *)step_state, parity, norm_out, stats, stats_host_dev, found_inf_extra);
         WW_LAUNCH_CHECK();
         return WW_OK;
     }
@@ -206,7 +209,7 @@ extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *f
     if (rc) return rc;
     const int grid = (int)std::min<size_t>((n + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(k_optim_update, dim3(grid), dim3(256), 0, st, a, flat_params, flat_grads, exp_avg, exp_avg_sq, n,
-                       (long long *)step_state, parity, ctx->norm_partials, parts, norm_out, stats, stats_host_dev);
+                       (long long *)step_state, parity, ctx->norm_partials, parts, norm_out, stats, stats_host_dev, found_inf_extra);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

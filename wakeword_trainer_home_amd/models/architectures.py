@@ -119,6 +119,8 @@ class CNNSmallWakeword(nn.Module):
         self._pptr = None
         self._gptr = None
         self._flat_grad = None
+        self._flat_grad_ext = None
+        self._late_offset = 0
         self._flat_param = None
         self._grad_views = None
         self._ws = {}
@@ -162,9 +164,15 @@ class CNNSmallWakeword(nn.Module):
         # no alignment padding: EVERY element of the bucket is rewritten by each backward, so a non-finite step
         # (clip multiplies by NaN) cannot leave poison behind in never-written slots
         sizes = [t.numel() for t in self._plist]
-        self._flat_grad = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        # one spare float behind the gradients: the data-parallel found_inf flag (written by the loss kernel, summed by the
+        # same all-reduce as the gradients, read by the fused optimizer) -- see Trainer._step_native
+        self._flat_grad_ext = torch.zeros(sum(sizes) + 1, dtype=torch.float32, device=dev)
+        self._flat_grad = self._flat_grad_ext[:-1]
         views, off = {}, 0
+        self._late_offset = 0
         for t, n in zip(self._plist, sizes):
+            if self.N_BLOCKS >= 3 and t is self.blocks[2].dw.weight:
+                self._late_offset = off              # first gradient written by the WW_BWD_LATE half of the backward
             views[id(t)] = self._flat_grad[off:off + t.numel()].view_as(t)
             off += n
         self._grad_views = views
@@ -186,6 +194,16 @@ class CNNSmallWakeword(nn.Module):
     def flat_grad(self):
         """The one flat fp32 gradient bucket (all-reduce / clip operate on it)."""
         return self._flat_grad
+
+    @property
+    def flat_grad_ext(self):
+        """``flat_grad`` plus one trailing float, the data-parallel found_inf slot (``flat_grad_ext[-1:]``)."""
+        return self._flat_grad_ext
+
+    @property
+    def late_offset(self) -> int:
+        """``flat_grad[late_offset:]`` = gradients of blocks 2, 3 and the classifier (complete after WW_BWD_LATE)."""
+        return self._late_offset
 
     def set_act_dtype(self, act_dtype):
         """'fp32' (parity mode) or 'bf16' (half the HBM traffic; fp32 arithmetic and statistics)."""
@@ -232,8 +250,18 @@ class CNNSmallWakeword(nn.Module):
             self._pending_tracked += 1
         return logits, slot, step
 
-    def _launch_backward(self, x, dlogits, slot, step):
+    def _launch_backward(self, x, dlogits, slot, step, mid_hook=None):
         fresh = all(p.grad is None for p in self._plist)
+        if fresh and mid_hook is not None:      # two halves; the caller starts reducing the late layers' gradients between them
+            for part in (nat.BWD_LATE, nat.BWD_EARLY):
+                nat.cnn_small_bwd(self._pptr, self._gptr, x, dlogits.contiguous(), slot["buf"], dropout_p=self.p,
+                                  seed=self.dropout_seed, step=step, sample_offset=self.sample_offset, act=self.act, part=part)
+                if part == nat.BWD_LATE:
+                    mid_hook()
+            slot["busy"] = False
+            for p in self._plist:
+                p.grad = self._grad_views[id(p)]
+            return
         if fresh:
             gptr = self._gptr
         else:                                   # accumulate into existing .grad tensors
@@ -289,10 +317,12 @@ class CNNSmallWakeword(nn.Module):
             else:
                 p.grad.add_(views[id(p)])
 
-    def train_step_native(self, x: torch.Tensor, targets: torch.Tensor, criterion):
+    def train_step_native(self, x: torch.Tensor, targets: torch.Tensor, criterion, mid_hook=None, found_inf_out=None):
         """forward -> native loss -> backward as three C-ABI calls, without the autograd engine (what Trainer's native step
         uses: the loss kernel already returns dL/dlogits, so nothing needs recording).  Gradients land in the flat bucket
-        exactly as after ``criterion(model(x), targets).backward()``; returns the device ``ww_step_stats`` tensor."""
+        exactly as after ``criterion(model(x), targets).backward()``; returns the device ``ww_step_stats`` tensor.
+        Data parallel: ``mid_hook()`` is called once ``flat_grad[late_offset:]`` is complete (the backward then runs as two
+        C-ABI calls); ``found_inf_out`` (float32[1]) also receives the loss kernel's skip flag."""
         x = self._check_input(x)
         if not self.training:
             raise RuntimeError("train_step_native() needs model.train()")
@@ -300,8 +330,8 @@ class CNNSmallWakeword(nn.Module):
             raise RuntimeError("train_step_native() writes fresh gradients: call optimizer.zero_grad(set_to_none=True) first")
         self._prepare(x.device)
         logits, slot, step = self._launch_forward(x, training=True)
-        stats, dlogits = criterion.native_fwd_bwd(logits, targets)
-        self._launch_backward(x, dlogits, slot, step)
+        stats, dlogits = criterion.native_fwd_bwd(logits, targets, found_inf_out=found_inf_out)
+        self._launch_backward(x, dlogits, slot, step, mid_hook=mid_hook)
         return stats
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -14,12 +14,13 @@ class FlatBuckets:
 
     _fb_param = None
     _fb_grad = None
+    _fb_grad_ext = None
     _fb_plist = None
     _fb_views = None
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
-        self._fb_param = self._fb_grad = self._fb_plist = self._fb_views = None
+        self._fb_param = self._fb_grad = self._fb_grad_ext = self._fb_plist = self._fb_views = None
         return r
 
     def _fb_build(self):
@@ -39,7 +40,9 @@ class FlatBuckets:
                 t.data = view                       # state_dict() / load_state_dict() go through the views
                 off += t.numel()
         self._fb_param, self._fb_plist = flat, plist
-        self._fb_grad = torch.zeros_like(flat)
+        # one spare float behind the gradients: the data-parallel found_inf slot (see CNNSmallWakeword._prepare)
+        self._fb_grad_ext = torch.zeros(flat.numel() + 1, dtype=torch.float32, device=dev)
+        self._fb_grad = self._fb_grad_ext[:-1]
         views, off = [], 0
         for t in plist:
             views.append(self._fb_grad[off:off + t.numel()].view_as(t))
@@ -60,6 +63,12 @@ class FlatBuckets:
     def flat_grad(self):
         self._fb_ready()
         return self._fb_grad
+
+    @property
+    def flat_grad_ext(self):
+        """``flat_grad`` plus the trailing data-parallel found_inf slot."""
+        self._fb_ready()
+        return self._fb_grad_ext
 
     def grads_in_bucket(self) -> bool:
         """autograd hands every parameter a fresh gradient tensor: they are gathered (``gather_grads``), never in place."""

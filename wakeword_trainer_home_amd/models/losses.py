@@ -15,7 +15,8 @@ class _CE2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets, mod):
         loss, dl, stats = nat.ce2_loss_fwd_bwd(logits.contiguous(), targets.contiguous(), mod._kind, mod._eps,
-                                               mod._alpha, mod._gamma, stats=mod._stats_for(logits.device))
+                                               mod._alpha, mod._gamma, stats=mod._stats_for(logits.device),
+                                               found_inf_out=mod.found_inf_out)
         mod.last_stats = stats
         ctx.save_for_backward(dl)
         return loss.reshape(())
@@ -39,7 +40,8 @@ class _NativeLoss(nn.Module):
             raise ValueError(f"the HIP loss kernel implements reduction='mean', got {reduction!r}")
         self.weight, self.reduction = weight, reduction
         self.validate_targets = True      # reference behaviour: raise at once (costs a host sync)
-        self.last_stats = None            # device uint8[40] = ww_step_stats of the last call
+        self.last_stats = None            # device uint8[48] = ww_step_stats of the last call
+        self.found_inf_out = None         # float32[1] device tensor that also receives found_inf (data-parallel bucket slot)
         self._stats = {}
 
     def _stats_for(self, dev):
@@ -47,13 +49,14 @@ class _NativeLoss(nn.Module):
             self._stats[dev] = torch.zeros(nat.STEP_STATS_BYTES, dtype=torch.uint8, device=dev)
         return self._stats[dev]
 
-    def native_fwd_bwd(self, logits: torch.Tensor, target: torch.Tensor):
+    def native_fwd_bwd(self, logits: torch.Tensor, target: torch.Tensor, found_inf_out=None):
         """Loss kernel without autograd: -> (device ww_step_stats, dL/dlogits).  Target range errors are reported through
         ``stats.bad_target`` (the caller reads the stats once per step)."""
         if logits.dim() != 2 or logits.size(1) != 2 or target.dim() != 1 or logits.size(0) != target.size(0):
             raise ValueError(f"expected logits (B,2) and targets (B,), got {tuple(logits.shape)} and {tuple(target.shape)}")
         _, dl, stats = nat.ce2_loss_fwd_bwd(logits.contiguous(), target.long().contiguous(), self._kind, self._eps,
-                                            self._alpha, self._gamma, stats=self._stats_for(logits.device))
+                                            self._alpha, self._gamma, stats=self._stats_for(logits.device),
+                                            found_inf_out=found_inf_out)
         self.last_stats = stats
         return stats, dl
 

@@ -61,6 +61,15 @@ class TrainingState:
     training_time: float = 0.0
 
 
+def _checkpoint_safe_globals():
+    """Classes a checkpoint may contain besides tensors and plain containers (trainer.py:493-494 pickles both)."""
+    import collections
+    from ..config import defaults
+    import dataclasses
+    cfg_classes = [v for v in vars(defaults).values() if isinstance(v, type) and dataclasses.is_dataclass(v)]
+    return [TrainingState, collections.OrderedDict, collections.defaultdict, dict] + cfg_classes
+
+
 _HISTORY_KEYS = ("train_loss", "train_acc", "val_loss", "val_acc", "val_f1", "val_fpr", "val_fnr", "learning_rates")
 _SAVE_EVERY = {"every_epoch": 1, "every_5_epochs": 5, "every_10_epochs": 10}
 
@@ -97,7 +106,11 @@ class Trainer:
         self.train_metrics_tracker = MetricsTracker(device=device)
         self.val_metrics_tracker = MetricsTracker(device=device)
         self.metric_monitor = MetricMonitor(window_size=100)
-        self.state = TrainingState()
+        self.state = TrainingState()               # the reference's fields, nothing added (checkpoint schema, trainer.py:33-41)
+        # every LAUNCHED training batch, skipped or not: the counter of all Philox streams (SpecAugment, audio augmentation,
+        # dropout), so a skipped batch never makes later batches reuse its masks; saved as the checkpoint's one extra key
+        # so a resumed run continues the streams (state.global_step counts only batches that reported a result, :208)
+        self.launched_steps = 0
         self.early_stopping_patience = config.training.early_stopping_patience
         self.checkpoint_dir = Path(checkpoint_dir) if checkpoint_dir is not None else Path("checkpoints")
         self.checkpoint_dir.mkdir(parents=True, exist_ok=True)
@@ -130,6 +143,8 @@ class Trainer:
         self.deferred_metrics = (bool(getattr(config.training, "deferred_metrics", True))
                                  and (self.native or self._async_autograd) and self._native_loss and self._skip_on_device)
         self._pending = None
+        self._dropout_modules = [m for m in self.model.modules() if hasattr(m, "dropout_step")]
+        self._dp_voted = False             # the ranks agreed to skip the current batch (reference-style step only)
         self._dp_pack = None               # (key, flat buffer, views) of the packed gradient all-reduce
         self._host_bufs, self._buf_i = None, 0
         self._in_stream = None
@@ -186,43 +201,93 @@ class Trainer:
         torch.cuda.current_stream(stats.device).synchronize()
         return nat.decode_stats(self._stats_host)
 
+    # ------------------------------------------------------------------------------- data parallel
+    def _reduce_start(self, t: torch.Tensor):
+        """Start averaging ``t`` over the ranks.  RCCL: asynchronous on the process group's stream -- it waits for what
+        the current stream has queued so far and runs beside whatever is queued next (the rest of the backward)."""
+        if self._dist.get_backend() == "nccl":
+            return self._dist.all_reduce(t, op=self._dist.ReduceOp.AVG, async_op=True), None
+        return self._dist.all_reduce(t, async_op=True), t           # gloo (CPU tests) has no AVG
+
+    def _reduce_finish(self, handles):
+        """The current stream (RCCL) / the host (gloo) waits for the started reductions."""
+        for work, t in handles:
+            work.wait()
+            if t is not None:
+                t.div_(self.world_size)
+
+    def _pack_buffer(self):
+        """Persistent flat fp32 buffer for the gradients of a model without buckets of its own, plus the found_inf slot."""
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        key = tuple(p.numel() for p in params) + (params[0].device, params[0].dtype)
+        if self._dp_pack is None or self._dp_pack[0] != key:
+            buf = torch.zeros(sum(key[:-2]) + 1, dtype=params[0].dtype, device=params[0].device)
+            views, off = [], 0
+            for p in params:
+                views.append(buf[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self._dp_pack = (key, buf, views)
+        return self._dp_pack[1], self._dp_pack[2], params
+
+    def _dp_flag_slot(self):
+        """float32[1] device view that travels with the gradients through the all-reduce: any rank's found_inf."""
+        if not self._dist or torch.device(self.device).type != "cuda":
+            return None
+        if hasattr(self.model, "flat_grad_ext"):
+            if self.native:
+                self.model._prepare(torch.device(self.device))
+            return self.model.flat_grad_ext[-1:]
+        return self._pack_buffer()[0][-1:]
+
     def _allreduce_grads(self):
-        """Average the gradients over the ranks with ONE collective: the native model's flat bucket as it is, any other
+        """Average the gradients over the ranks with ONE collective: a bucketed model's flat bucket as it is, any other
         model's gradients packed into a persistent flat buffer (two multi-tensor copies around the all-reduce instead of
-        one latency-bound collective per parameter tensor -- 45 of them for the CRNN)."""
+        one latency-bound collective per parameter tensor -- 45 of them for the CRNN).  The buffer's last element is the
+        found_inf slot (``_dp_flag_slot``), so the skip decision is reduced with the gradients."""
         if not self._dist:
             return
-        if self.native:
-            flat, grads = self.model.flat_grad, None
-        else:
-            grads = [p.grad for p in self.model.parameters() if p.grad is not None]
-            if not grads:
-                return
-            if len(grads) == 1:
-                flat, grads = grads[0], None
-            else:
-                key = tuple(g.numel() for g in grads) + (grads[0].device, grads[0].dtype)
-                if self._dp_pack is None or self._dp_pack[0] != key:
-                    buf = torch.empty(sum(key[:-2]), dtype=grads[0].dtype, device=grads[0].device)
-                    views, off = [], 0
-                    for g in grads:
-                        views.append(buf[off:off + g.numel()].view_as(g))
-                        off += g.numel()
-                    self._dp_pack = (key, buf, views)
-                _, flat, views = self._dp_pack
-                torch._foreach_copy_(views, grads)
-        if self._dist.get_backend() == "nccl":
-            self._dist.all_reduce(flat, op=self._dist.ReduceOp.AVG)      # RCCL averages in-kernel
-        else:                                                            # gloo (CPU tests) has no AVG
-            self._dist.all_reduce(flat)
-            flat.div_(self.world_size)
-        if grads is not None:
-            torch._foreach_copy_(grads, self._dp_pack[2])
+        if hasattr(self.model, "flat_grad_ext") and self.model.flat_grad_ext is not None and (
+                self.native or not any(p.grad is None for p in self.model.parameters())):
+            if not self.native:
+                self.model.gather_grads()
+            self._reduce_finish([self._reduce_start(self.model.flat_grad_ext)])
+            return
+        buf, views, params = self._pack_buffer()
+        have = [(v, p.grad) for v, p in zip(views, params) if p.grad is not None]
+        if not have:
+            return
+        missing = [v for v, p in zip(views, params) if p.grad is None]
+        if missing:
+            torch._foreach_zero_(missing)
+        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        self._reduce_finish([self._reduce_start(buf)])
+        torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
+
+    def _vote_skip(self, bad: bool) -> bool:
+        """Reference-style step in data-parallel mode: the ranks agree BEFORE the gradient all-reduce whether this batch is
+        skipped (a non-finite loss or an exception in the forward pass on one rank), so no rank is left waiting in a
+        collective its peers never enter."""
+        if not self._dist:
+            return bad
+        dev = self.device if torch.device(self.device).type == "cuda" else "cpu"
+        flag = torch.tensor([1.0 if bad else 0.0], device=dev)
+        self._dist.all_reduce(flag, op=self._dist.ReduceOp.MAX)
+        return bool(flag.item() > 0)
 
     # ------------------------------------------------------------------------------- inner steps
     def _launch_step_index(self) -> int:
-        """Counter of the Philox streams (SpecAugment): the index of the step being launched."""
-        return self.state.global_step + (1 if self._pending is not None else 0)
+        """Counter of the Philox streams (SpecAugment, audio augmentation, dropout): the index of the step being
+        launched -- every launched batch takes one, skipped or not."""
+        return self.launched_steps
+
+    def _begin_step(self, index: Optional[int] = None) -> int:
+        """Hand the step's Philox counter to every HIP module that draws masks, then advance it."""
+        if index is None:
+            index = self.launched_steps
+            self.launched_steps += 1
+        for m in self._dropout_modules:
+            m.dropout_step = index
+        return index
 
     def _resolve(self, pending):
         """Read one launched step's stats (waits for that step only) -> (batch_idx, loss, acc) or None if skipped."""
@@ -251,7 +316,7 @@ class Trainer:
     def _prepare_native(self, inputs, targets, step_index):
         """Input stage of a native step on its own HIP stream: H2D (if needed) + fused log-mel/SpecAugment.  It has no
         dependency on the model, so for batch k+1 it runs while step k's conv stack (HBM-bound) is executing -- the
-        front end is LDS/latency-bound, the two overlap well.  Returns (features, targets, ready_event)."""
+        front end is LDS/latency-bound, the two overlap well.  Returns (features, targets, ready_event, step_index)."""
         if self._in_stream is None:
             self._in_stream = torch.cuda.Stream(device=self.device)
         with torch.cuda.stream(self._in_stream):
@@ -262,21 +327,35 @@ class Trainer:
             tg = targets.to(self.device, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self._in_stream)
-        return feats, tg, ready
+        return feats, tg, ready, step_index
 
     def _step_native(self, inputs, targets, batch_idx, prepared=None):
         """Launch one native step; returns the list of steps whose results became available."""
         if prepared is None:
-            prepared = self._prepare_native(inputs, targets, self._launch_step_index())
-        inputs, targets, ready = prepared
+            prepared = self._prepare_native(inputs, targets, self._begin_step())
+        inputs, targets, ready, step_index = prepared
+        self._begin_step(step_index)               # dropout draws from the same counter as the batch's SpecAugment
         main = torch.cuda.current_stream(self.device)
         main.wait_event(ready)
         inputs.record_stream(main)
         targets.record_stream(main)
         self.model.sample_offset = self.rank * inputs.shape[0]
         self.optimizer.zero_grad(set_to_none=True)
-        stats = self.model.train_step_native(inputs, targets, self.criterion)     # fwd, loss, bwd: three C-ABI calls
-        self._allreduce_grads()
+        flag = None
+        if not self._dist:
+            stats = self.model.train_step_native(inputs, targets, self.criterion)     # fwd, loss, bwd: three C-ABI calls
+        else:
+            # two gradient buckets (SURVEY.md §8e): blocks 2, 3 + classifier (+ the found_inf slot) are reduced on the
+            # collective's stream while the backward of blocks 1, 0 and the stem runs; only the second, smaller
+            # reduction is exposed.  The clip needs the REDUCED gradients of both, so the optimizer waits for both.
+            self.model._prepare(inputs.device)
+            ext, cut, handles = self.model.flat_grad_ext, self.model.late_offset, []
+            flag = ext[-1:]
+            stats = self.model.train_step_native(inputs, targets, self.criterion, found_inf_out=flag,
+                                                 mid_hook=lambda: handles.append(self._reduce_start(ext[cut:])))
+            if cut > 0:
+                handles.append(self._reduce_start(ext[:cut]))
+            self._reduce_finish(handles)
         if self._host_bufs is None:
             self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
         buf = self._host_bufs[self._buf_i]
@@ -284,8 +363,12 @@ class Trainer:
         if self._fused_optimizer:
             # clip_gradients + "skip a non-finite batch" + optimizer.step() (trainer.py:177-193) in ONE launch, which also
             # writes the step's 48-byte record into pinned host memory
-            self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats, stats_host=buf)
+            self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats, stats_host=buf,
+                                found_inf_extra=flag)
         else:
+            if flag is not None:                   # some rank's bad batch -> every rank's found_inf
+                sv = stats.view(torch.float32)
+                sv[nat.FOUND_INF_FLOAT_INDEX] = torch.maximum(sv[nat.FOUND_INF_FLOAT_INDEX], (flag[0] != 0).float())
             nat.grad_norm_clip_(self.model.flat_grad, max(float(self.gradient_clip), 0.0), stats=stats)
         if self._skip_on_device and not self._fused_optimizer:
             # the reference skips a batch whose loss is not finite (trainer.py:177-179) or whose targets are invalid
@@ -320,11 +403,13 @@ class Trainer:
         """Training step of a HIP-backed autograd model without host reads: forward / native loss / backward through
         autograd, gradient all-reduce, clip_grad_norm_ and the "skip a non-finite batch" decision on the device (the
         fused optimizer takes it as found_inf), statistics resolved one step later."""
-        inputs = self._to_model_input(inputs, training=True)
+        inputs = self._to_model_input(inputs, training=True, step=self._begin_step())
         targets = targets.to(self.device, non_blocking=True)
         if hasattr(self.model, "sample_offset"):
             self.model.sample_offset = self.rank * inputs.shape[0]
         self.optimizer.zero_grad(set_to_none=True)
+        flag = self._dp_flag_slot()                # the loss kernel drops its skip flag behind the gradient bucket
+        self.criterion.found_inf_out = flag
         loss = self.criterion(self.model(inputs), targets)
         loss.backward()
         stats = self.criterion.last_stats
@@ -335,17 +420,16 @@ class Trainer:
         if self._fused_optimizer:
             # flat buckets (models/flat_buckets.py): gather the autograd gradients, ONE all-reduce, then clip + skip +
             # update + the 48-byte statistics record in one launch -- as the native cnn_small step does
-            flat = self.model.gather_grads()
+            self.model.gather_grads()
             if self._dist:
-                if self._dist.get_backend() == "nccl":
-                    self._dist.all_reduce(flat, op=self._dist.ReduceOp.AVG)
-                else:
-                    self._dist.all_reduce(flat)
-                    flat.div_(self.world_size)
-            self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats, stats_host=buf, gathered=True)
+                self._reduce_finish([self._reduce_start(self.model.flat_grad_ext)])
+            self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats, stats_host=buf, gathered=True,
+                                found_inf_extra=flag)
         else:
             self._allreduce_grads()
             sv = stats.view(torch.float32)
+            if flag is not None:
+                sv[nat.FOUND_INF_FLOAT_INDEX] = torch.maximum(sv[nat.FOUND_INF_FLOAT_INDEX], (flag[0] != 0).float())
             if self.gradient_clip > 0:
                 norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), float(self.gradient_clip), foreach=True)
                 sv[1] = norm                                                               # ww_step_stats.grad_norm
@@ -368,25 +452,39 @@ class Trainer:
         self._pending = launched
         return done
 
-    def _to_model_input(self, inputs, training):
+    def _to_model_input(self, inputs, training, step=None):
         """(B,N) waveforms go through the native front end (log-mel/MFCC [+SpecAugment, audio augmentation]); feature
         batches are moved as the reference does (channels_last, trainer.py:160)."""
         if inputs.dim() == 2 and torch.device(self.device).type == "cuda":
-            return self._features(inputs, training=training)
+            return self._features(inputs, training=training, step=step)
         return inputs.to(self.device, non_blocking=True, memory_format=torch.channels_last)
 
     def _step_generic(self, inputs, targets, batch_idx):
-        inputs = self._to_model_input(inputs, training=True)
-        targets = targets.to(self.device, non_blocking=True)
-        if hasattr(self.model, "sample_offset"):
-            self.model.sample_offset = self.rank * inputs.shape[0]
+        step_index = self._begin_step()
         self.optimizer.zero_grad(set_to_none=True)
         dev_type = torch.device(self.device).type
-        with torch.autocast(dev_type, enabled=self.use_mixed_precision and dev_type == "cuda"):
-            outputs = self.model(inputs)
-            loss = self.criterion(outputs, targets)
-        if not torch.isfinite(loss):
-            logger.error("Non-finite loss detected at batch %d: %s", batch_idx, loss.item())
+        failure = None
+        try:
+            inputs = self._to_model_input(inputs, training=True, step=step_index)
+            targets = targets.to(self.device, non_blocking=True)
+            if hasattr(self.model, "sample_offset"):
+                self.model.sample_offset = self.rank * inputs.shape[0]
+            with torch.autocast(dev_type, enabled=self.use_mixed_precision and dev_type == "cuda"):
+                outputs = self.model(inputs)
+                loss = self.criterion(outputs, targets)
+            finite = bool(torch.isfinite(loss))
+        except Exception as e:                     # noqa: BLE001 -- data parallel: the peers must learn of it before the all-reduce
+            if not self._dist:
+                raise
+            failure, finite = e, False
+        if self._vote_skip(not finite):            # all ranks skip together (no rank waits in a collective alone)
+            if failure is not None:
+                self._dp_voted = True              # the peers skip this batch too: the epoch loop may log + continue
+                raise failure
+            if not finite:
+                logger.error("Non-finite loss detected at batch %d: %s", batch_idx, loss.item())
+            else:
+                logger.error("Batch %d skipped: another rank reported a non-finite loss or an error", batch_idx)
             return []
         self.scaler.scale(loss).backward()
         self._allreduce_grads()
@@ -466,12 +564,18 @@ class Trainer:
                 self._call_callbacks("on_batch_end", idx, loss_value, batch_acc)
 
         pipelined = self.native and self._native_loss
-        launched = 0                                # native steps launched this epoch (Philox step = base + launched)
-        base_step = self.state.global_step
+
+        def survivable(e) -> bool:
+            """The reference logs and skips a failed batch (trainer.py:214-226).  Data parallel, that is only safe when
+            the peers skip it too -- i.e. the ranks voted (reference-style step); a rank that dropped out of a sync-free
+            step would leave the others inside the gradient all-reduce, so there the error ends the run on every rank."""
+            if not self._dist:
+                return True
+            voted, self._dp_voted = self._dp_voted, False
+            return voted
 
         def stage(item):
             """fetch-side work for one loader item: validate, and (native) enqueue its input stage on the side stream"""
-            nonlocal launched
             idx, batch = item
             try:
                 parsed = self._unpack(batch, idx, "batch")
@@ -479,11 +583,12 @@ class Trainer:
                     return None
                 prep = None
                 if pipelined:
-                    prep = self._prepare_native(parsed[0], parsed[1], base_step + launched)
-                    launched += 1
+                    index = self.launched_steps
+                    self.launched_steps += 1          # the batch owns this Philox step whether or not it survives
+                    prep = self._prepare_native(parsed[0], parsed[1], index)
                 return idx, parsed, prep
             except RuntimeError as e:
-                if "out of memory" in str(e).lower():
+                if "out of memory" in str(e).lower() and survivable(e):
                     logger.error("GPU OOM at batch %d. Clearing cache and skipping batch.", idx)
                     torch.cuda.empty_cache()
                     return None
@@ -491,6 +596,8 @@ class Trainer:
                 raise
             except Exception as e:
                 logger.exception("Unexpected error at batch %d: %s", idx, e)
+                if not survivable(e):
+                    raise
                 return None
 
         it = iter(enumerate(bar))
@@ -514,7 +621,7 @@ class Trainer:
                 else:
                     account(step(parsed[0], parsed[1], batch_idx))
             except RuntimeError as e:
-                if "out of memory" in str(e).lower():
+                if "out of memory" in str(e).lower() and survivable(e):
                     logger.error("GPU OOM at batch %d. Clearing cache and skipping batch.", batch_idx)
                     torch.cuda.empty_cache()
                     continue
@@ -522,6 +629,8 @@ class Trainer:
                 raise
             except Exception as e:
                 logger.exception("Unexpected error at batch %d: %s", batch_idx, e)
+                if not survivable(e):
+                    raise
                 continue
         account(self._flush_pending())            # the last step's deferred results
         epoch_loss, num_batches = self._epoch_reduce(self.train_metrics_tracker, epoch_loss, num_batches)
@@ -657,7 +766,8 @@ class Trainer:
                     "optimizer_state_dict": self.optimizer.state_dict(),
                     "scheduler_state_dict": self.scheduler.state_dict() if self.scheduler else None,
                     "scaler_state_dict": self.scaler.state_dict(), "state": self.state, "config": self.config,
-                    "val_loss": val_loss, "val_metrics": val_metrics.to_dict()}
+                    "val_loss": val_loss, "val_metrics": val_metrics.to_dict(),
+                    "launched_steps": int(self.launched_steps)}      # extension: not in the reference's dict (:487-497)
         except Exception as e:
             logger.error("Failed to create checkpoint dict: %s", e)
             return
@@ -673,10 +783,13 @@ class Trainer:
         if not checkpoint_path.is_file():
             raise ValueError(f"Checkpoint path is not a file: {checkpoint_path}")
         try:
-            # the dict pickles TrainingState / config instances, as the reference's does (:493-494)
-            ckpt = torch.load(checkpoint_path, map_location=self.device, weights_only=False)
+            # the dict pickles TrainingState / config instances, as the reference's does (:493-494); they are the ONLY
+            # non-tensor classes the restricted unpickler accepts -- a checkpoint cannot run code in the training process
+            with torch.serialization.safe_globals(_checkpoint_safe_globals()):
+                ckpt = torch.load(checkpoint_path, map_location=self.device, weights_only=True)
         except Exception as e:
-            raise RuntimeError(f"Corrupted or invalid checkpoint file: {checkpoint_path}") from e
+            raise RuntimeError(f"Corrupted or invalid checkpoint file (loaded with weights_only=True; classes other than "
+                               f"TrainingState and the config dataclasses are refused): {checkpoint_path}: {e}") from e
         missing = [k for k in ("model_state_dict", "optimizer_state_dict", "state") if k not in ckpt]
         if missing:
             raise ValueError(f"Checkpoint missing required keys: {missing}")
@@ -694,11 +807,12 @@ class Trainer:
             except Exception as e:
                 logger.warning("Failed to load %s state dict: %s. Continuing with fresh %s.", name, e, name)
         self.state = ckpt["state"]
-        # the Philox streams of the HIP modules (dropout masks) continue where the interrupted run stood: their counter is the
-        # number of training steps taken (SpecAugment / audio augmentation take theirs from state.global_step directly)
-        for m in self.model.modules():
-            if hasattr(m, "dropout_step"):
-                m.dropout_step = int(self.state.global_step)
+        # a reference checkpoint has no launched-step counter: without skipped batches it equals global_step
+        self.launched_steps = int(ckpt.get("launched_steps", self.state.global_step))
+        # the Philox streams (SpecAugment, audio augmentation, dropout) continue where the interrupted run stood: all of
+        # them are driven by self.launched_steps (_begin_step)
+        for m in self._dropout_modules:
+            m.dropout_step = int(self.launched_steps)
         logger.info("Checkpoint loaded: Epoch %d", self.state.epoch + 1)
 
     # ------------------------------------------------------------------------------- callbacks
