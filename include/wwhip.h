@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 5
+#define WW_ABI_VERSION 6
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -46,6 +46,30 @@ int ww_abi_version(void);
 const char *ww_last_error(void);
 int ww_ctx_create(int device, ww_ctx **out);
 int ww_ctx_destroy(ww_ctx *ctx);
+
+/* ------------------------------------------------------------------ device-resident step control (HIP graph replay)
+ * A captured HIP graph bakes every by-value launch argument, but three things change from one training step to the next:
+ * the Philox step of SpecAugment / audio augmentation / dropout, the optimizer's learning rate (schedulers,
+ * src/training/optimizer_factory.py:281-333) and its step_state slot.  While a control block is BOUND to the ctx, every
+ * entry point reads them from this 32-byte device struct at kernel RUN time:
+ *   Philox step  = the call's `step` argument (now an OFFSET: 0 = the batch being trained, 1 = the batch whose input stage
+ *                  runs one step ahead) + ctl->step;
+ *   ww_clip_optim_step: lr = ctl->lr (cfg->lr ignored), parity = ctl->parity (argument ignored), and the step record goes
+ *                  to stats_host_alt instead of stats_host when that parity is 1 (two pinned buffers, so the host may
+ *                  read step k's record while step k+1 is running).
+ * ww_step_ctl_advance is the one-thread kernel that opens a step: step += 1, parity ^= 1 (the first node of the captured
+ * graph).  The host owns the struct's memory and writes lr / the initial step through ordinary copies between replays.
+ * The reference has no graph capture; BASELINE config 5 asks for a "hipGraph-captured step".       */
+typedef struct {
+    uint64_t step;      /* launched-step counter */
+    float lr;
+    int32_t parity;     /* 0 | 1 */
+    float loss_scale;   /* fp16 storage mode: the dynamic loss scale (ww_ce2_loss_fwd_bwd multiplies dlogits by it) */
+    int32_t growth_tracker;
+    int32_t reserved[2];
+} ww_step_ctl;
+int ww_ctx_bind_step_ctl(ww_ctx *ctx, const ww_step_ctl *ctl_dev /* device memory, 8-byte aligned; NULL unbinds */);
+int ww_step_ctl_advance(ww_ctx *ctx, ww_stream_t stream);
 
 /* ------------------------------------------------------------------ features
  * Replaces FeatureExtractor.__call__ (src/data/feature_extraction.py -- ABSENT from the
@@ -339,11 +363,13 @@ typedef struct {
 int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *flat_params, float *flat_grads, float *exp_avg,
                        float *exp_avg_sq, size_t n, int64_t *step_state, int parity, float *norm_out,
                        ww_step_stats *stats /* nullable */, ww_step_stats *stats_host /* nullable */,
+                       ww_step_stats *stats_host_alt /* nullable; see ww_step_ctl */,
                        const float *found_inf_extra /* nullable: != 0 -> skip (another rank's verdict) */,
                        ww_stream_t stream);
 
 /* ------------------------------------------------------------------ collectives: deliberately NOT in this ABI
- * SURVEY.md §8b sketched ww_comm_init(ctx, nccl_unique_id, rank, world) / ww_allreduce_f32(ctx, buf, n, avg, comm_stream).
+ * SURVEY.md §8b sketched two more entry points, `ww_comm_init` (ctx, nccl_unique_id, rank, world) and `ww_allreduce_f32`
+ * (ctx, buf, n, avg, comm_stream).
  * They are waived: the exchange step of this path is ONE averaged all-reduce of the flat fp32 gradient bucket (two
  * ranges of it, see WW_BWD_LATE/EARLY above), and the host side of the boundary is Python on PyTorch-ROCm, whose
  * torch.distributed "nccl" backend IS RCCL over xGMI -- a second communicator owned by this library would duplicate

@@ -1,0 +1,99 @@
+"""GPU: the HIP-graph-captured training step (BASELINE config 5 "hipGraph-captured step"; Trainer._graph_capture).
+
+What a replay must reproduce is everything an eager step does, with the per-step quantities (Philox step of SpecAugment
+and dropout, learning rate, optimizer step_state slot, pinned stats buffer) read from the device-resident control block
+instead of baked launch arguments.  The kernels are deterministic (fixed-order reductions), so the bar is BIT equality:
+loss trace, every parameter, every BatchNorm buffer and the optimizer's moments after N replayed steps equal N eager steps."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cfg(graph, epochs=2, sched="cosine"):
+    from wakeword_trainer_home_amd.config import get_preset
+    cfg = get_preset("cnn_small_logmel40")
+    cfg.training.epochs, cfg.training.batch_size = epochs, 16
+    cfg.optimizer.scheduler, cfg.optimizer.warmup_epochs = sched, 0
+    cfg.optimizer.mixed_precision = True              # bf16 storage: the benched mode
+    cfg.model.dropout = 0.3
+    cfg.training.hip_graph = graph
+    cfg.training.checkpoint_frequency = "best_only"
+    return cfg
+
+
+def _run(tmp_path, graph, batches, val, epochs=2):
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    cfg = _cfg(graph, epochs)
+    torch.manual_seed(7)
+    model = create_model("cnn_small", dropout=cfg.model.dropout, dropout_seed=3)
+    t = Trainer(model, batches, val, cfg, checkpoint_dir=tmp_path / ("g" if graph else "e"), device=DEV)
+    rec = []
+    t.add_callback(type("R", (), {"on_batch_end": lambda self, i, l, a: rec.append((i, l, a))})())
+    res = t.train()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    opt = copy.deepcopy(t.optimizer.state_dict())
+    return t, rec, sd, opt, res
+
+
+def _assert_same(a, b):
+    ta, ra, sa, oa, resa = a
+    tb, rb, sb, ob, resb = b
+    assert [r[0] for r in ra] == [r[0] for r in rb]
+    assert [r[1] for r in ra] == [r[1] for r in rb], "loss traces differ"          # float equality: bit-identical steps
+    assert [r[2] for r in ra] == [r[2] for r in rb]
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    for (ka, va), (kb, vb) in zip(sorted(oa["state"].items()), sorted(ob["state"].items())):
+        for f in va:
+            assert torch.equal(torch.as_tensor(va[f]).cpu(), torch.as_tensor(vb[f]).cpu()), (ka, f)
+    assert resa["history"]["train_loss"] == resb["history"]["train_loss"]
+    assert resa["history"]["learning_rates"] == resb["history"]["learning_rates"]
+    assert ta.launched_steps == tb.launched_steps and ta.state.global_step == tb.state.global_step
+
+
+def test_replayed_steps_equal_eager_steps_bit_for_bit(tmp_path):
+    """Waveform batches (the input stage runs as the graph's side branch, one batch ahead), 2 epochs x 6 steps with a
+    cosine schedule (the learning rate reaches the replay through the control block)."""
+    from wakeword_trainer_home_amd.data import make_synthetic_batch
+    wave, y = make_synthetic_batch(16 * 6, 24000, seed=5)
+    y[::4] = 1
+    batches = [(wave[16 * i:16 * i + 16], y[16 * i:16 * i + 16]) for i in range(6)]
+    eager = _run(tmp_path, False, batches, batches[:1])
+    graph = _run(tmp_path, True, batches, batches[:1])
+    assert graph[0]._graph is not None and eager[0]._graph is None
+    assert len(graph[1]) == 12
+    _assert_same(eager, graph)
+
+
+def test_ragged_batch_and_feature_inputs_fall_back_and_resume(tmp_path):
+    """Feature-map batches (B,1,40,151) (no side branch), with a smaller batch in the middle: that batch takes the eager
+    step, the replays before and after it stay in step with the Philox / optimizer-slot bookkeeping."""
+    from tests.golden_util import make_inputs
+    x, y = make_inputs(9, 16 * 5 + 5)
+    cuts = [0, 16, 32, 37, 53, 69, 85]                       # batch 2 has 5 samples
+    batches = [(x[a:b], y[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    eager = _run(tmp_path, False, batches, batches[:1], epochs=1)
+    graph = _run(tmp_path, True, batches, batches[:1], epochs=1)
+    assert graph[0]._graph is not None and graph[0]._graph["waveform"] is False
+    _assert_same(eager, graph)
+
+
+def test_nonfinite_batch_is_skipped_inside_a_replay(tmp_path):
+    """found_inf is device state: a poisoned batch replayed through the graph leaves parameters and the optimizer's step
+    count untouched, exactly as the eager step does."""
+    from tests.golden_util import make_inputs
+    x, y = make_inputs(3, 16 * 5)
+    x = x.clone()
+    x[16 * 3 + 2, 0, 5, 7] = float("nan")                    # batch 3 is poisoned
+    batches = [(x[16 * i:16 * i + 16], y[16 * i:16 * i + 16]) for i in range(5)]
+    eager = _run(tmp_path, False, batches, batches[:1], epochs=1)
+    graph = _run(tmp_path, True, batches, batches[:1], epochs=1)
+    assert [r[0] for r in graph[1]] == [0, 1, 2, 4]
+    assert graph[0].optimizer.step_count() == 4 and graph[0].launched_steps == 5
+    _assert_same(eager, graph)

@@ -13,7 +13,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 BWD_ALL, BWD_LATE, BWD_EARLY = 0, 1, 2
 ACT_F32, ACT_BF16 = 0, 1
 LOSS_CE, LOSS_FOCAL = 0, 1
@@ -60,6 +60,14 @@ class OptimCfg(C.Structure):
 OPT_ADAM, OPT_ADAMW, OPT_SGD = 0, 1, 2
 
 
+class StepCtl(C.Structure):
+    _fields_ = [("step", C.c_uint64), ("lr", C.c_float), ("parity", C.c_int32), ("loss_scale", C.c_float),
+                ("growth_tracker", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+
+STEP_CTL_BYTES = C.sizeof(StepCtl)
+
+
 class StepStats(C.Structure):
     _fields_ = [("loss", C.c_float), ("grad_norm", C.c_float), ("correct", C.c_int32), ("tp", C.c_int32),
                 ("tn", C.c_int32), ("fp", C.c_int32), ("fn", C.c_int32), ("nonfinite", C.c_int32),
@@ -74,6 +82,8 @@ _SIGS = {
     "ww_last_error": (C.c_char_p, []),
     "ww_ctx_create": (C.c_int, [_i, C.POINTER(_vp)]),
     "ww_ctx_destroy": (C.c_int, [_vp]),
+    "ww_ctx_bind_step_ctl": (C.c_int, [_vp, _vp]),
+    "ww_step_ctl_advance": (C.c_int, [_vp, _vp]),
     "ww_feat_num_frames": (C.c_int, [_i, _i]),
     "ww_logmel_fwd": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(FeatCfg), _vp, C.POINTER(SpecAugCfg), _u64, _u64, _u64,
                                 _vp, _vp]),
@@ -103,7 +113,7 @@ _SIGS = {
     "ww_gru_fwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_long, _vp, _vp, _sz, _vp]),
     "ww_gru_bwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, C.c_long, _i,
                              _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ww_layer_scratch_bytes": (_sz, []),
     "ww_conv_stem_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
     "ww_dwconv3x3_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
@@ -590,8 +600,41 @@ def gru_bwd(x, w_ih, w_hh, dy, dh_n, ws, reverse=False, dx=None, accumulate_dx=F
     return dw_ih, dw_hh, db_ih, db_hh, dh0
 
 
+def step_ctl_new(dev, step=0, lr=0.0, parity=0):
+    """A device control block (uint8[32] tensor) initialised to (step, lr, parity); see include/wwhip.h ww_step_ctl."""
+    host = StepCtl(step, lr, parity, 1.0, 0)
+    return torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(dev)
+
+
+def step_ctl_write(ctl, step=None, lr=None, parity=None):
+    """Update fields of a control block from the host (small async copies on the current stream, between replays)."""
+    if step is not None:
+        ctl[0:8].copy_(torch.frombuffer(bytearray(int(step).to_bytes(8, "little")), dtype=torch.uint8), non_blocking=False)
+    if lr is not None:
+        ctl[8:12].view(torch.float32).fill_(float(lr))
+    if parity is not None:
+        ctl[12:16].view(torch.int32).fill_(int(parity))
+
+
+def step_ctl_read(ctl) -> dict:
+    s = StepCtl.from_buffer_copy(bytes(ctl.cpu().numpy().tobytes()))
+    return {"step": s.step, "lr": s.lr, "parity": s.parity, "loss_scale": s.loss_scale, "growth_tracker": s.growth_tracker}
+
+
+def bind_step_ctl(dev, ctl):
+    """Bind (ctl = uint8[32] device tensor) or unbind (None) the device-resident step control of ``dev``'s context."""
+    if ctl is not None and (not ctl.is_cuda or ctl.numel() < STEP_CTL_BYTES or ctl.dtype != torch.uint8):
+        raise ValueError("the step control block must be a uint8 device tensor of at least 32 bytes")
+    _check(load().ww_ctx_bind_step_ctl(ctx(dev), _p(ctl)), "ww_ctx_bind_step_ctl")
+
+
+def step_ctl_advance(dev):
+    with _guard(dev):
+        _check(load().ww_step_ctl_advance(ctx(dev), _stream(dev)), "ww_step_ctl_advance")
+
+
 def clip_optim_step_(cfg: OptimCfg, flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, parity, norm_out=None,
-                     stats=None, stats_host=None, found_inf_extra=None):
+                     stats=None, stats_host=None, found_inf_extra=None, stats_host_alt=None):
     """In place: clip flat_grads to cfg.max_norm, then one Adam/AdamW/SGD step on flat_params (skipped on found_inf).
     ``stats_host``: pinned uint8[48] host tensor the kernel copies the step's ww_step_stats into.
     ``found_inf_extra``: float32[1] device tensor; non-zero also skips the step (data parallel: some rank's bad batch)."""
@@ -606,6 +649,7 @@ def clip_optim_step_(cfg: OptimCfg, flat_params, flat_grads, exp_avg, exp_avg_sq
         _check(load().ww_clip_optim_step(ctx(dev), C.byref(cfg), _p(flat_params), _p(flat_grads), _p(exp_avg), _p(exp_avg_sq),
                                          flat_params.numel(), _p(step_state), parity, _p(norm_out), _p(stats),
                                          None if stats_host is None else C.c_void_p(stats_host.data_ptr()),
+                                         None if stats_host_alt is None else C.c_void_p(stats_host_alt.data_ptr()),
                                          _p(found_inf_extra), _stream(dev)), "ww_clip_optim_step")
 
 

@@ -31,14 +31,16 @@ struct AugParams {
     float snr_min, snr_max;
     uint32_t seed_lo, seed_hi, step_lo, step_hi;
     uint64_t sample_offset;
+    const ww_step_ctl *ctl;
 };
 struct AugChoice { int rir, noise, offset; float snr_db; };
 
 __device__ __forceinline__ AugChoice aug_choice(const AugParams &p, int b) {
     const uint32_t g = (uint32_t)(p.sample_offset + (uint64_t)b);
-    uint32_t r0[4], r1[4];
-    ww_philox(p.step_lo, p.step_hi, g, (TAG_AUDIO << 24) | 0u, p.seed_lo, p.seed_hi, r0);
-    ww_philox(p.step_lo, p.step_hi, g, (TAG_AUDIO << 24) | 1u, p.seed_lo, p.seed_hi, r1);
+    uint32_t r0[4], r1[4], slo, shi;
+    ww_step_resolve(p.ctl, p.step_lo, p.step_hi, slo, shi);
+    ww_philox(slo, shi, g, (TAG_AUDIO << 24) | 0u, p.seed_lo, p.seed_hi, r0);
+    ww_philox(slo, shi, g, (TAG_AUDIO << 24) | 1u, p.seed_lo, p.seed_hi, r1);
     AugChoice c;
     c.rir = (p.R > 0 && (uint64_t)r0[0] < p.rir_thresh) ? (int)(r0[1] % (uint32_t)p.R) : -1;
     c.noise = (p.K > 0 && (uint64_t)r1[0] < p.noise_thresh) ? (int)(r1[1] % (uint32_t)p.K) : -1;
@@ -425,6 +427,7 @@ extern "C" int ww_audio_augment(ww_ctx *ctx, const float *wave_in, float *wave_o
     p.snr_min = cfg->snr_min_db; p.snr_max = cfg->snr_max_db;
     p.seed_lo = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
     p.step_lo = (uint32_t)step; p.step_hi = (uint32_t)(step >> 32);
+    p.ctl = ctx->step_ctl;
     p.sample_offset = sample_offset;
     const size_t smem = (size_t)(AUG_TILE + 2 * p.Lp) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;

@@ -34,8 +34,9 @@ __global__ __launch_bounds__(1024) void k_head_bwd(const float *__restrict__ dlo
                                                   const float *__restrict__ mr, float *__restrict__ dfc_w,
                                                   float *__restrict__ dfc_b, float *__restrict__ dpool,
                                                   float *__restrict__ coef, float *__restrict__ dgamma,
-                                                  float *__restrict__ dbeta) {
+                                                  float *__restrict__ dbeta, const ww_step_ctl *__restrict__ ctl) {
     __shared__ double sh[6][1024];
+    ww_step_resolve(ctl, step_lo, step_hi, step_lo, step_hi);
     const int c = 8 * blockIdx.x + (threadIdx.x & 7), part = threadIdx.x >> 3;      // 128 batch parts
     const float w0 = fc_w[c], w1 = fc_w[64 + c];
     const float inv_hw = 1.0f / (float)HW;
@@ -719,7 +720,7 @@ extern "C" int ww_head_bwd(ww_ctx *ctx, const float *dlogits, const float *pd, c
     hipLaunchKernelGGL(k_head_bwd, dim3(8), dim3(1024), 0, (hipStream_t)stream, dlogits, pd, pool, B, HW, fc_w, scale,
                        ww_prob_threshold((double)dropout_p), use_dropout, (uint32_t)seed, (uint32_t)(seed >> 32),
                        (uint32_t)step, (uint32_t)(step >> 32), sample_offset, gamma_last, mr_last, dfc_w, dfc_b, dpool,
-                       coef_last, dgamma_last, dbeta_last);
+                       coef_last, dgamma_last, dbeta_last, ctx->step_ctl);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

@@ -472,9 +472,10 @@ __global__ __launch_bounds__(256) void k_head_fwd(const float *__restrict__ pool
                                                   float drop_scale, uint64_t drop_thresh, int use_dropout,
                                                   uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo, uint32_t step_hi,
                                                   uint64_t sample_offset, float *__restrict__ pd,
-                                                  float *__restrict__ logits) {
+                                                  float *__restrict__ logits, const ww_step_ctl *__restrict__ ctl) {
     const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
+    ww_step_resolve(ctl, step_lo, step_hi, step_lo, step_hi);
     float v = pool[(size_t)b * 192 + lane] / (float)HW;
     if (use_dropout) {
         uint32_t rr[4];
@@ -664,7 +665,7 @@ extern "C" int ww_head_fwd(ww_ctx *ctx, const float *pool, int B, int HW, const 
     ww_prof_scope ps_(ctx, WW_K_HEAD_LOSS, (hipStream_t)stream);
     hipLaunchKernelGGL(k_head_fwd, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, pool, B, HW, fc_w, fc_b,
                        scale, ww_prob_threshold((double)dropout_p), use_dropout, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       (uint32_t)step, (uint32_t)(step >> 32), sample_offset, pd, logits);
+                       (uint32_t)step, (uint32_t)(step >> 32), sample_offset, pd, logits, ctx->step_ctl);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

@@ -49,11 +49,32 @@ extern "C" int ww_ctx_create(int device, ww_ctx **out) {
     c->device = device;
     c->tables = nullptr;
     c->prof_mask = 0;
+    c->step_ctl = nullptr;
     c->tw16k = nullptr;
     c->norm_partials = nullptr;
     c->prof_recs = new std::vector<ww_prof_rec>();
     c->prof_free = new std::vector<ww_prof_rec>();
     *out = c;
+    return WW_OK;
+}
+
+// ---- device-resident step control (HIP graph replay)
+__global__ void k_step_ctl_advance(ww_step_ctl *ctl) {
+    ctl->step += 1;
+    ctl->parity ^= 1;
+}
+
+extern "C" int ww_ctx_bind_step_ctl(ww_ctx *ctx, const ww_step_ctl *ctl_dev) {
+    WW_REQUIRE(ctx != nullptr, WW_E_INVALID, "ww_ctx_bind_step_ctl: ctx is null");
+    WW_REQUIRE(((uintptr_t)ctl_dev & 7) == 0, WW_E_INVALID, "ww_ctx_bind_step_ctl: the control block must be 8-byte aligned");
+    ctx->step_ctl = ctl_dev;
+    return WW_OK;
+}
+
+extern "C" int ww_step_ctl_advance(ww_ctx *ctx, ww_stream_t stream) {
+    WW_REQUIRE(ctx && ctx->step_ctl, WW_E_INVALID, "ww_step_ctl_advance: no control block is bound");
+    hipLaunchKernelGGL(k_step_ctl_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, const_cast<ww_step_ctl *>(ctx->step_ctl));
+    WW_LAUNCH_CHECK();
     return WW_OK;
 }
 

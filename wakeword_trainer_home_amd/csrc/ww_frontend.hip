@@ -293,7 +293,9 @@ __global__ __launch_bounds__(256) void k_specaug_apply(float *__restrict__ x, in
     }
 }
 
-int resolve_mask(const ww_specaug_cfg *sa, uint64_t seed, uint64_t step, uint64_t sample_offset, ww_mask_params *mp) {
+int resolve_mask(const ww_ctx *ctx, const ww_specaug_cfg *sa, uint64_t seed, uint64_t step, uint64_t sample_offset,
+                 ww_mask_params *mp) {
+    mp->ctl = ctx->step_ctl;
     WW_REQUIRE(sa->n_freq_masks >= 0 && sa->n_time_masks >= 0 &&
                    sa->n_freq_masks + sa->n_time_masks <= WW_MAX_MASKS,
                WW_E_INVALID, "specaug: n_freq_masks + n_time_masks must be in [0,%d]", WW_MAX_MASKS);
@@ -351,7 +353,7 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
     ww_mask_params mp = {};
     int use_mask = 0;
     if (sa) {
-        if ((rc = resolve_mask(sa, seed, step, sample_offset, &mp))) return rc;
+        if ((rc = resolve_mask(ctx, sa, seed, step, sample_offset, &mp))) return rc;
         use_mask = (mp.n_f + mp.n_t) > 0;
     }
     const size_t smem = (size_t)4 * BUF_ELEMS * sizeof(float2) + (size_t)4 * 2 * PB_LD * sizeof(float) +
@@ -381,7 +383,7 @@ extern "C" int ww_specaug_apply(ww_ctx *ctx, float *x, int B, int F, int T, cons
     WW_REQUIRE(ctx && x && sa, WW_E_INVALID, "ww_specaug_apply: null argument");
     WW_REQUIRE(B >= 0 && F >= 1 && T >= 1, WW_E_INVALID, "ww_specaug_apply: bad shape (%d,%d,%d)", B, F, T);
     ww_mask_params mp = {};
-    int rc = resolve_mask(sa, seed, step, sample_offset, &mp);
+    int rc = resolve_mask(ctx, sa, seed, step, sample_offset, &mp);
     if (rc) return rc;
     if (B == 0 || mp.n_f + mp.n_t == 0) return WW_OK;
     hipLaunchKernelGGL(k_specaug_apply, dim3(B), dim3(256), 0, (hipStream_t)stream, x, B, F, T, mp, mask_idx);

@@ -338,7 +338,8 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
 __global__ __launch_bounds__(256) void k_dropout_bt(const float *__restrict__ x, long ldx, int B, int T, int C, float scale,
                                                     uint64_t thresh, uint32_t seed_lo, uint32_t seed_hi, uint32_t step_lo,
                                                     uint32_t step_hi, uint64_t sample_offset, uint32_t stream_id,
-                                                    float *__restrict__ out, long ldo) {
+                                                    float *__restrict__ out, long ldo, const ww_step_ctl *__restrict__ ctl) {
+    ww_step_resolve(ctl, step_lo, step_hi, step_lo, step_hi);
     const int cq = (C + 3) / 4;
     const long n = (long)B * T * cq;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -397,7 +398,7 @@ extern "C" int ww_dropout_bt(ww_ctx *ctx, const float *x, long ldx, int B, int T
     const int grid = (int)std::min<long>((n + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(k_dropout_bt, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, B, T, C,
                        (float)(1.0 / (1.0 - (double)p)), ww_prob_threshold((double)p), (uint32_t)seed, (uint32_t)(seed >> 32),
-                       (uint32_t)step, (uint32_t)(step >> 32), sample_offset, (uint32_t)stream_id, out, ldo);
+                       (uint32_t)step, (uint32_t)(step >> 32), sample_offset, (uint32_t)stream_id, out, ldo, ctx->step_ctl);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

@@ -70,6 +70,7 @@ struct ww_ctx {
     ww_feat_tables *tables;
     float2 *tw16k;                         // (1024) exp(-2 pi i m / 16384), ww_audio.hip's FFT convolution; lazy
     double *norm_partials;                 // (WW_NORM_PARTS) block sums of squares of a large gradient bucket; lazy
+    const ww_step_ctl *step_ctl;           // bound device control block (ww_ctx_bind_step_ctl) or NULL
     uint32_t prof_mask;
     std::vector<ww_prof_rec> *prof_recs;   // recorded, not yet collected
     std::vector<ww_prof_rec> *prof_free;   // event pairs ready for reuse
@@ -78,6 +79,8 @@ struct ww_prof_scope {   // RAII: records an event pair around the launches issu
     ww_ctx *ctx; hipStream_t st; ww_prof_rec r; bool on;
     ww_prof_scope(ww_ctx *c, int cls, hipStream_t s) : ctx(c), st(s), on(false) {
         if (!c || !(c->prof_mask & (1u << cls))) return;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;      // event pairs cannot time nodes of a graph being captured
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
         if (!c->prof_free->empty()) { r = c->prof_free->back(); c->prof_free->pop_back(); }
         else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
         r.cls = cls;
@@ -143,18 +146,30 @@ __host__ __device__ inline void ww_philox(uint32_t c0, uint32_t c1, uint32_t c2,
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Philox step of a launch: the by-value argument, plus the bound control block's counter read at RUN time (so a captured
+// HIP graph draws fresh masks on every replay)
+__device__ __forceinline__ void ww_step_resolve(const ww_step_ctl *ctl, uint32_t lo, uint32_t hi, uint32_t &out_lo,
+                                                uint32_t &out_hi) {
+    uint64_t s = ((uint64_t)hi << 32) | lo;
+    if (ctl) s += ctl->step;
+    out_lo = (uint32_t)s;
+    out_hi = (uint32_t)(s >> 32);
+}
+
 struct ww_mask_params {  // resolved SpecAugment parameters passed by value to kernels
     int32_t n_f, n_t, f_param, t_param;
     uint64_t f_thresh, t_thresh;
     uint32_t seed_lo, seed_hi, step_lo, step_hi;
     uint64_t sample_offset;
+    const ww_step_ctl *ctl;
 };
 
 // (start,width) of mask k for sample b; width==0 when the mask is not applied.
 __device__ inline void ww_specaug_mask(const ww_mask_params &mp, uint32_t sample, int k, int F, int T, int &s,
                                        int &w) {
-    uint32_t r[4];
-    ww_philox(mp.step_lo, mp.step_hi, sample, (WW_TAG_SPECAUG << 24) | (uint32_t)k, mp.seed_lo, mp.seed_hi, r);
+    uint32_t r[4], slo, shi;
+    ww_step_resolve(mp.ctl, mp.step_lo, mp.step_hi, slo, shi);
+    ww_philox(slo, shi, sample, (WW_TAG_SPECAUG << 24) | (uint32_t)k, mp.seed_lo, mp.seed_hi, r);
     const bool is_f = k < mp.n_f;
     const uint32_t dim = is_f ? (uint32_t)F : (uint32_t)T;
     const uint32_t param = is_f ? (uint32_t)mp.f_param : (uint32_t)mp.t_param;

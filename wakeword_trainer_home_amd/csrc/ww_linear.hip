@@ -36,6 +36,7 @@ struct Epilogue {
     uint64_t drop_thresh;
     uint32_t seed_lo, seed_hi, step_lo, step_hi;
     uint64_t sample_offset;
+    const ww_step_ctl *ctl;
     int accumulate;             // C += result (second direction of a bidirectional layer adds into dX)
 };
 
@@ -52,8 +53,9 @@ __device__ __forceinline__ float lin_act_grad(int act, float z) {      // torch'
     return 1.f;
 }
 __device__ __forceinline__ bool drop_keep(const Epilogue &e, long row, int col) {
-    uint32_t rr[4];
-    ww_philox(e.step_lo, e.step_hi, (uint32_t)(e.sample_offset + (uint64_t)row), (WW_TAG_DROPOUT << 24) | (uint32_t)(col >> 2),
+    uint32_t rr[4], slo, shi;
+    ww_step_resolve(e.ctl, e.step_lo, e.step_hi, slo, shi);
+    ww_philox(slo, shi, (uint32_t)(e.sample_offset + (uint64_t)row), (WW_TAG_DROPOUT << 24) | (uint32_t)(col >> 2),
               e.seed_lo, e.seed_hi, rr);
     const int q = col & 3;
     const uint32_t rv = q == 0 ? rr[0] : q == 1 ? rr[1] : q == 2 ? rr[2] : rr[3];
@@ -297,8 +299,9 @@ __global__ __launch_bounds__(1024) void k_colsum_chunk(const float *__restrict__
     }
 }
 
-int make_epilogue(const ww_linear_epi *epi, const float *bias, float *pre, Epilogue *out) {
+int make_epilogue(const ww_ctx *ctx, const ww_linear_epi *epi, const float *bias, float *pre, Epilogue *out) {
     Epilogue e = {};
+    e.ctl = ctx ? ctx->step_ctl : nullptr;
     e.bias = bias;
     e.pre = pre;
     if (epi) {
@@ -424,7 +427,7 @@ extern "C" int ww_linear_mfma_fwd(ww_ctx *ctx, int mode, const float *x, const f
     int rc = check_dims("ww_linear_mfma_fwd", mode, M, K, N);
     if (rc) return rc;
     Epilogue e;
-    if ((rc = make_epilogue(epi, bias, pre, &e))) return rc;
+    if ((rc = make_epilogue(ctx, epi, bias, pre, &e))) return rc;
     const GemmOperand A{x, K, 1, M}, B{w, K, 1, N};
     ww_prof_scope ps_(ctx, WW_K_LINEAR, (hipStream_t)stream);
     return launch_gemm<true, true, true>(mode, A, B, K, y, N, e, (hipStream_t)stream);
@@ -452,7 +455,7 @@ extern "C" int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const f
     if (rc) return rc;
     WW_REQUIRE(scratch_bytes >= ww_linear_mfma_bwd_scratch_bytes(M, K, N), WW_E_WORKSPACE, "ww_linear_mfma_bwd: scratch too small");
     Epilogue e;
-    if ((rc = make_epilogue(epi, nullptr, nullptr, &e))) return rc;
+    if ((rc = make_epilogue(ctx, epi, nullptr, nullptr, &e))) return rc;
     WW_REQUIRE(e.act == WW_LIN_NONE || pre, WW_E_INVALID, "ww_linear_mfma_bwd: the activation's backward needs `pre`");
     hipStream_t st = (hipStream_t)stream;
     ww_prof_scope ps_(ctx, WW_K_LINEAR, st);

@@ -15,7 +15,12 @@ namespace {
 struct OptimArgs {
     int kind;
     float lr, beta1, beta2, eps, wd, momentum, max_norm;
+    const ww_step_ctl *ctl;       // bound control block: lr and the step_state slot come from device memory (HIP graph replay)
 };
+// learning rate / slot of this launch: by value, or the bound control block's (read at run time)
+__device__ __forceinline__ void optim_resolve(OptimArgs &a, int &parity) {
+    if (a.ctl) { a.lr = a.ctl->lr; parity = a.ctl->parity & 1; }
+}
 
 __device__ __forceinline__ void optim_update(const OptimArgs &a, float &p, const float g0, float &m, float &v,
                                              const float step_size, const float bc2_sqrt) {
@@ -52,7 +57,10 @@ __global__ __launch_bounds__(1024) void k_clip_optim_small(OptimArgs a, float *_
                                                            long long *__restrict__ step_state, int parity,
                                                            float *__restrict__ norm_out, ww_step_stats *__restrict__ stats,
                                                            ww_step_stats *__restrict__ stats_host,
+                                                           ww_step_stats *__restrict__ stats_host_alt,
                                                            const float *__restrict__ found_inf_extra) {
+    optim_resolve(a, parity);
+    if (parity && stats_host_alt) stats_host = stats_host_alt;
     __shared__ double sh[1024];
     __shared__ float coef_sh, ss_sh, bc_sh;
     __shared__ int skip_sh;
@@ -126,7 +134,10 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
                                                       const double *__restrict__ parts, int nparts,
                                                       float *__restrict__ norm_out, ww_step_stats *__restrict__ stats,
                                                       ww_step_stats *__restrict__ stats_host,
+                                                      ww_step_stats *__restrict__ stats_host_alt,
                                                       const float *__restrict__ found_inf_extra) {
+    optim_resolve(a, parity);
+    if (parity && stats_host_alt) stats_host = stats_host_alt;
     double t = 0.0;
     for (int i = 0; i < nparts; ++i) t += parts[i];
     const float norm = (float)sqrt(t);
@@ -172,17 +183,22 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
 extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *flat_params, float *flat_grads,
                                   float *exp_avg, float *exp_avg_sq, size_t n, int64_t *step_state, int parity,
                                   float *norm_out, ww_step_stats *stats, ww_step_stats *stats_host,
-                                  const float *found_inf_extra, ww_stream_t stream) {
+                                  ww_step_stats *stats_host_alt, const float *found_inf_extra, ww_stream_t stream) {
     WW_REQUIRE(ctx && cfg && flat_params && flat_grads && step_state, WW_E_INVALID, "ww_clip_optim_step: null argument");
-    ww_step_stats *stats_host_dev = nullptr;
+    ww_step_stats *stats_host_dev = nullptr, *stats_host_alt_dev = nullptr;
     if (stats_host) {
         WW_REQUIRE(stats != nullptr, WW_E_INVALID, "ww_clip_optim_step: stats_host needs stats");
         WW_HIP(hipHostGetDevicePointer((void **)&stats_host_dev, stats_host, 0));   // fails for pageable memory
     }
+    if (stats_host_alt) {
+        WW_REQUIRE(stats_host != nullptr && ctx->step_ctl != nullptr, WW_E_INVALID,
+                   "ww_clip_optim_step: stats_host_alt needs stats_host and a bound step control block");
+        WW_HIP(hipHostGetDevicePointer((void **)&stats_host_alt_dev, stats_host_alt, 0));
+    }
     WW_REQUIRE(cfg->kind == WW_OPT_ADAM || cfg->kind == WW_OPT_ADAMW || cfg->kind == WW_OPT_SGD, WW_E_INVALID,
                "ww_clip_optim_step: unknown optimizer kind %d", cfg->kind);
     WW_REQUIRE(parity == 0 || parity == 1, WW_E_INVALID, "ww_clip_optim_step: parity must be 0 or 1");
-    WW_REQUIRE(cfg->lr > 0.f, WW_E_INVALID, "Learning rate must be positive, got %g", (double)cfg->lr);
+    WW_REQUIRE(cfg->lr > 0.f || ctx->step_ctl, WW_E_INVALID, "Learning rate must be positive, got %g", (double)cfg->lr);
     WW_REQUIRE(cfg->weight_decay >= 0.f, WW_E_INVALID, "Weight decay must be non-negative, got %g", (double)cfg->weight_decay);
     if (cfg->kind == WW_OPT_SGD) {
         WW_REQUIRE(cfg->momentum >= 0.f && cfg->momentum <= 1.f, WW_E_INVALID, "Momentum must be in [0, 1], got %g",
@@ -194,12 +210,13 @@ extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *f
         WW_REQUIRE(exp_avg && exp_avg_sq, WW_E_INVALID, "ww_clip_optim_step: Adam needs exp_avg and exp_avg_sq");
     }
     if (n == 0) return WW_OK;
-    OptimArgs a{cfg->kind, cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->momentum, cfg->max_norm};
+    OptimArgs a{cfg->kind, cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->momentum, cfg->max_norm,
+                ctx->step_ctl};
     hipStream_t st = (hipStream_t)stream;
     if (n <= (size_t)OPT_EPT * 1024) {
         ww_prof_scope ps_(ctx, WW_K_CLIP, st);
         hipLaunchKernelGGL(k_clip_optim_small, dim3(1), dim3(1024), 0, st, a, flat_params, flat_grads, exp_avg, exp_avg_sq,
-                           n, (long long *)step_state, parity, norm_out, stats, stats_host_dev, found_inf_extra);
+                           n, (long long *)step_state, parity, norm_out, stats, stats_host_dev, stats_host_alt_dev, found_inf_extra);
         WW_LAUNCH_CHECK();
         return WW_OK;
     }
@@ -209,7 +226,8 @@ extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *f
     if (rc) return rc;
     const int grid = (int)std::min<size_t>((n + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(k_optim_update, dim3(grid), dim3(256), 0, st, a, flat_params, flat_grads, exp_avg, exp_avg_sq, n,
-                       (long long *)step_state, parity, ctx->norm_partials, parts, norm_out, stats, stats_host_dev, found_inf_extra);
+                       (long long *)step_state, parity, ctx->norm_partials, parts, norm_out, stats, stats_host_dev,
+                       stats_host_alt_dev, found_inf_extra);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
