@@ -157,6 +157,7 @@ def main():
                     help="BASELINE config 4's input stage: on-GPU RIR convolution + background mix ahead of the log-mel "
                          "(rir_prob 0.25, noise prob 0.5, SNR 5-20 dB: src/config/defaults.py:82-87); not the headline line")
     ap.add_argument("--rir-len", type=int, default=4000, help="RIR taps for --augment (0.25 s at 16 kHz)")
+    ap.add_argument("--dp-overlap", action="store_true", help="two gradient buckets (Trainer.dp_overlap)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as a captured HIP graph (Trainer.enable_hip_graph; not the headline line)")
     args = ap.parse_args()
@@ -211,6 +212,7 @@ def main():
 
     cfg = get_preset("cnn_small_logmel40")
     cfg.training.batch_size = args.batch
+    cfg.training.dp_overlap = args.dp_overlap
     torch.manual_seed(1234)                                   # same initial weights on every rank
     model = create_model("cnn_small", num_classes=2, pretrained=False, dropout=cfg.model.dropout,
                          act_dtype="bf16" if args.dtype == "bf16" else "fp32")
@@ -335,8 +337,9 @@ def main():
                        "global_batch": args.batch * world, "n_samples": N_SAMPLES,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "ranks_seen": dist.get_world_size() if use_dist else 1, "devices": devices,
-                       "collective": (f"{dist.get_backend()} all-reduce (AVG) of the flat gradient bucket in 2 buckets, first "
-                                      "one under the early layers' backward") if use_dist else None,
+                       "collective": (f"{dist.get_backend()} all-reduce (AVG) of the flat gradient bucket, "
+                                      + ("2 buckets, the first under the early layers' backward" if trainer.dp_overlap
+                                         else "in-stream after the backward")) if use_dist else None,
                        "hip_graph": bool(args.graph),
                        "last_loss": None if last is None else round(last[0], 6)},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

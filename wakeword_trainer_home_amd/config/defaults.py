@@ -50,6 +50,7 @@ class TrainingConfig(_Section):
     save_best_only: bool = True
     data_parallel: bool = True                # all-reduce gradients when torch.distributed is initialised
     deferred_metrics: bool = True             # HIP model: read a step's stats while the next step runs
+    dp_overlap: bool = False                  # data parallel: reduce the late layers' gradients under the early layers' backward
     hip_graph: bool = False                   # HIP model: capture the training step once per batch shape, replay it
 
 

@@ -97,11 +97,12 @@ class FlatFusedOptimizer(optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, max_norm: float = 0.0, stats=None, stats_host=None, gathered: bool = False,
-             found_inf_extra=None):
+             found_inf_extra=None, stats_host_alt=None):
         """``max_norm > 0`` also clips (clip_grad_norm_ semantics, in place on the bucket); ``stats`` is the step's
         device ``ww_step_stats`` (found_inf gate, grad_norm output); ``stats_host`` a pinned 48-byte tensor the kernel
         copies it to; ``gathered``: ``flat_grad`` already holds this step's (all-reduced) gradients; ``found_inf_extra``:
-        float32[1] device tensor, non-zero = skip (the all-reduced verdict of the other ranks)."""
+        float32[1] device tensor, non-zero = skip (the all-reduced verdict of the other ranks); ``stats_host_alt``: second
+        pinned buffer, used instead of ``stats_host`` when a bound step control block says parity 1 (graph replay)."""
         if closure is not None:
             raise ValueError("FlatFusedOptimizer does not support closures")
         model = self._model
@@ -123,7 +124,7 @@ class FlatFusedOptimizer(optim.Optimizer):
                 off += n
         self._nat.clip_optim_step_(self._cfg(max_norm), model.flat_param, model.flat_grad, self._m, self._v,
                                    self._step_state, self._parity, norm_out=self.grad_norm, stats=stats,
-                                   stats_host=stats_host, found_inf_extra=found_inf_extra)
+                                   stats_host=stats_host, found_inf_extra=found_inf_extra, stats_host_alt=stats_host_alt)
         self._parity ^= 1
         return None
 

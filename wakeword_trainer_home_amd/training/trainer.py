@@ -130,6 +130,7 @@ class Trainer:
         import torch.distributed as dist
         self._dist = dist if (dist.is_available() and dist.is_initialized()
                               and getattr(config.training, "data_parallel", True)) else None
+        self.dp_overlap = bool(getattr(config.training, "dp_overlap", False))   # two gradient buckets, see _step_native
         self.world_size = self._dist.get_world_size() if self._dist else 1
         self.rank = self._dist.get_rank() if self._dist else 0
         if self._dist:
@@ -222,6 +223,14 @@ class Trainer:
             return self._dist.all_reduce(t, op=self._dist.ReduceOp.AVG, async_op=True), None
         return self._dist.all_reduce(t, async_op=True), t           # gloo (CPU tests) has no AVG
 
+    def _reduce_inline(self, t: torch.Tensor):
+        """Average ``t`` over the ranks on the CURRENT stream (RCCL: no stream hand-off; ordered like any kernel)."""
+        if self._dist.get_backend() == "nccl":
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.AVG)
+        else:
+            self._dist.all_reduce(t)
+            t.div_(self.world_size)
+
     def _reduce_finish(self, handles):
         """The current stream (RCCL) / the host (gloo) waits for the started reductions."""
         for work, t in handles:
@@ -263,7 +272,7 @@ class Trainer:
                 self.native or not any(p.grad is None for p in self.model.parameters())):
             if not self.native:
                 self.model.gather_grads()
-            self._reduce_finish([self._reduce_start(self.model.flat_grad_ext)])
+            self._reduce_inline(self.model.flat_grad_ext)
             return
         buf, views, params = self._pack_buffer()
         have = [(v, p.grad) for v, p in zip(views, params) if p.grad is not None]
@@ -273,7 +282,7 @@ class Trainer:
         if missing:
             torch._foreach_zero_(missing)
         torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        self._reduce_finish([self._reduce_start(buf)])
+        self._reduce_inline(buf)
         torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
 
     def _vote_skip(self, bad: bool) -> bool:
@@ -367,16 +376,22 @@ class Trainer:
         if not self._dist:
             stats = self.model.train_step_native(inputs, targets, self.criterion)     # fwd, loss, bwd: three C-ABI calls
         else:
-            # two gradient buckets: blocks 2, 3 + classifier (+ the found_inf slot) are reduced on the
-            # collective's stream while the backward of blocks 1, 0 and the stem runs; only the second, smaller
-            # reduction is exposed.  The clip needs the REDUCED gradients of both, so the optimizer waits for both.
+            # The skip flag rides in the bucket's spare last float.  Default: ONE in-stream all-reduce of the whole bucket
+            # after the backward -- on this stack a collective issued on the step's own stream costs its latency only
+            # (2 us at one rank), while every hand-off to the collective's stream and back stalls the main queue ~20 us
+            # (profiles/r02_allreduce_microbench.json), more than an 82 KB bucket can hide.  dp_overlap=True selects the
+            # two-bucket form: blocks 2, 3 + classifier reduced on RCCL's stream under the backward of
+            # blocks 1, 0 and the stem -- for buckets large enough to be worth two hand-offs.
             self.model._prepare(inputs.device)
             ext, cut, handles = self.model.flat_grad_ext, self.model.late_offset, []
             flag = ext[-1:]
-            stats = self.model.train_step_native(inputs, targets, self.criterion, found_inf_out=flag,
-                                                 mid_hook=lambda: handles.append(self._reduce_start(ext[cut:])))
-            if cut > 0:
+            if self.dp_overlap and cut > 0:
+                stats = self.model.train_step_native(inputs, targets, self.criterion, found_inf_out=flag,
+                                                     mid_hook=lambda: handles.append(self._reduce_start(ext[cut:])))
                 handles.append(self._reduce_start(ext[:cut]))
+            else:
+                stats = self.model.train_step_native(inputs, targets, self.criterion, found_inf_out=flag)
+                self._reduce_inline(ext)
             self._reduce_finish(handles)
         if self._host_bufs is None:
             self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
@@ -477,13 +492,10 @@ class Trainer:
                 if not self._dist:
                     stats = self.model.train_step_native(g["feats_cur"], g["tgt_cur"], self.criterion)
                 else:
-                    ext, cut, handles = self.model.flat_grad_ext, self.model.late_offset, []
+                    ext = self.model.flat_grad_ext
                     flag = ext[-1:]
-                    stats = self.model.train_step_native(g["feats_cur"], g["tgt_cur"], self.criterion, found_inf_out=flag,
-                                                         mid_hook=lambda: handles.append(self._reduce_start(ext[cut:])))
-                    if cut > 0:
-                        handles.append(self._reduce_start(ext[:cut]))
-                    self._reduce_finish(handles)
+                    stats = self.model.train_step_native(g["feats_cur"], g["tgt_cur"], self.criterion, found_inf_out=flag)
+                    self._reduce_inline(ext)
                 self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats,
                                     stats_host=self._host_bufs[0], stats_host_alt=self._host_bufs[1], found_inf_extra=flag)
                 if waveform:
@@ -567,7 +579,7 @@ class Trainer:
             # update + the 48-byte statistics record in one launch -- as the native cnn_small step does
             self.model.gather_grads()
             if self._dist:
-                self._reduce_finish([self._reduce_start(self.model.flat_grad_ext)])
+                self._reduce_inline(self.model.flat_grad_ext)
             self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats, stats_host=buf, gathered=True,
                                 found_inf_extra=flag)
         else:
