@@ -22,6 +22,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before HIP initialises; see wakeword_trainer_home_amd/__init__.py
 
 N_SAMPLES = 24000            # 16 kHz x 1.5 s
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the achievable copy rate
@@ -248,7 +249,7 @@ def main():
             prepare(i)
         prep = staged.pop(i)
         prepare(i + 1)                                    # one batch of lookahead, as Trainer.train_epoch does
-        for done in trainer._step_native(None, None, i, prepared=prep, lookahead=staged[i + 1]):   # results arrive one step late
+        for done in trainer._step_native(None, None, i, prepared=prep):   # results arrive one step late
             trainer.state.global_step += 1
             last_done[0] = done
 

@@ -70,14 +70,6 @@ def _checkpoint_safe_globals():
     return [TrainingState, collections.OrderedDict, collections.defaultdict, dict] + cfg_classes
 
 
-class _GraphBatch:
-    """A staged batch whose input stage runs inside the replayed HIP graph (see Trainer._graph_capture)."""
-    __slots__ = ("inputs", "targets", "index")
-
-    def __init__(self, inputs, targets, index):
-        self.inputs, self.targets, self.index = inputs, targets, index
-
-
 _HISTORY_KEYS = ("train_loss", "train_acc", "val_loss", "val_acc", "val_f1", "val_fpr", "val_fnr", "learning_rates")
 _SAVE_EVERY = {"every_epoch": 1, "every_5_epochs": 5, "every_10_epochs": 10}
 
@@ -160,7 +152,7 @@ class Trainer:
         # HIP graph replay of the native step (BASELINE config 5 "hipGraph-captured step"; see _graph_capture)
         self.use_hip_graph = bool(getattr(config.training, "hip_graph", False))
         self._graph = None                 # dict: captured graph + its static buffers + host mirror of the control block
-        self._graph_src = None             # (raw inputs, targets) of the last eagerly prepared batch: the shapes to capture
+        self._graph_seen = None            # feature shape of the last eager step (a shape is captured when it repeats)
         self._eager_native_steps = 0
         self.audio_augmentation = None     # data.augmentation.AudioAugmentation; applied to (B,N) training batches
         logger.info("Trainer initialized (device=%s, model=%s, native=%s, optimizer=%s, scheduler=%s, loss=%s, "
@@ -341,12 +333,6 @@ class Trainer:
         front end is LDS/latency-bound, the two overlap well.  Returns (features, targets, ready_event, step_index)."""
         if self._in_stream is None:
             self._in_stream = torch.cuda.Stream(device=self.device)
-        g = self._graph
-        if g is not None and tuple(inputs.shape) == g["in_shape"] and inputs.dtype == g["in_dtype"] \
-                and tuple(targets.shape) == (g["in_shape"][0],) and self.model.act == g["act"] and self.use_hip_graph:
-            return _GraphBatch(inputs, targets, step_index)     # the replayed graph runs this batch's input stage itself
-        if self.use_hip_graph and self._graph is None:
-            self._graph_src = (inputs, targets)
         with torch.cuda.stream(self._in_stream):
             if inputs.dim() == 2:
                 feats = self._features(inputs, training=True, step=step_index)
@@ -357,19 +343,19 @@ class Trainer:
             ready.record(self._in_stream)
         return feats, tg, ready, step_index
 
-    def _step_native(self, inputs, targets, batch_idx, prepared=None, lookahead=None):
-        """Launch one native step; returns the list of steps whose results became available.  ``lookahead``: what
-        ``_prepare_native`` returned for the NEXT batch (graph mode feeds it to the replay's input-stage branch)."""
+    def _step_native(self, inputs, targets, batch_idx, prepared=None):
+        """Launch one native step; returns the list of steps whose results became available."""
         if prepared is None:
             prepared = self._prepare_native(inputs, targets, self._begin_step())
-        if isinstance(prepared, _GraphBatch):
-            return self._step_native_graph(prepared, batch_idx, lookahead)
         inputs, targets, ready, step_index = prepared
         self._begin_step(step_index)               # dropout draws from the same counter as the batch's SpecAugment
         main = torch.cuda.current_stream(self.device)
         main.wait_event(ready)
         inputs.record_stream(main)
         targets.record_stream(main)
+        g = self._graph
+        if g is not None and self.use_hip_graph and tuple(inputs.shape) == g["in_shape"] and self.model.act == g["act"]:
+            return self._step_native_graph(inputs, targets, step_index, batch_idx)
         self.model.sample_offset = self.rank * inputs.shape[0]
         self.optimizer.zero_grad(set_to_none=True)
         flag = None
@@ -423,8 +409,11 @@ class Trainer:
         event.record()
         launched = (batch_idx, buf, event)
         self._eager_native_steps += 1
-        if self.use_hip_graph and self._graph is None and self._fused_optimizer and self._graph_src is not None:
-            self._graph_capture(*self._graph_src)   # tables, workspaces and buckets are warm after this eager step
+        if self.use_hip_graph and self._fused_optimizer and (self._graph is None or self._graph["in_shape"] != tuple(inputs.shape)
+                                                             or self._graph["act"] != self.model.act):
+            if self._graph_seen == tuple(inputs.shape):
+                self._graph_capture(inputs)        # second batch of this shape: workspaces and buckets are warm
+            self._graph_seen = tuple(inputs.shape)
         if not self._skip_on_device:               # optimizer cannot skip on the device: decide on the host
             r = self._resolve(launched)
             if r is None:
@@ -440,52 +429,34 @@ class Trainer:
         return done
 
     # ------------------------------------------------------------------------------- HIP graph replay of the native step
-    def _graph_capture(self, inputs, targets):
-        """Capture ONE training step for batches shaped like ``inputs`` / ``targets`` as a HIP graph:
+    def _graph_capture(self, feats):
+        """Capture ONE training step for feature batches shaped like ``feats`` as a HIP graph:
 
-            ww_step_ctl_advance                                   (step += 1, parity ^= 1 in the device control block)
-            +-- side branch (waveform batches): fused log-mel + SpecAugment [+ RIR / noise mix] of the NEXT batch,
-            |                                   Philox step = ctl.step + 1, from wave_next -> feats_next
-            +-- main branch: cnn_small forward -> loss -> backward [-> all-reduce] -> fused clip + optimizer on
-            |                feats_cur / tgt_cur, Philox step = ctl.step, lr and step_state slot from the control block
-            join; feats_cur <- feats_next, tgt_cur <- tgt_next          (so the next replay trains the batch staged now)
+            ww_step_ctl_advance   (step += 1, parity ^= 1 in the device control block)
+            cnn_small forward -> loss -> backward [-> all-reduce] -> fused clip + optimizer  on feats_cur / tgt_cur,
+            dropout's Philox step, the learning rate and the optimizer's step_state slot read from the control block
 
-        Everything a step changes from one replay to the next lives in device memory (include/wwhip.h ww_step_ctl);
-        the host only copies the next batch into wave_next / tgt_next and replays.  Replayed steps are bit-identical
-        to eager ones (tests/test_hip_graph.py)."""
+        Everything a step changes from one replay to the next lives in device memory (include/wwhip.h ww_step_ctl); the
+        host copies the batch into the static buffers and replays.  The input stage (log-mel + SpecAugment of the NEXT
+        batch) stays a host-issued launch on the side stream: a fork inside the graph does not run concurrently with
+        the main branch on this stack (measured), the side stream does.  Replayed steps are bit-identical to
+        eager ones (tests/test_hip_graph.py)."""
         dev = torch.device(self.device)
-        main = torch.cuda.current_stream(dev)
-        waveform = inputs.dim() == 2
-        B = inputs.shape[0]
-        g = {"in_shape": tuple(inputs.shape), "in_dtype": inputs.dtype, "waveform": waveform}
-        if waveform:
-            g["wave_next"] = torch.zeros(inputs.shape, dtype=inputs.dtype, device=dev)
-            g["tgt_next"] = torch.zeros(B, dtype=torch.int64, device=dev)
-            probe = self._features(g["wave_next"], training=True, step=0)        # also warms the feature tables
-            g["feats_cur"] = torch.zeros_like(probe)
-        else:
-            g["feats_cur"] = torch.zeros(inputs.shape, dtype=torch.float32, device=dev)
+        B = feats.shape[0]
+        g = {"in_shape": tuple(feats.shape), "act": self.model.act}
+        g["feats_cur"] = torch.zeros(feats.shape, dtype=torch.float32, device=dev)
         g["tgt_cur"] = torch.zeros(B, dtype=torch.int64, device=dev)
         g["ctl"] = nat.step_ctl_new(dev, step=0, lr=get_learning_rate(self.optimizer), parity=0)
         g["step"], g["parity"], g["lr"] = 0, 0, get_learning_rate(self.optimizer)
-        g["feats_index"] = None
-        if self._host_bufs is None:
-            self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
         opt_parity, tracked = self.optimizer._parity, self.model._pending_tracked
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
         nat.bind_step_ctl(dev, g["ctl"])           # launches issued while bound read step / lr / parity from the block
         try:
             with torch.cuda.graph(graph):
-                cap = torch.cuda.current_stream(dev)
                 nat.step_ctl_advance(dev)
-                if waveform:
-                    side = self._in_stream
-                    side.wait_stream(cap)
-                    with torch.cuda.stream(side):
-                        feats_next = self._features(g["wave_next"], training=True, step=1)   # offsets while bound
                 for m in self._dropout_modules:
-                    m.dropout_step = 0
+                    m.dropout_step = 0             # an OFFSET while the block is bound
                 self.model.sample_offset = self.rank * B
                 self.optimizer.zero_grad(set_to_none=True)
                 flag = None
@@ -498,38 +469,23 @@ class Trainer:
                     self._reduce_inline(ext)
                 self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats,
                                     stats_host=self._host_bufs[0], stats_host_alt=self._host_bufs[1], found_inf_extra=flag)
-                if waveform:
-                    cap.wait_stream(side)
-                    g["feats_cur"].copy_(feats_next)
-                    g["tgt_cur"].copy_(g["tgt_next"])
         finally:
             nat.bind_step_ctl(dev, None)
             self.optimizer._parity, self.model._pending_tracked = opt_parity, tracked     # capturing ran nothing
             for p_ in self.model._plist:           # .grad stay the views of the flat bucket every replay writes
                 p_.grad = self.model._grad_views[id(p_)]
         g["graph"] = graph
-        g["act"] = self.model.act
         # buffers the graph's nodes point at but that were allocated outside its memory pool: keep them alive with it
         g["keepalive"] = [slot["buf"] for slot in self.model._ws.values()] + [self.model.flat_grad_ext, self.model.flat_param,
                                                                               self.criterion.last_stats] + self._host_bufs
         self._graph = g
-        logger.info("HIP graph captured for the native step (inputs %s %s)", g["in_shape"], g["in_dtype"])
+        logger.info("HIP graph captured for the native step (features %s)", g["in_shape"])
 
-    def _step_native_graph(self, batch, batch_idx, lookahead):
-        """Replay the captured step for ``batch`` (a _GraphBatch); ``lookahead`` = the next _GraphBatch or anything else."""
-        g, dev = self._graph, torch.device(self.device)
-        idx = batch.index
-        nxt = lookahead if (g["waveform"] and isinstance(lookahead, _GraphBatch)) else None
-        if g["feats_index"] != idx:
-            # this batch's input stage was not part of the previous replay (first step, after an eager step): run it here
-            if g["waveform"]:
-                g["feats_cur"].copy_(self._features(batch.inputs, training=True, step=idx))
-            else:
-                g["feats_cur"].copy_(batch.inputs.to(dev, non_blocking=True))
-            g["tgt_cur"].copy_(batch.targets.to(dev, non_blocking=True))
-        if nxt is not None:
-            g["wave_next"].copy_(nxt.inputs.to(dev, non_blocking=True))
-            g["tgt_next"].copy_(nxt.targets.to(dev, non_blocking=True))
+    def _step_native_graph(self, feats, targets, idx, batch_idx):
+        """Replay the captured step on this batch (its input stage has been waited for on the current stream)."""
+        g = self._graph
+        g["feats_cur"].copy_(feats)
+        g["tgt_cur"].copy_(targets)
         # host mirror of the control block: rewritten only when it would be wrong (lr change, eager step in between)
         lr = get_learning_rate(self.optimizer)
         before = ((idx - 1) & 0xFFFFFFFFFFFFFFFF, self.optimizer._parity ^ 1)
@@ -538,14 +494,11 @@ class Trainer:
         if g["lr"] != lr:
             nat.step_ctl_write(g["ctl"], lr=lr)
             g["lr"] = lr
-        for m in self._dropout_modules:
-            m.dropout_step = idx + 1
         g["graph"].replay()
         g["step"], g["parity"] = idx & 0xFFFFFFFFFFFFFFFF, self.optimizer._parity
         buf = self._host_bufs[self.optimizer._parity]
         self.optimizer._parity ^= 1
         self.model._pending_tracked += 1
-        g["feats_index"] = nxt.index if nxt is not None else None
         event = torch.cuda.Event()
         event.record()
         launched = (batch_idx, buf, event)
@@ -774,8 +727,7 @@ class Trainer:
                     staged, nxt = stage(nxt), next(it, None)
                 batch_idx, parsed, prep = cur
                 if pipelined:
-                    account(self._step_native(None, None, batch_idx, prepared=prep,
-                                              lookahead=staged[2] if staged is not None else None))
+                    account(self._step_native(None, None, batch_idx, prepared=prep))
                 else:
                     account(step(parsed[0], parsed[1], batch_idx))
             except RuntimeError as e:
