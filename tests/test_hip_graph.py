@@ -98,3 +98,34 @@ def test_nonfinite_batch_is_skipped_inside_a_replay(tmp_path):
     assert [r[0] for r in graph[1]] == [0, 1, 2, 4]
     assert graph[0].optimizer.step_count() == 4 and graph[0].launched_steps == 5
     _assert_same(eager, graph)
+
+
+@pytest.mark.parametrize("arch", ["crnn", "mobilenetv3", "gru"])
+def test_autograd_models_replay_bit_for_bit(tmp_path, arch):
+    """crnn (BASELINE config 5's model), gru and mobilenetv3 run forward / loss / backward through autograd nodes whose
+    bodies are C-ABI launches; with their parameters in one flat bucket the whole step (incl. the gather of the autograd
+    gradients and the fused clip + optimizer) is captured and replayed.  Same bar: bit equality with the eager steps."""
+    from wakeword_trainer_home_amd.data import make_synthetic_batch
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    from wakeword_trainer_home_amd.training.optimizer_factory import FlatFusedOptimizer
+    wave, y = make_synthetic_batch(8 * 5, 24000, seed=6)
+    y[::3] = 1
+    batches = [(wave[8 * i:8 * i + 8], y[8 * i:8 * i + 8]) for i in range(5)]
+    runs = []
+    for graph in (False, True):
+        cfg = _cfg(graph, epochs=2)
+        cfg.optimizer.mixed_precision = False
+        cfg.training.batch_size = 8
+        torch.manual_seed(11)
+        model = create_model(arch, dropout=0.3, dropout_seed=2)
+        t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=tmp_path / f"{arch}{int(graph)}", device=DEV)
+        assert isinstance(t.optimizer, FlatFusedOptimizer) and t._async_autograd
+        rec = []
+        t.add_callback(type("R", (), {"on_batch_end": lambda self, i, l, a: rec.append((i, l, a))})())
+        res = t.train()
+        runs.append((t, rec, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                     copy.deepcopy(t.optimizer.state_dict()), res))
+    assert runs[1][0]._graph is not None and runs[0][0]._graph is None
+    assert len(runs[1][1]) == 10
+    _assert_same(runs[0], runs[1])

@@ -149,13 +149,21 @@ class CNNSmallWakeword(nn.Module):
         # parameters become views of ONE flat fp32 bucket (same order as the gradient bucket): the fused clip+optimizer
         # kernel walks both buckets linearly; state_dict()/load_state_dict() are unaffected (copy_ goes through views)
         plist = [t for t in tensors if isinstance(t, nn.Parameter)]
-        flat = torch.empty(sum(t.numel() for t in plist), dtype=torch.float32, device=dev)
-        off = 0
-        for t in plist:
-            view = flat[off:off + t.numel()].view_as(t)
-            view.copy_(t.data)
-            t.data = view
-            off += t.numel()
+        n_all = sum(t.numel() for t in plist)
+        packed = all(b.data_ptr() == a.data_ptr() + 4 * a.numel() for a, b in zip(plist[:-1], plist[1:]))
+        if packed and plist[0].data.untyped_storage().nbytes() >= 4 * (plist[0].storage_offset() + n_all):
+            # the parameters already sit back to back in one storage, in this order: an enclosing model (CRNNWakeword,
+            # FlatBuckets) has put them into ITS bucket -- adopt that range instead of moving them out again
+            flat = torch.empty(0, dtype=torch.float32, device=dev).set_(plist[0].data.untyped_storage(),
+                                                                         plist[0].storage_offset(), (n_all,))
+        else:
+            flat = torch.empty(n_all, dtype=torch.float32, device=dev)
+            off = 0
+            for t in plist:
+                view = flat[off:off + t.numel()].view_as(t)
+                view.copy_(t.data)
+                t.data = view
+                off += t.numel()
         self._flat_param = flat
         key = tuple(0 if t is None else t.data_ptr() for t in tensors)
         self._pkey = key

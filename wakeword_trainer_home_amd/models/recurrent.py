@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native as nat
+from .flat_buckets import FlatBuckets
 from .heads import MFMALinear
 
 
@@ -183,7 +184,10 @@ class _DropFn(torch.autograd.Function):
         return dg, None, None, None, None
 
 
-class CRNNWakeword(nn.Module):
+class CRNNWakeword(FlatBuckets, nn.Module):
+    # FlatBuckets: all 45 parameter tensors are views of one fp32 bucket (the conv front-end adopts its range of it), so the
+    # step ends in the fused clip + optimizer launch, data-parallel training all-reduces one tensor, and the whole step can
+    # be captured as a HIP graph (Trainer._graph_capture)
     hip_backed = True      # every op is a HIP kernel of this build: the Trainer may run its sync-free step (no host reads)
 
     """Conv front-end + GRU (BASELINE config 5's model; the reference has no CRNN -- SURVEY.md F4 -- so the topology is this
@@ -196,7 +200,7 @@ class CRNNWakeword(nn.Module):
         super().__init__()
         from .architectures import CNNSmallWakeword
         self.front = CNNSmallWakeword(num_classes=2, dropout=0.0, act_dtype=act_dtype, features_only=True)
-        self.rnn = GRUWakeword(input_size=CNNSmallWakeword.CH, hidden_size=hidden_size, num_layers=num_layers,
+        self.rnn = _GRUWakewordBase(input_size=CNNSmallWakeword.CH, hidden_size=hidden_size, num_layers=num_layers,
                                num_classes=num_classes, bidirectional=bidirectional, dropout=dropout, dropout_seed=dropout_seed,
                                mode="bf16" if nat.act_code(act_dtype) == nat.ACT_BF16 else "fp32")
 
@@ -213,7 +217,7 @@ class CRNNWakeword(nn.Module):
         return self.rnn(self.front(x))
 
 
-class GRUWakeword(nn.Module):
+class _GRUWakewordBase(nn.Module):
     hip_backed = True
 
     def __init__(self, input_size: int = 40, hidden_size: int = 128, num_layers: int = 2, num_classes: int = 2,
@@ -244,3 +248,8 @@ class GRUWakeword(nn.Module):
         if self.training and self.gru.dropout == 0 and self.fc[0].p > 0:
             self.gru.dropout_step += 1                      # single-layer stacks: the fc dropout alone advances the stream
         return self.fc(h)
+
+
+class GRUWakeword(FlatBuckets, _GRUWakewordBase):
+    """The reference's class name; as a top-level model its parameters live in one flat bucket (fused clip + optimizer, one
+    all-reduce, graph-capturable step).  Inside ``CRNNWakeword`` the plain base is used -- the CRNN owns the bucket."""

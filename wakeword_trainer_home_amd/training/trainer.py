@@ -353,9 +353,9 @@ class Trainer:
         main.wait_event(ready)
         inputs.record_stream(main)
         targets.record_stream(main)
-        g = self._graph
-        if g is not None and self.use_hip_graph and tuple(inputs.shape) == g["in_shape"] and self.model.act == g["act"]:
-            return self._step_native_graph(inputs, targets, step_index, batch_idx)
+        replayed = self._graph_step_or_capture(inputs, targets, step_index, batch_idx)
+        if replayed is not None:
+            return replayed
         self.model.sample_offset = self.rank * inputs.shape[0]
         self.optimizer.zero_grad(set_to_none=True)
         flag = None
@@ -381,7 +381,8 @@ class Trainer:
             self._reduce_finish(handles)
         if self._host_bufs is None:
             self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
-        buf = self._host_bufs[self._buf_i]
+        # two pinned records, alternating: the fused optimizer's slot parity picks one (the same rule a graph replay follows)
+        buf = self._host_bufs[self.optimizer._parity if self._fused_optimizer else self._buf_i]
         self._buf_i ^= 1
         if self._fused_optimizer:
             # clip_gradients + "skip a non-finite batch" + optimizer.step() (trainer.py:177-193) in ONE launch, which also
@@ -409,11 +410,7 @@ class Trainer:
         event.record()
         launched = (batch_idx, buf, event)
         self._eager_native_steps += 1
-        if self.use_hip_graph and self._fused_optimizer and (self._graph is None or self._graph["in_shape"] != tuple(inputs.shape)
-                                                             or self._graph["act"] != self.model.act):
-            if self._graph_seen == tuple(inputs.shape):
-                self._graph_capture(inputs)        # second batch of this shape: workspaces and buckets are warm
-            self._graph_seen = tuple(inputs.shape)
+        self._graph_after_eager(inputs)
         if not self._skip_on_device:               # optimizer cannot skip on the device: decide on the host
             r = self._resolve(launched)
             if r is None:
@@ -443,41 +440,52 @@ class Trainer:
         eager ones (tests/test_hip_graph.py)."""
         dev = torch.device(self.device)
         B = feats.shape[0]
-        g = {"in_shape": tuple(feats.shape), "act": self.model.act}
+        g = {"in_shape": tuple(feats.shape), "act": self._graph_mode_key()}
         g["feats_cur"] = torch.zeros(feats.shape, dtype=torch.float32, device=dev)
         g["tgt_cur"] = torch.zeros(B, dtype=torch.int64, device=dev)
         g["ctl"] = nat.step_ctl_new(dev, step=0, lr=get_learning_rate(self.optimizer), parity=0)
         g["step"], g["parity"], g["lr"] = 0, 0, get_learning_rate(self.optimizer)
-        opt_parity, tracked = self.optimizer._parity, self.model._pending_tracked
+        # host-side counters the captured Python code bumps (capturing runs nothing on the device): BatchNorm's pending
+        # num_batches_tracked of the conv stack -- restored here, re-applied per replay
+        counted = [m for m in self.model.modules() if hasattr(m, "_pending_tracked")]
+        opt_parity, tracked = self.optimizer._parity, [m._pending_tracked for m in counted]
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
         nat.bind_step_ctl(dev, g["ctl"])           # launches issued while bound read step / lr / parity from the block
+        max_norm = max(float(self.gradient_clip), 0.0)
         try:
             with torch.cuda.graph(graph):
                 nat.step_ctl_advance(dev)
                 for m in self._dropout_modules:
                     m.dropout_step = 0             # an OFFSET while the block is bound
-                self.model.sample_offset = self.rank * B
+                if hasattr(self.model, "sample_offset"):
+                    self.model.sample_offset = self.rank * B
                 self.optimizer.zero_grad(set_to_none=True)
-                flag = None
-                if not self._dist:
-                    stats = self.model.train_step_native(g["feats_cur"], g["tgt_cur"], self.criterion)
-                else:
-                    ext = self.model.flat_grad_ext
-                    flag = ext[-1:]
+                flag = self.model.flat_grad_ext[-1:] if self._dist else None
+                if self.native:
                     stats = self.model.train_step_native(g["feats_cur"], g["tgt_cur"], self.criterion, found_inf_out=flag)
-                    self._reduce_inline(ext)
-                self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats,
-                                    stats_host=self._host_bufs[0], stats_host_alt=self._host_bufs[1], found_inf_extra=flag)
+                else:                              # HIP-backed autograd model (crnn, gru, mobilenetv3) with flat buckets
+                    self.criterion.found_inf_out = flag
+                    self.criterion(self.model(g["feats_cur"]), g["tgt_cur"]).backward()
+                    stats = self.criterion.last_stats
+                    self.model.gather_grads()
+                if self._dist:
+                    self._reduce_inline(self.model.flat_grad_ext)
+                self.optimizer.step(max_norm=max_norm, stats=stats, stats_host=self._host_bufs[0],
+                                    stats_host_alt=self._host_bufs[1], found_inf_extra=flag, gathered=not self.native)
         finally:
             nat.bind_step_ctl(dev, None)
-            self.optimizer._parity, self.model._pending_tracked = opt_parity, tracked     # capturing ran nothing
-            for p_ in self.model._plist:           # .grad stay the views of the flat bucket every replay writes
-                p_.grad = self.model._grad_views[id(p_)]
+            self.optimizer._parity = opt_parity    # capturing ran nothing
+            g["tracked"] = [(m, m._pending_tracked - t0) for m, t0 in zip(counted, tracked)]
+            for m, t0 in zip(counted, tracked):
+                m._pending_tracked = t0
+            if self.native:
+                for p_ in self.model._plist:       # .grad stay the views of the flat bucket every replay writes
+                    p_.grad = self.model._grad_views[id(p_)]
         g["graph"] = graph
         # buffers the graph's nodes point at but that were allocated outside its memory pool: keep them alive with it
-        g["keepalive"] = [slot["buf"] for slot in self.model._ws.values()] + [self.model.flat_grad_ext, self.model.flat_param,
-                                                                              self.criterion.last_stats] + self._host_bufs
+        g["keepalive"] = [self.model.flat_grad_ext, self.model.flat_param, self.criterion.last_stats] + self._host_bufs
+        g["keepalive"] += [slot["buf"] for m in self.model.modules() if hasattr(m, "_ws") for slot in m._ws.values()]
         self._graph = g
         logger.info("HIP graph captured for the native step (features %s)", g["in_shape"])
 
@@ -498,7 +506,8 @@ class Trainer:
         g["step"], g["parity"] = idx & 0xFFFFFFFFFFFFFFFF, self.optimizer._parity
         buf = self._host_bufs[self.optimizer._parity]
         self.optimizer._parity ^= 1
-        self.model._pending_tracked += 1
+        for m, d in g["tracked"]:
+            m._pending_tracked += d
         event = torch.cuda.Event()
         event.record()
         launched = (batch_idx, buf, event)
@@ -509,12 +518,39 @@ class Trainer:
         self._pending = launched
         return done
 
+    def _graph_mode_key(self):
+        """What a captured graph bakes besides shapes: the storage / matrix modes of the model's HIP modules."""
+        return tuple((getattr(m, "act", None), str(getattr(m, "mode", None))) for m in self.model.modules()
+                     if hasattr(m, "act") or hasattr(m, "mode"))
+
+    def _graph_step_or_capture(self, feats, targets, step_index, batch_idx):
+        """Graph mode of a sync-free step: replay when a graph for this feature shape exists, else None (the caller runs
+        the eager step; ``_graph_after_eager`` then captures a shape the second time it is seen)."""
+        g = self._graph
+        if g is not None and self.use_hip_graph and tuple(feats.shape) == g["in_shape"] and g["act"] == self._graph_mode_key():
+            return self._step_native_graph(feats, targets, step_index, batch_idx)
+        return None
+
+    def _graph_after_eager(self, feats):
+        if not (self.use_hip_graph and self._fused_optimizer):
+            return
+        shape = tuple(feats.shape)
+        if self._graph is None or self._graph["in_shape"] != shape or self._graph["act"] != self._graph_mode_key():
+            if self._graph_seen == shape:
+                self._graph_capture(feats)         # second batch of this shape: workspaces, tables and buckets are warm
+            self._graph_seen = shape
+
     def _step_autograd_async(self, inputs, targets, batch_idx):
         """Training step of a HIP-backed autograd model without host reads: forward / native loss / backward through
         autograd, gradient all-reduce, clip_grad_norm_ and the "skip a non-finite batch" decision on the device (the
         fused optimizer takes it as found_inf), statistics resolved one step later."""
-        inputs = self._to_model_input(inputs, training=True, step=self._begin_step())
+        step_index = self._begin_step()
+        inputs = self._to_model_input(inputs, training=True, step=step_index)
         targets = targets.to(self.device, non_blocking=True)
+        if inputs.dim() == 4 and inputs.is_cuda and self._fused_optimizer:
+            replayed = self._graph_step_or_capture(inputs.contiguous(), targets, step_index, batch_idx)
+            if replayed is not None:
+                return replayed
         if hasattr(self.model, "sample_offset"):
             self.model.sample_offset = self.rank * inputs.shape[0]
         self.optimizer.zero_grad(set_to_none=True)
@@ -525,7 +561,8 @@ class Trainer:
         stats = self.criterion.last_stats
         if self._host_bufs is None:
             self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
-        buf = self._host_bufs[self._buf_i]
+        # two pinned records, alternating: the fused optimizer's slot parity picks one (the same rule a graph replay follows)
+        buf = self._host_bufs[self.optimizer._parity if self._fused_optimizer else self._buf_i]
         self._buf_i ^= 1
         if self._fused_optimizer:
             # flat buckets (models/flat_buckets.py): gather the autograd gradients, ONE all-reduce, then clip + skip +
@@ -555,6 +592,8 @@ class Trainer:
         event = torch.cuda.Event()
         event.record()
         launched = (batch_idx, buf, event)
+        if inputs.dim() == 4 and inputs.is_cuda:
+            self._graph_after_eager(inputs)
         if not self.deferred_metrics:
             r = self._resolve(launched)
             return [] if r is None else [r]
