@@ -449,6 +449,11 @@ class Trainer:
         # num_batches_tracked of the conv stack -- restored here, re-applied per replay
         counted = [m for m in self.model.modules() if hasattr(m, "_pending_tracked")]
         opt_parity, tracked = self.optimizer._parity, [m._pending_tracked for m in counted]
+        # a fork inside a captured graph does not run beside the main branch on this stack (measured: CRNN B=512 7.59 ms
+        # forked vs 7.15 ms serial vs 5.38 ms eager with the GRU directions on two streams), so capture them in line
+        forked = [m for m in self.model.modules() if getattr(m, "overlap_directions", False)]
+        for m in forked:
+            m.overlap_directions = False
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(dev)
         nat.bind_step_ctl(dev, g["ctl"])           # launches issued while bound read step / lr / parity from the block
@@ -475,6 +480,8 @@ class Trainer:
                                     stats_host_alt=self._host_bufs[1], found_inf_extra=flag, gathered=not self.native)
         finally:
             nat.bind_step_ctl(dev, None)
+            for m in forked:
+                m.overlap_directions = True
             self.optimizer._parity = opt_parity    # capturing ran nothing
             g["tracked"] = [(m, m._pending_tracked - t0) for m, t0 in zip(counted, tracked)]
             for m, t0 in zip(counted, tracked):
@@ -556,9 +563,8 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         flag = self._dp_flag_slot()                # the loss kernel drops its skip flag behind the gradient bucket
         self.criterion.found_inf_out = flag
-        loss = self.criterion(self.model(inputs), targets)
-        loss.backward()
-        stats = self.criterion.last_stats
+        self.criterion(self.model(inputs), targets).backward()     # no reference to the autograd graph survives this line: a
+        stats = self.criterion.last_stats                          # later graph capture needs fresh AccumulateGrad nodes
         if self._host_bufs is None:
             self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
         # two pinned records, alternating: the fused optimizer's slot parity picks one (the same rule a graph replay follows)
