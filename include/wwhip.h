@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 6
+#define WW_ABI_VERSION 7
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -161,6 +161,8 @@ typedef struct {
 #define WW_C 64              /* channel width of the conv stack */
 #define WW_ACT_F32 0         /* storage type of the activation tensors y_l / g_l (void* arguments) */
 #define WW_ACT_BF16 1
+#define WW_ACT_F16 2         /* fp16 storage / matrix operands: the reference's own AMP type (fp16 autocast + GradScaler,
+                                src/training/trainer.py:172,182-193); gradients carry the loss scale (ww_loss_scale) */
 #define WW_MAX_PARTIALS 1024 /* rows of a reduction slab */
 /* scratch for one layer call: partial-sum slabs */
 size_t ww_layer_scratch_bytes(void);
@@ -252,12 +254,29 @@ typedef struct {
                            (trainer.py:177-179) needs no host round trip before optimizer.step(). */
     int32_t reserved;
 } ww_step_stats;
+/* Dynamic loss scaling of the fp16 storage mode (WW_ACT_F16) -- torch.amp.GradScaler's state and update rule
+ * (create_grad_scaler, src/training/optimizer_factory.py:403-420; scale -> unscale_ -> step -> update,
+ * src/training/trainer.py:182-193) kept and advanced on the DEVICE: ww_ce2_loss_fwd_bwd multiplies dL/dlogits by
+ * scale[slot], every gradient down to the flat bucket then carries that factor, ww_clip_optim_step divides it out before the
+ * norm / clip / update, and writes scale[slot^1], growth_tracker[slot^1]: non-finite gradients -> scale * backoff_factor and
+ * the step is skipped; an applied step -> tracker + 1, and scale * growth_factor once it reaches growth_interval; a batch
+ * skipped for its loss or targets leaves both unchanged.  slot alternates like ww_clip_optim_step's parity (it IS that parity).
+ * GradScaler's defaults: scale 65536, growth 2, backoff 0.5, interval 2000.                                            */
+typedef struct {
+    float scale[2];
+    int32_t growth_tracker[2];
+    float growth_factor, backoff_factor;
+    int32_t growth_interval;
+    int32_t reserved;
+} ww_loss_scale;
 /* found_inf_out (nullable): receives stats->found_inf as a float of its own -- a data-parallel caller points it at the
  * spare last element of its flat gradient bucket, so the all-reduce of the gradients also tells every rank that SOME rank
- * must skip this batch (ww_clip_optim_step's found_inf_extra reads it back). */
+ * must skip this batch (ww_clip_optim_step's found_inf_extra reads it back).  loss_scale (nullable) / loss_scale_slot: see
+ * ww_loss_scale; with a bound ww_step_ctl the slot is the block's parity.                                              */
 int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64_t *targets, int B, int loss_kind,
                         float label_smoothing, float focal_alpha, float focal_gamma, float *loss_out,
-                        float *dlogits, ww_step_stats *stats, float *found_inf_out, ww_stream_t stream);
+                        float *dlogits, ww_step_stats *stats, float *found_inf_out, const ww_loss_scale *loss_scale,
+                        int loss_scale_slot, ww_stream_t stream);
 /* Replaces clip_gradients -> torch.nn.utils.clip_grad_norm_
  * (src/training/optimizer_factory.py:446-452) on one flat gradient bucket.  max_norm <= 0:
  * only the norm is computed.  norm_out (nullable) receives the pre-clip L2 norm.          */
@@ -365,7 +384,7 @@ int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *flat_params,
                        ww_step_stats *stats /* nullable */, ww_step_stats *stats_host /* nullable */,
                        ww_step_stats *stats_host_alt /* nullable; see ww_step_ctl */,
                        const float *found_inf_extra /* nullable: != 0 -> skip (another rank's verdict) */,
-                       ww_stream_t stream);
+                       ww_loss_scale *loss_scale /* nullable: fp16 mode, slot = parity */, ww_stream_t stream);
 
 /* ------------------------------------------------------------------ collectives: deliberately NOT in this ABI
  * SURVEY.md §8b sketched two more entry points, `ww_comm_init` (ctx, nccl_unique_id, rank, world) and `ww_allreduce_f32`

@@ -13,9 +13,9 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 BWD_ALL, BWD_LATE, BWD_EARLY = 0, 1, 2
-ACT_F32, ACT_BF16 = 0, 1
+ACT_F32, ACT_BF16, ACT_F16 = 0, 1, 2
 LOSS_CE, LOSS_FOCAL = 0, 1
 WAVE_F32, WAVE_I16 = 0, 1
 CNN_SMALL_NPTR = 47
@@ -68,6 +68,27 @@ class StepCtl(C.Structure):
 STEP_CTL_BYTES = C.sizeof(StepCtl)
 
 
+class LossScale(C.Structure):
+    _fields_ = [("scale", C.c_float * 2), ("growth_tracker", C.c_int32 * 2), ("growth_factor", C.c_float),
+                ("backoff_factor", C.c_float), ("growth_interval", C.c_int32), ("reserved", C.c_int32)]
+
+
+LOSS_SCALE_BYTES = C.sizeof(LossScale)
+
+
+def loss_scale_new(dev, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, growth_tracker=0):
+    """Device ww_loss_scale (uint8[32] tensor) with torch.amp.GradScaler's defaults; both slots start equal."""
+    host = LossScale((C.c_float * 2)(init_scale, init_scale), (C.c_int32 * 2)(growth_tracker, growth_tracker),
+                     growth_factor, backoff_factor, growth_interval, 0)
+    return torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(dev)
+
+
+def loss_scale_read(t, slot=0) -> dict:
+    s = LossScale.from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+    return {"scale": s.scale[slot], "growth_tracker": s.growth_tracker[slot], "growth_factor": s.growth_factor,
+            "backoff_factor": s.backoff_factor, "growth_interval": s.growth_interval}
+
+
 class StepStats(C.Structure):
     _fields_ = [("loss", C.c_float), ("grad_norm", C.c_float), ("correct", C.c_int32), ("tp", C.c_int32),
                 ("tn", C.c_int32), ("fp", C.c_int32), ("fn", C.c_int32), ("nonfinite", C.c_int32),
@@ -113,7 +134,7 @@ _SIGS = {
     "ww_gru_fwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_long, _vp, _vp, _sz, _vp]),
     "ww_gru_bwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, C.c_long, _i,
                              _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ww_layer_scratch_bytes": (_sz, []),
     "ww_conv_stem_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
     "ww_dwconv3x3_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(BN), _vp, _vp, _vp, _vp]),
@@ -132,7 +153,7 @@ _SIGS = {
     "ww_cnn_front_bwd": (C.c_int, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "ww_cnn_small_bwd": (C.c_int, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp, _i, _i, _i, _f, _u64, _u64, _u64,
                                    _vp, _sz, _i, _vp]),
-    "ww_ce2_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ww_ce2_loss_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "ww_grad_norm_clip": (C.c_int, [_vp, _vp, _sz, _f, _vp, _vp, _vp]),
     "ww_prof_num_classes": (C.c_int, []),
     "ww_prof_class_name": (C.c_char_p, [_i]),
@@ -226,21 +247,22 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-_ACT = {torch.float32: ACT_F32, torch.bfloat16: ACT_BF16}
+_ACT = {torch.float32: ACT_F32, torch.bfloat16: ACT_BF16, torch.float16: ACT_F16}
 
 
 def act_code(dtype) -> int:
     """storage type of the conv-stack activation tensors: 'fp32'/torch.float32 or 'bf16'/torch.bfloat16."""
     if isinstance(dtype, str):
         dtype = {"fp32": torch.float32, "f32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
-                 "bfloat16": torch.bfloat16}.get(dtype.lower())
+                 "bfloat16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16, "float16": torch.float16,
+                 "half": torch.float16}.get(dtype.lower())
     if dtype not in _ACT:
-        raise ValueError("activation storage must be float32 or bfloat16")
+        raise ValueError("activation storage must be float32, bfloat16 or float16")
     return _ACT[dtype]
 
 
 def act_torch_dtype(code):
-    return torch.bfloat16 if code == ACT_BF16 else torch.float32
+    return {ACT_BF16: torch.bfloat16, ACT_F16: torch.float16}.get(code, torch.float32)
 
 
 def _stream(dev):
@@ -634,11 +656,11 @@ def step_ctl_advance(dev):
 
 
 def clip_optim_step_(cfg: OptimCfg, flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, parity, norm_out=None,
-                     stats=None, stats_host=None, found_inf_extra=None, stats_host_alt=None):
+                     stats=None, stats_host=None, found_inf_extra=None, stats_host_alt=None, loss_scale=None):
     """In place: clip flat_grads to cfg.max_norm, then one Adam/AdamW/SGD step on flat_params (skipped on found_inf).
     ``stats_host``: pinned uint8[48] host tensor the kernel copies the step's ww_step_stats into.
     ``found_inf_extra``: float32[1] device tensor; non-zero also skips the step (data parallel: some rank's bad batch)."""
-    dev = _dev(flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, norm_out, stats, found_inf_extra)
+    dev = _dev(flat_params, flat_grads, exp_avg, exp_avg_sq, step_state, norm_out, stats, found_inf_extra, loss_scale)
     if stats_host is not None and not (stats_host.is_pinned() and stats_host.numel() * stats_host.element_size() >= STEP_STATS_BYTES):
         raise ValueError("stats_host must be a pinned host tensor of at least 48 bytes")
     if flat_params.dtype != torch.float32 or flat_grads.dtype != torch.float32 or flat_params.numel() != flat_grads.numel():
@@ -650,7 +672,7 @@ def clip_optim_step_(cfg: OptimCfg, flat_params, flat_grads, exp_avg, exp_avg_sq
                                          flat_params.numel(), _p(step_state), parity, _p(norm_out), _p(stats),
                                          None if stats_host is None else C.c_void_p(stats_host.data_ptr()),
                                          None if stats_host_alt is None else C.c_void_p(stats_host_alt.data_ptr()),
-                                         _p(found_inf_extra), _stream(dev)), "ww_clip_optim_step")
+                                         _p(found_inf_extra), _p(loss_scale), _stream(dev)), "ww_clip_optim_step")
 
 
 def layer_scratch(dev):
@@ -816,10 +838,10 @@ def cnn_front_bwd(params, grads, x, dseq, ws, act=ACT_F32):
 
 
 def ce2_loss_fwd_bwd(logits, targets, kind=LOSS_CE, label_smoothing=0.0, focal_alpha=0.25, focal_gamma=2.0,
-                     stats=None, found_inf_out=None):
+                     stats=None, found_inf_out=None, loss_scale=None, loss_scale_slot=0):
     """-> (loss (1,) f32, dlogits (B,2) f32, stats uint8[STEP_STATS_BYTES]).  ``found_inf_out``: float32[1] device tensor
     that also receives the step's found_inf flag (the spare slot of a data-parallel gradient bucket)."""
-    dev = _dev(logits, targets, stats, found_inf_out)
+    dev = _dev(logits, targets, stats, found_inf_out, loss_scale)
     if logits.dim() != 2 or logits.shape[1] != 2 or logits.dtype != torch.float32:
         raise ValueError(f"native loss needs float32 logits of shape (B,2), got {logits.dtype} {tuple(logits.shape)}")
     if targets.dim() != 1 or targets.shape[0] != logits.shape[0] or targets.dtype != torch.int64:
@@ -831,7 +853,8 @@ def ce2_loss_fwd_bwd(logits, targets, kind=LOSS_CE, label_smoothing=0.0, focal_a
         stats = torch.zeros(STEP_STATS_BYTES, dtype=torch.uint8, device=dev)
     with _guard(dev):
         _check(load().ww_ce2_loss_fwd_bwd(ctx(dev), _p(logits), _p(targets), B, kind, label_smoothing, focal_alpha,
-                                          focal_gamma, _p(loss), _p(dl), _p(stats), _p(found_inf_out), _stream(dev)),
+                                          focal_gamma, _p(loss), _p(dl), _p(stats), _p(found_inf_out), _p(loss_scale),
+                                          int(loss_scale_slot), _stream(dev)),
                "ww_ce2_loss_fwd_bwd")
     return loss, dl, stats
 

@@ -100,6 +100,8 @@ class OptimizerConfig(_Section):
     factor: float = 0.5
     gradient_clip: float = 1.0
     mixed_precision: bool = False
+    amp_dtype: str = "bf16"          # HIP models: storage type behind mixed_precision -- "bf16" (no loss scaling needed) or
+                                     # "fp16" (the reference's own AMP type, with the device-side GradScaler)
 
 
 @dataclass

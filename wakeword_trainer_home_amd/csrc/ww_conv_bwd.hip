@@ -251,23 +251,18 @@ __global__ __launch_bounds__(256, 2) void k_pw_bwd(const T *__restrict__ g, cons
 // and yhat of the input layer in the epilogue) and a = relu(bn(y_in)).  dX reads dy rows with ds_read_b128; dW needs
 // its operands pixel-major (K = pixels) and takes them from the same [pixel][channel] tiles with the transposing
 // read ds_read_b64_tr_b16: a 16-lane group reads 4 pixels x 16 channels and lane i receives channel i's 4 pixels.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short short4v __attribute__((ext_vector_type(4)));
-constexpr int PWH_LD = 72;      // bf16 elements per LDS row (144 B)
+constexpr int PWH_LD = 72;      // 16-bit elements per LDS row (144 B)
 
-__device__ __forceinline__ bf16x8 pack8b(const float (&v)[8]) {
-    typedef float f32x8 __attribute__((ext_vector_type(8)));
-    f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-    return __builtin_convertvector(f, bf16x8);
-}
 // A/B operand of a 32x32x16 MFMA whose K index is the PIXEL: channels c0..c0+31 (lane&31), pixels p0 + 8*(lane>>5) .. +7
-__device__ __forceinline__ bf16x8 tr_operand(const ww_bf16 *tile, int p0, int c0, int lane) {
+template <typename H>
+__device__ __forceinline__ typename H16<H>::x8 tr_operand(const H *tile, int p0, int c0, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-    const ww_bf16 *base = tile + (p0 + 8 * (g >> 1) + q) * PWH_LD + c0 + 16 * (g & 1) + 4 * pp;
+    const H *base = tile + (p0 + 8 * (g >> 1) + q) * PWH_LD + c0 + 16 * (g & 1) + 4 * pp;
     typedef short4v __attribute__((address_space(3))) * lds_p;
     const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
     const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * PWH_LD));
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    return __builtin_bit_cast(typename H16<H>::x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 // The layer's own output y_out is NOT read back: it is recomputed from the a tile with the forward kernel's exact
@@ -275,21 +270,22 @@ __device__ __forceinline__ bf16x8 tr_operand(const ww_bf16 *tile, int p0, int c0
 // stored), which trades one activation-tensor read (97 MB at the full batch) for 4 MFMAs per wave and a third barrier.
 // WIDE_IMG: an image has at least one tile of pixels (HW >= 64), so a tile touches at most two images and their pooled
 // gradients are two registers; the per-pixel lookup (a division per element) is compiled only into the other variant.
-template <bool FROM_POOL, bool WIDE_IMG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_pw_bwd_bf16(const ww_bf16 *__restrict__ g, const float *__restrict__ dpool,
+template <typename H, bool FROM_POOL, bool WIDE_IMG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_pw_bwd_bf16(const H *__restrict__ g, const float *__restrict__ dpool,
                                                      const float *__restrict__ ss_out,
-                                                     const float *__restrict__ coef, const ww_bf16 *__restrict__ y_in,
+                                                     const float *__restrict__ coef, const H *__restrict__ y_in,
                                                      const float *__restrict__ ss_in, const float *__restrict__ mr_in,
                                                      const float *__restrict__ w, long M, int HW,
-                                                     ww_bf16 *__restrict__ g_in, float *__restrict__ stat_partials,
+                                                     H *__restrict__ g_in, float *__restrict__ stat_partials,
                                                      float *__restrict__ dw_partials) {
     // dy, a = relu(bn(y_in)), and two y_in tiles (even / odd tile of the unrolled loop): g_in overwrites the raw y_in tile
     // in place and is stored from there while the next tile is staged into the other one.  36.9 KB -> 4 workgroups per CU.
     // + the 64x64 weights (bf16): both MFMA B operands come from this one copy (row reads forward, transposing reads for dX)
-    __shared__ __align__(16) ww_bf16 tiles[5 * PWB_TILE * PWH_LD];
-    ww_bf16 *dyt = tiles, *at = tiles + PWB_TILE * PWH_LD, *yit0 = tiles + 2 * PWB_TILE * PWH_LD, *yit1 = tiles + 3 * PWB_TILE * PWH_LD;
-    ww_bf16 *wtile = tiles + 4 * PWB_TILE * PWH_LD;
-    typedef Act<ww_bf16> A16;
+    __shared__ __align__(16) H tiles[5 * PWB_TILE * PWH_LD];
+    H *dyt = tiles, *at = tiles + PWB_TILE * PWH_LD, *yit0 = tiles + 2 * PWB_TILE * PWH_LD, *yit1 = tiles + 3 * PWB_TILE * PWH_LD;
+    H *wtile = tiles + 4 * PWB_TILE * PWH_LD;
+    typedef Act<H> A16;
+    typedef typename H16<H>::x8 bf16x8;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int rh = wv >> 1, n = wv & 1;   // y/dX: pixels [32rh,+32) x channels [32n,+32); dW: quadrant (jt,kt) = (rh,n)
@@ -300,7 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int i = 0; i < 4; ++i) {
         const int row = (tid >> 4) + 16 * i, c = 4 * (tid & 15);
         const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)row * 64 + c);
-        *reinterpret_cast<uint2 *>(wtile + row * PWH_LD + c) = make_uint2(Act<ww_bf16>::pack2(v.x, v.y), Act<ww_bf16>::pack2(v.z, v.w));
+        *reinterpret_cast<uint2 *>(wtile + row * PWH_LD + c) = make_uint2(A16::pack2(v.x, v.y), A16::pack2(v.z, v.w));
     }
     const int c4 = tid & 15;
     const float cA = coef[ch], cB = coef[64 + ch], cC = coef[128 + ch];
@@ -318,9 +314,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
     const long ntiles = (M + PWB_TILE - 1) / PWB_TILE;
     const long last_img = (M - 1) / HW;
-    A16::raw4 rg0[4], ri0[4];
+    typename A16::raw4 rg0[4], ri0[4];
     float dpA0 = 0.f, dpB0 = 0.f;   // pooled gradient of the (at most two, when HW >= tile) images of a tile
-    auto issue = [&](long ti, A16::raw4 (&rg)[4], A16::raw4 (&ri)[4], float &ndpA, float &ndpB) {
+    auto issue = [&](long ti, typename A16::raw4 (&rg)[4], typename A16::raw4 (&ri)[4], float &ndpA, float &ndpB) {
         if (ti >= ntiles) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -335,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             ndpB = dpool[(size_t)(b0 < last_img ? b0 + 1 : last_img) * 64 + ch];
         }
     };
-    auto tile = [&](long ti, ww_bf16 *yit, A16::raw4 (&rg)[4], A16::raw4 (&ri)[4], float &ndpA, float &ndpB) {
+    auto tile = [&](long ti, H *yit, typename A16::raw4 (&rg)[4], typename A16::raw4 (&ri)[4], float &ndpA, float &ndpB) {
         const long p0 = ti * PWB_TILE;
         const float dpA = ndpA, dpB = ndpB;
 #pragma unroll
@@ -361,7 +357,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int t = 0; t < 4; ++t) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8 *>(at + (rbase + r) * PWH_LD + 16 * t + 8 * h);
                 const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(wtile + ch * PWH_LD + 16 * t + 8 * h);
-                yacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wf, yacc, 0, 0, 0);
+                yacc = H16<H>::mfma32(a, wf, yacc);
             }
             const int p0i = (int)p0, Mi = (int)M;
             const int bnd = FROM_POOL ? (int)(((uint32_t)p0 / (uint32_t)HW + 1u) * (uint32_t)HW) : 0;
@@ -379,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     dz = (float)dyt[prow * PWH_LD + ch];
                 }
                 const float d = okf * fmaf(cA, dz, fmaf(cB, yv, cC));
-                dyt[prow * PWH_LD + ch] = (ww_bf16)d;
+                dyt[prow * PWH_LD + ch] = (H)d;
             }
         }
         __syncthreads();
@@ -390,14 +386,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int t = 0; t < 4; ++t) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8 *>(dyt + (rbase + r) * PWH_LD + 16 * t + 8 * h);
                 const bf16x8 wt = tr_operand(wtile, 16 * t, 32 * n, lane);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wt, acc, 0, 0, 0);
+                acc = H16<H>::mfma32(a, wt, acc);
             }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 const float yv = (float)yit[prow * PWH_LD + ch];
                 const float d = A16::round1(fmaf(yv, sci, sfi) > 0.f ? acc[reg] : 0.f);
-                yit[prow * PWH_LD + ch] = (ww_bf16)d;
+                yit[prow * PWH_LD + ch] = (H)d;
                 st1 += d;
                 st2 = fmaf(d, (yv - mui) * rsi, st2);
             }
@@ -407,7 +403,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int t = 0; t < 4; ++t) {
             const bf16x8 dyop = tr_operand(dyt, 16 * t, 32 * rh, lane);
             const bf16x8 aop = tr_operand(at, 16 * t, 32 * n, lane);
-            dwacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dyop, aop, dwacc, 0, 0, 0);
+            dwacc = H16<H>::mfma32(dyop, aop, dwacc);
         }
         __syncthreads();
 #pragma unroll
@@ -727,26 +723,27 @@ extern "C" int ww_head_bwd(ww_ctx *ctx, const float *dlogits, const float *pd, c
 
 namespace {
 int check_act_b(const char *who, int act_dtype) {
-    WW_REQUIRE(act_dtype == WW_ACT_F32 || act_dtype == WW_ACT_BF16, WW_E_INVALID, "%s: unknown act_dtype %d", who,
+    WW_REQUIRE(act_dtype == WW_ACT_F32 || act_dtype == WW_ACT_BF16 || act_dtype == WW_ACT_F16, WW_E_INVALID, "%s: unknown act_dtype %d", who,
                act_dtype);
     return WW_OK;
 }
 
+template <typename H>
 int launch_pw_bwd_bf16(ww_ctx *ctx, const void *g, const float *dpool, const void *y_out, const float *ss_out,
                        const float *coef, const void *y_in, const float *ss_in, const float *mr_in, const float *w, long M,
                        int HW, void *g_in, float *stat, float *dwp, int *grid_out, hipStream_t st) {
-    typedef const ww_bf16 *cp;
+    typedef const H *cp;
     const long ntiles = (M + PWB_TILE - 1) / PWB_TILE;
     int grid;
     ww_prof_scope ps_(ctx, WW_K_PW_BWD, st);
     auto go = [&](auto kern) {
         grid = ww_occupancy_grid((const void *)kern, 256, 0, ntiles, WW_DW_SLAB_ROWS);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, (cp)g, dpool, ss_out, coef, (cp)y_in, ss_in, mr_in, w, M, HW,
-                           (ww_bf16 *)g_in, stat, dwp);
+                           (H *)g_in, stat, dwp);
     };
-    if (g) go(k_pw_bwd_bf16<false, true>);
-    else if (HW >= PWB_TILE) go(k_pw_bwd_bf16<true, true>);
-    else go(k_pw_bwd_bf16<true, false>);
+    if (g) go(k_pw_bwd_bf16<H, false, true>);
+    else if (HW >= PWB_TILE) go(k_pw_bwd_bf16<H, true, true>);
+    else go(k_pw_bwd_bf16<H, true, false>);
     *grid_out = grid;
     return WW_OK;
 }
@@ -823,8 +820,11 @@ extern "C" int ww_pwconv1x1_bwd(ww_ctx *ctx, int act_dtype, const void *g, const
     float *stat = (float *)scratch, *dwp = stat + WW_STAT_SLAB_FLOATS;
     int grid = 0;
     rc = act_dtype == WW_ACT_BF16
-             ? launch_pw_bwd_bf16(ctx, g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, w, M, H * W, g_in, stat, dwp,
-                                  &grid, st)
+             ? launch_pw_bwd_bf16<ww_bf16>(ctx, g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, w, M, H * W, g_in, stat, dwp,
+                                           &grid, st)
+         : act_dtype == WW_ACT_F16
+             ? launch_pw_bwd_bf16<ww_f16>(ctx, g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, w, M, H * W, g_in, stat, dwp,
+                                          &grid, st)
              : launch_pw_bwd<float>(ctx, g, dpool, y_out, ss_out, coef, y_in, ss_in, mr_in, w, M, H * W, g_in, stat, dwp,
                                     &grid, st);
     if (rc) return rc;
@@ -855,6 +855,8 @@ extern "C" int ww_dwconv3x3_bwd(ww_ctx *ctx, int act_dtype, const void *g, const
     int grid = 0;
     rc = act_dtype == WW_ACT_BF16
              ? launch_dw_bwd<ww_bf16>(ctx, g, y_out, coef, y_in, ss_in, mr_in, w, gm, g_in, stat, dwp, &grid, st)
+         : act_dtype == WW_ACT_F16
+             ? launch_dw_bwd<ww_f16>(ctx, g, y_out, coef, y_in, ss_in, mr_in, w, gm, g_in, stat, dwp, &grid, st)
              : launch_dw_bwd<float>(ctx, g, y_out, coef, y_in, ss_in, mr_in, w, gm, g_in, stat, dwp, &grid, st);
     if (rc) return rc;
     WW_LAUNCH_CHECK();
@@ -873,8 +875,9 @@ int ww_stem_bwd_impl(ww_ctx *ctx, int act_dtype, const void *g, const void *y_ou
     hipStream_t st = (hipStream_t)stream;
     float *dwp = (float *)scratch + WW_STAT_SLAB_FLOATS;
     int grid = 0;
-    rc = act_dtype == WW_ACT_BF16 ? launch_stem_bwd<ww_bf16>(ctx, g, y_out, w, coef, x, B, Hin, Win, dwp, &grid, st)
-                                  : launch_stem_bwd<float>(ctx, g, y_out, w, coef, x, B, Hin, Win, dwp, &grid, st);
+    rc = act_dtype == WW_ACT_BF16  ? launch_stem_bwd<ww_bf16>(ctx, g, y_out, w, coef, x, B, Hin, Win, dwp, &grid, st)
+         : act_dtype == WW_ACT_F16 ? launch_stem_bwd<ww_f16>(ctx, g, y_out, w, coef, x, B, Hin, Win, dwp, &grid, st)
+                                   : launch_stem_bwd<float>(ctx, g, y_out, w, coef, x, B, Hin, Win, dwp, &grid, st);
     if (rc) return rc;
     WW_LAUNCH_CHECK();
     ww_prof_scope pf_(ctx, WW_K_FINALIZE, st);

@@ -329,23 +329,19 @@ __global__ __launch_bounds__(256) void k_pw_fwd(const T *__restrict__ yin, const
 // HBM-bound).  LDS tile holds relu(bn(y_in)) as bf16 with 144-byte rows (conflict-free ds_read_b128 fragments);
 // lane (r,h) of k-step t reads channels 16t+8h .. +7 of pixel r.  Weights are rounded to bf16 once per kernel
 // (what autocast does to conv weights); accumulation is fp32.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int PWH_LD = 72;      // bf16 elements per LDS row (64 + 8 pad = 144 B)
+constexpr int PWH_LD = 72;      // 16-bit elements per LDS row (64 + 8 pad = 144 B)
 
-__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
-    typedef float f32x8 __attribute__((ext_vector_type(8)));
-    f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-    return __builtin_convertvector(f, bf16x8);
-}
-
-__global__ __launch_bounds__(256) void k_pw_fwd_bf16(const ww_bf16 *__restrict__ yin, const float *__restrict__ ss,
-                                                     const float *__restrict__ w, long M, ww_bf16 *__restrict__ y,
+// H = H | ww_f16 (the same kernel on v_mfma_f32_32x32x16_bf16 / _f16)
+template <typename H>
+__global__ __launch_bounds__(256) void k_pw_fwd_bf16(const H *__restrict__ yin, const float *__restrict__ ss,
+                                                     const float *__restrict__ w, long M, H *__restrict__ y,
                                                      float *__restrict__ partials) {
     extern __shared__ __align__(16) unsigned char pwh_lds[];
-    ww_bf16 *atile = reinterpret_cast<ww_bf16 *>(pwh_lds);                       // [128][72] bf16
-    ww_bf16 *otile = atile + PW_TILE * PWH_LD;                                   // [128][72] bf16: the output as it is stored
+    H *atile = reinterpret_cast<H *>(pwh_lds);                       // [128][72] bf16
+    H *otile = atile + PW_TILE * PWH_LD;                                   // [128][72] bf16: the output as it is stored
     // (36.9 KB together: 4 workgroups per CU, what the 96 VGPRs allow; an fp32 staging tile capped it at 3)
-    typedef Act<ww_bf16> A16;
+    typedef Act<H> A16;
+    typedef typename H16<H>::x8 bf16x8;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int rh = wv >> 1, n = wv & 1;
@@ -356,14 +352,14 @@ __global__ __launch_bounds__(256) void k_pw_fwd_bf16(const ww_bf16 *__restrict__
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = w[(size_t)(32 * n + r) * 64 + 16 * t + 8 * h + j];
-        wb[t] = pack8(v);
+        wb[t] = ww_pack8<H>(v);
     }
     const int c4 = tid & 15;
     const float4 sc = *reinterpret_cast<const float4 *>(ss + 4 * c4);
     const float4 sf = *reinterpret_cast<const float4 *>(ss + 64 + 4 * c4);
     float s1 = 0.f, s2 = 0.f;
     const long ntiles = (M + PW_TILE - 1) / PW_TILE;
-    A16::raw4 raw[8];
+    typename A16::raw4 raw[8];
     auto issue = [&](long ti) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -393,13 +389,13 @@ __global__ __launch_bounds__(256) void k_pw_fwd_bf16(const ww_bf16 *__restrict__
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8 *>(atile + (rbase + r) * PWH_LD + 16 * t + 8 * h);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, wb[t], acc, 0, 0, 0);
+                acc = H16<H>::mfma32(a, wb[t], acc);
             }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int prow = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 const float v = A16::round1(acc[reg]);
-                otile[prow * PWH_LD + 32 * n + r] = (ww_bf16)v;
+                otile[prow * PWH_LD + 32 * n + r] = (H)v;
                 s1 += v;
                 s2 = fmaf(v, v, s2);
             }
@@ -512,7 +508,7 @@ int check_bn(const char *who, const ww_bn_t *bn, const float *ss_out, const floa
 }
 
 int check_act(const char *who, int act_dtype) {
-    WW_REQUIRE(act_dtype == WW_ACT_F32 || act_dtype == WW_ACT_BF16, WW_E_INVALID, "%s: unknown act_dtype %d", who,
+    WW_REQUIRE(act_dtype == WW_ACT_F32 || act_dtype == WW_ACT_BF16 || act_dtype == WW_ACT_F16, WW_E_INVALID, "%s: unknown act_dtype %d", who,
                act_dtype);
     return WW_OK;
 }
@@ -547,15 +543,15 @@ int launch_dw_fwd(ww_ctx *ctx, const void *y_in, const float *ss_in, const float
     return WW_OK;
 }
 
+template <typename H>
 int launch_pw_fwd_bf16(ww_ctx *ctx, const void *y_in, const float *ss_in, const float *w, long M, void *y,
                        float *partials, int *grid_out, hipStream_t st) {
     const long ntiles = (M + PW_TILE - 1) / PW_TILE;
     const size_t smem = (size_t)2 * PW_TILE * PWH_LD * 2;
-    const int grid = ww_occupancy_grid((const void *)k_pw_fwd_bf16, 256, smem, ntiles, WW_MAX_PARTIALS);
+    const int grid = ww_occupancy_grid((const void *)k_pw_fwd_bf16<H>, 256, smem, ntiles, WW_MAX_PARTIALS);
     {
         ww_prof_scope ps_(ctx, WW_K_PW_FWD, st);
-        hipLaunchKernelGGL(k_pw_fwd_bf16, dim3(grid), dim3(256), smem, st, (const ww_bf16 *)y_in, ss_in, w, M,
-                           (ww_bf16 *)y, partials);
+        hipLaunchKernelGGL(k_pw_fwd_bf16<H>, dim3(grid), dim3(256), smem, st, (const H *)y_in, ss_in, w, M, (H *)y, partials);
     }
     WW_LAUNCH_CHECK();
     *grid_out = grid;
@@ -590,8 +586,9 @@ extern "C" int ww_conv_stem_fwd(ww_ctx *ctx, int act_dtype, const float *x, cons
     hipStream_t st = (hipStream_t)stream;
     float *partials = bn->training ? (float *)scratch : nullptr;
     int grid = 0;
-    rc = act_dtype == WW_ACT_BF16 ? launch_stem_fwd<ww_bf16>(ctx, x, w, B, Hin, Win, y, partials, &grid, st)
-                                  : launch_stem_fwd<float>(ctx, x, w, B, Hin, Win, y, partials, &grid, st);
+    rc = act_dtype == WW_ACT_BF16  ? launch_stem_fwd<ww_bf16>(ctx, x, w, B, Hin, Win, y, partials, &grid, st)
+         : act_dtype == WW_ACT_F16 ? launch_stem_fwd<ww_f16>(ctx, x, w, B, Hin, Win, y, partials, &grid, st)
+                                   : launch_stem_fwd<float>(ctx, x, w, B, Hin, Win, y, partials, &grid, st);
     if (rc) return rc;
     return finish_bn(ctx, partials, grid, (double)B * ((Hin + 1) / 2) * ((Win + 1) / 2), bn, ss_out, mr_out, st);
 }
@@ -613,8 +610,9 @@ extern "C" int ww_dwconv3x3_fwd(ww_ctx *ctx, int act_dtype, const void *y_in, co
     hipStream_t st = (hipStream_t)stream;
     float *partials = bn->training ? (float *)scratch : nullptr;
     int grid = 0;
-    rc = act_dtype == WW_ACT_BF16 ? launch_dw_fwd<ww_bf16>(ctx, y_in, ss_in, w, g, y, partials, &grid, st)
-                                  : launch_dw_fwd<float>(ctx, y_in, ss_in, w, g, y, partials, &grid, st);
+    rc = act_dtype == WW_ACT_BF16  ? launch_dw_fwd<ww_bf16>(ctx, y_in, ss_in, w, g, y, partials, &grid, st)
+         : act_dtype == WW_ACT_F16 ? launch_dw_fwd<ww_f16>(ctx, y_in, ss_in, w, g, y, partials, &grid, st)
+                                   : launch_dw_fwd<float>(ctx, y_in, ss_in, w, g, y, partials, &grid, st);
     if (rc) return rc;
     return finish_bn(ctx, partials, grid, (double)B * H * W, bn, ss_out, mr_out, st);
 }
@@ -630,8 +628,9 @@ extern "C" int ww_pwconv1x1_fwd(ww_ctx *ctx, int act_dtype, const void *y_in, co
     hipStream_t st = (hipStream_t)stream;
     float *partials = bn->training ? (float *)scratch : nullptr;
     int grid = 0;
-    rc = act_dtype == WW_ACT_BF16 ? launch_pw_fwd_bf16(ctx, y_in, ss_in, w, M, y, partials, &grid, st)
-                                  : launch_pw_fwd<float>(ctx, y_in, ss_in, w, M, y, partials, &grid, st);
+    rc = act_dtype == WW_ACT_BF16  ? launch_pw_fwd_bf16<ww_bf16>(ctx, y_in, ss_in, w, M, y, partials, &grid, st)
+         : act_dtype == WW_ACT_F16 ? launch_pw_fwd_bf16<ww_f16>(ctx, y_in, ss_in, w, M, y, partials, &grid, st)
+                                   : launch_pw_fwd<float>(ctx, y_in, ss_in, w, M, y, partials, &grid, st);
     if (rc) return rc;
     return finish_bn(ctx, partials, grid, (double)M, bn, ss_out, mr_out, st);
 }
@@ -647,6 +646,8 @@ extern "C" int ww_gap_fwd(ww_ctx *ctx, int act_dtype, const void *y, const float
         ww_prof_scope ps_(ctx, WW_K_GAP_FWD, st);
         if (act_dtype == WW_ACT_BF16)
             hipLaunchKernelGGL(k_gap_fwd<ww_bf16>, dim3(B), dim3(1024), 0, st, (const ww_bf16 *)y, ss, mr, H * W, pool);
+        else if (act_dtype == WW_ACT_F16)
+            hipLaunchKernelGGL(k_gap_fwd<ww_f16>, dim3(B), dim3(1024), 0, st, (const ww_f16 *)y, ss, mr, H * W, pool);
         else
             hipLaunchKernelGGL(k_gap_fwd<float>, dim3(B), dim3(1024), 0, st, (const float *)y, ss, mr, H * W, pool);
     }

@@ -21,14 +21,11 @@
 namespace {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int HB_LD = 128 + 8;       // bf16 row strides (16-byte aligned 8-element fragments)
+constexpr int HB_LD = 128 + 8;       // 16-bit row strides (16-byte aligned 8-element fragments)
 constexpr int DGB_LD = 3 * 128 + 8;
-__device__ __forceinline__ bf16x8 pack8g(const float (&v)[8]) {
-    typedef float f32x8 __attribute__((ext_vector_type(8)));
-    f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-    return __builtin_convertvector(f, bf16x8);
-}
+// matrix mode of the recurrent kernels: 0 = fp32 MFMA, 1 = bf16, 2 = fp16 operands (state, gates, updates stay fp32)
+template <int MODE> struct ModeH { typedef ww_bf16 type; };
+template <> struct ModeH<2> { typedef ww_f16 type; };
 constexpr int GH = 128;          // hidden size
 constexpr int GBT = 16;          // batch rows per block (one 16-row MFMA tile)
 constexpr int HS_LD = GH + 4;    // LDS row strides: lane (row i, k) -> bank 4i + k, conflict-free fragment reads
@@ -51,13 +48,16 @@ struct GruSaved { float *r, *z, *n, *hn, *hp; };    // (B*T, 128) each: gates, W
 
 // grid ceil(B/16), block 512 = 8 waves; wave w owns hidden units [16w, 16w+16).  BF16: h and W_hh enter the MFMA as bf16
 // (v_mfma_f32_16x16x32_bf16, 12 instead of 96 matrix instructions per step); h itself, the gates and the update stay fp32.
-template <bool BF16>
+template <int MODE>
 __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, const float *__restrict__ w_hh,
                                                  const float *__restrict__ b_hh, const float *__restrict__ h0, int B, int T,
                                                  int reverse, float *__restrict__ y, long ldy, long bsy,
                                                  float *__restrict__ hn_out, GruSaved sv, int y_vec) {
+    constexpr bool BF16 = MODE != 0;
+    typedef typename ModeH<MODE>::type H;
+    typedef typename H16<H>::x8 bf16x8;
     __shared__ __align__(16) float hs[2][GBT][HS_LD];
-    __shared__ __align__(16) ww_bf16 hb[BF16 ? 2 : 1][BF16 ? GBT : 1][HB_LD];
+    __shared__ __align__(16) H hb[BF16 ? 2 : 1][BF16 ? GBT : 1][HB_LD];
     // what the backward needs of a step (r, z, n, W_hn h + b_hn, h_{t-1}) is parked in LDS in the MFMA result layout (a lane
     // holds 4 ROWS of one unit) and written out one step later as float4 along the UNIT axis by thread (row, 4 units):
     // 6 vector stores per thread and step instead of 24 scalar ones -- the store issue, not the MFMAs, bounded a step.
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = w_hh[(size_t)(g * GH + u) * GH + 32 * kk + 8 * kq + e];
-                wb[g][kk] = pack8g(v);
+                wb[g][kk] = ww_pack8<H>(v);
             }
     } else {
 #pragma unroll
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
         const int row = e >> 7, c = e & 127;
         const float hv = (h0 && b0 + row < B) ? h0[(size_t)(b0 + row) * GH + c] : 0.f;
         hs[0][row][c] = hv;
-        if constexpr (BF16) hb[0][row][c] = (ww_bf16)hv;
+        if constexpr (BF16) hb[0][row][c] = (H)hv;
     }
     __syncthreads();
     // input projections of a step are loaded TWO steps ahead (register sets A / B, alternating): a step is ~0.5 us of
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&hb[cur][j][32 * kk + 8 * kq]);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wb[g][kk], acc[g], 0, 0, 0);
+                for (int g = 0; g < 3; ++g) acc[g] = H16<H>::mfma16(a, wb[g][kk], acc[g]);
             }
         } else {
 #pragma unroll
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
             const float hp = hs[cur][row][u];
             const float h = (1.0f - z) * n + z * hp;
             hs[cur ^ 1][row][u] = h;
-            if constexpr (BF16) hb[cur ^ 1][row][u] = (ww_bf16)h;
+            if constexpr (BF16) hb[cur ^ 1][row][u] = (H)h;
             float *sp = gru_sav + (size_t)cur * 5 * GBT * HS_LD + row * HS_LD + u;
             sp[0] = r; sp[GBT * HS_LD] = z; sp[2 * GBT * HS_LD] = n; sp[3 * GBT * HS_LD] = hnv; sp[4 * GBT * HS_LD] = hp;
         }
@@ -183,14 +183,17 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
 }
 
 // same decomposition; wave w owns OUTPUT units [16w,16w+16) of dh_{t-1} = dh*z + dGh W_hh
-template <bool BF16>
+template <int MODE>
 __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh, const float *__restrict__ dy, long ldy,
                                                  long bsy, const float *__restrict__ dhn, int B, int T, int reverse,
                                                  GruSaved sv, float *__restrict__ dgi, float *__restrict__ dgh,
                                                  float *__restrict__ dh0, float *__restrict__ bias_part, int dy_vec) {
+    constexpr bool BF16 = MODE != 0;
+    typedef typename ModeH<MODE>::type H;
+    typedef typename H16<H>::x8 bf16x8;
     __shared__ __align__(16) float dhs[GBT][HS_LD];
     __shared__ __align__(16) float dg[BF16 ? 1 : GBT][DG_LD];      // fp32 operand tile
-    __shared__ __align__(16) ww_bf16 dgb[BF16 ? GBT : 1][DGB_LD];
+    __shared__ __align__(16) H dgb[BF16 ? GBT : 1][DGB_LD];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
     const int b0 = blockIdx.x * GBT, u = 16 * w + j;
     float wreg[BF16 ? 1 : 96];         // fp32: B operand of k-step cc: W_hh[4cc + kq][u]  (contraction over the 384 gate rows)
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = w_hh[(size_t)(32 * cc + 8 * kq + e) * GH + u];
-            wb[cc] = pack8g(v);
+            wb[cc] = ww_pack8<H>(v);
         }
     } else {
 #pragma unroll
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
             *reinterpret_cast<float4 *>(dgh + m3 + 2 * GH) = make_float4(dhn_[0], dhn_[1], dhn_[2], dhn_[3]);
         }
         if constexpr (BF16) {
-            typedef Act<ww_bf16> A16;
+            typedef Act<H> A16;
             *reinterpret_cast<uint2 *>(&dgb[erow][ec0]) = make_uint2(A16::pack2(dar[0], dar[1]), A16::pack2(dar[2], dar[3]));
             *reinterpret_cast<uint2 *>(&dgb[erow][GH + ec0]) = make_uint2(A16::pack2(daz[0], daz[1]), A16::pack2(daz[2], daz[3]));
             *reinterpret_cast<uint2 *>(&dgb[erow][2 * GH + ec0]) = make_uint2(A16::pack2(dhn_[0], dhn_[1]), A16::pack2(dhn_[2], dhn_[3]));
@@ -285,8 +288,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh,
         if constexpr (BF16) {
 #pragma unroll
             for (int cc = 0; cc < 12; ++cc)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&dgb[j][32 * cc + 8 * kq]), wb[cc], acc,
-                                                              0, 0, 0);
+                acc = H16<H>::mfma16(*reinterpret_cast<const bf16x8 *>(&dgb[j][32 * cc + 8 * kq]), wb[cc], acc);
         } else {
 #pragma unroll
             for (int cc = 0; cc < 96; ++cc)
@@ -413,7 +415,7 @@ extern "C" int ww_gru_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
                           float *h_n, void *ws, size_t ws_bytes, ww_stream_t stream) {
     int rc = check_gru("ww_gru_fwd", ctx, B, T, I, H, ws, ws_bytes);
     if (rc) return rc;
-    WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16, WW_E_INVALID, "ww_gru_fwd: unknown mode %d", mode);
+    WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16 || mode == WW_ACT_F16, WW_E_INVALID, "ww_gru_fwd: unknown mode %d", mode);
     WW_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && y, WW_E_INVALID, "ww_gru_fwd: null argument");
     WW_REQUIRE(ldx >= I && ldy >= H, WW_E_INVALID, "ww_gru_fwd: row strides smaller than the feature sizes");
     const WsLayout L = ws_layout(B, T, I);
@@ -431,7 +433,7 @@ extern "C" int ww_gru_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
                            reverse, y, ldy, (long)T * ldy, h_n, saved(w, L), y_vec);
         return WW_OK;
     };
-    if ((rc = mode == WW_ACT_BF16 ? go(k_gru_fwd<true>) : go(k_gru_fwd<false>))) return rc;
+    if ((rc = mode == WW_ACT_BF16 ? go(k_gru_fwd<1>) : mode == WW_ACT_F16 ? go(k_gru_fwd<2>) : go(k_gru_fwd<0>))) return rc;
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -442,7 +444,7 @@ extern "C" int ww_gru_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
                           float *dh0, ww_stream_t stream) {
     int rc = check_gru("ww_gru_bwd", ctx, B, T, I, H, ws, ws_bytes);
     if (rc) return rc;
-    WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16, WW_E_INVALID, "ww_gru_bwd: unknown mode %d", mode);
+    WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16 || mode == WW_ACT_F16, WW_E_INVALID, "ww_gru_bwd: unknown mode %d", mode);
     WW_REQUIRE(x && w_ih && w_hh && dw_ih && dw_hh && db_ih && db_hh, WW_E_INVALID, "ww_gru_bwd: null argument");
     WW_REQUIRE(dy || dh_n, WW_E_INVALID, "ww_gru_bwd: need dy and/or dh_n");
     const WsLayout L = ws_layout(B, T, I);
@@ -455,10 +457,13 @@ extern "C" int ww_gru_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
     const int nblk = (B + GBT - 1) / GBT;
     const int dy_vec = dy && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0);
     if (mode == WW_ACT_BF16)
-        hipLaunchKernelGGL(k_gru_bwd<true>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
+        hipLaunchKernelGGL(k_gru_bwd<1>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
+                           dgh, dh0, bpart, dy_vec);
+    else if (mode == WW_ACT_F16)
+        hipLaunchKernelGGL(k_gru_bwd<2>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
                            dgh, dh0, bpart, dy_vec);
     else
-        hipLaunchKernelGGL(k_gru_bwd<false>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
+        hipLaunchKernelGGL(k_gru_bwd<0>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
                            dgh, dh0, bpart, dy_vec);
     WW_LAUNCH_CHECK();
     const int M = B * T;

@@ -16,7 +16,9 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// matrix mode of a kernel: 0 = fp32 MFMA, 1 = bf16, 2 = fp16 operands (fp32 accumulation)
+template <int MODE> struct ModeH { typedef ww_bf16 type; };
+template <> struct ModeH<2> { typedef ww_f16 type; };
 
 // block tiles are 64 or 128 rows/columns (template parameters TM, TN of k_gemm)
 constexpr int GK = 32;      // K per LDS stage, fp32 mode
@@ -90,8 +92,10 @@ __device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k
     }
 }
 // LDS strides: [row][k]: KT + 4 (fp32) / KT + 8 (bf16);  [k][row]: ROWS + 4 (fp32) / ROWS + 8 (bf16)
-template <bool BF16, bool KC, int ROWS, int KT>
+template <int MODE, bool KC, int ROWS, int KT>
 __device__ __forceinline__ void stage_tile(void *lds, const float4 (&v)[ROWS * KT / 1024]) {
+    constexpr bool BF16 = MODE != 0;
+    typedef typename ModeH<MODE>::type H;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < ROWS * KT / 1024; ++j) {
@@ -99,8 +103,8 @@ __device__ __forceinline__ void stage_tile(void *lds, const float4 (&v)[ROWS * K
         const int off = KC ? (q / (KT / 4)) * (BF16 ? KT + 8 : KT + 4) + 4 * (q % (KT / 4))
                            : (q / (ROWS / 4)) * (BF16 ? ROWS + 8 : ROWS + 4) + 4 * (q % (ROWS / 4));
         if (BF16) {
-            typedef Act<ww_bf16> A16;
-            *reinterpret_cast<uint2 *>(reinterpret_cast<ww_bf16 *>(lds) + off) =
+            typedef Act<H> A16;
+            *reinterpret_cast<uint2 *>(reinterpret_cast<H *>(lds) + off) =
                 make_uint2(A16::pack2(v[j].x, v[j].y), A16::pack2(v[j].z, v[j].w));
         } else {
             *reinterpret_cast<float4 *>(reinterpret_cast<float *>(lds) + off) = v[j];
@@ -109,20 +113,24 @@ __device__ __forceinline__ void stage_tile(void *lds, const float4 (&v)[ROWS * K
 }
 typedef short short4v __attribute__((ext_vector_type(4)));
 // bf16 MFMA operand (rows row0 + lane&31, k = k0 + 8*(lane>>5) .. +7) from a [k][row] tile of stride ld: transposing LDS reads
-__device__ __forceinline__ bf16x8 tr_frag(const ww_bf16 *tile, int ld, int k0, int row0, int lane) {
+template <typename H>
+__device__ __forceinline__ typename H16<H>::x8 tr_frag(const H *tile, int ld, int k0, int row0, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-    const ww_bf16 *base = tile + (k0 + 8 * (g >> 1) + q) * ld + row0 + 16 * (g & 1) + 4 * pp;
+    const H *base = tile + (k0 + 8 * (g >> 1) + q) * ld + row0 + 16 * (g & 1) + 4 * pp;
     typedef short4v __attribute__((address_space(3))) * lds_p;
     const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base));
     const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(base + 4 * ld));
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    return __builtin_bit_cast(typename H16<H>::x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 // Block tile (64*TM) x 64: 4 wavefronts as 2 x 2, each TM 32x32 MFMA tiles stacked along the rows (TM = 2 for tall
 // problems: twice the MFMA work per staged B byte).  grid: x = column tiles, y = row tiles, z = K splits (partial
 // products go to C + z*split_stride)
-template <bool BF16, bool KCA, bool KCB, bool EPI, int TM, int TN>
+template <int MODE, bool KCA, bool KCB, bool EPI, int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int K, int k_per_split, float *__restrict__ C,
                                               long ldc, long split_stride, int vecA, int vecB, Epilogue e) {
+    constexpr bool BF16 = MODE != 0;
+    typedef typename ModeH<MODE>::type H;
+    typedef typename H16<H>::x8 bf16x8;
     constexpr int RA = 64 * TM, RB = 64 * TN;
     // K per LDS stage: the bf16 MFMA eats 16 k per instruction, so a 32-deep stage is two MFMAs between barrier pairs --
     // 128 gives eight (64 for the 128 x 128 tile, whose prefetch registers double); the fp32 MFMA eats 2 k: 32 is sixteen
@@ -148,15 +156,15 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
     }
     for (int k0 = kb; k0 < ke; k0 += KT) {
         __syncthreads();
-        stage_tile<BF16, KCA, RA, KT>(As, va);
-        stage_tile<BF16, KCB, RB, KT>(Bs, vb);
+        stage_tile<MODE, KCA, RA, KT>(As, va);
+        stage_tile<MODE, KCB, RB, KT>(Bs, vb);
         __syncthreads();
         if (k0 + KT < ke) {                        // next tile in flight under the MFMAs
             fetch_tile<KCA, RA, KT>(A, m0, k0 + KT, ke, vecA, va);
             fetch_tile<KCB, RB, KT>(B, n0, k0 + KT, ke, vecB, vb);
         }
         if (BF16) {
-            const ww_bf16 *a = reinterpret_cast<const ww_bf16 *>(As), *b = reinterpret_cast<const ww_bf16 *>(Bs);
+            const H *a = reinterpret_cast<const H *>(As), *b = reinterpret_cast<const H *>(Bs);
 #pragma unroll
             for (int t = 0; t < KT / 16; ++t) {
                 bf16x8 fb[TN];
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
                     const bf16x8 fa = KCA ? *reinterpret_cast<const bf16x8 *>(a + (row0 + r) * LDH_KC + 16 * t + 8 * h)
                                           : tr_frag(a, RA + 8, 16 * t, row0, lane);
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[tn], acc[tm][tn], 0, 0, 0);
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = H16<H>::mfma32(fa, fb[tn], acc[tm][tn]);
                 }
             }
         } else {
@@ -330,14 +338,14 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
     };
     const int vecA = aligned(A, KCA), vecB = aligned(B, KCB);
     int kps = K;
-    const int kt = mode == WW_ACT_BF16 ? GKH : GK;      // a multiple of every stage depth in use (128, 64, 32)
+    const int kt = mode != WW_ACT_F32 ? GKH : GK;      // a multiple of every stage depth in use (128, 64, 32)
     if (splits > 1) kps = ((K + splits - 1) / splits + kt - 1) / kt * kt;
     const int nz = (K + kps - 1) / kps;
     // Block tile: 64 x 64 by default; 128 x 128 (each staged byte feeds twice the MFMA work: these GEMMs are bound by operand
     // traffic, not by the matrix cores) when both extents allow it and enough workgroups remain; 128 x 64 for very tall ones
     const long tiles128 = (long)((A.rows + 127) / 128) * ((B.rows + 127) / 128) * nz;
     // (the 128 x 128 form pays in bf16 mode only: in fp32 mode its 64 accumulator + 32 prefetch registers cost occupancy, 72 vs 82 TF)
-    const int cfg = (mode == WW_ACT_BF16 && A.rows >= 128 && B.rows >= 128 && tiles128 >= 256) ? 2 : (A.rows >= 8192 ? 1 : 0);
+    const int cfg = (mode != WW_ACT_F32 && A.rows >= 128 && B.rows >= 128 && tiles128 >= 256) ? 2 : (A.rows >= 8192 ? 1 : 0);
     const int RA = cfg ? 128 : 64, RBt = cfg == 2 ? 128 : 64;
     dim3 grid((B.rows + RBt - 1) / RBt, (A.rows + RA - 1) / RA, nz);
     float *dst = nz > 1 ? part : C;
@@ -345,9 +353,11 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
 #define WW_GEMM_LAUNCH(BF, TM_, TN_) \
     hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, TN_>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e)
     if (mode == WW_ACT_BF16) {
-        if (cfg == 2) WW_GEMM_LAUNCH(true, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(true, 2, 1); else WW_GEMM_LAUNCH(true, 1, 1);
+        if (cfg == 2) WW_GEMM_LAUNCH(1, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(1, 2, 1); else WW_GEMM_LAUNCH(1, 1, 1);
+    } else if (mode == WW_ACT_F16) {
+        if (cfg == 2) WW_GEMM_LAUNCH(2, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(2, 2, 1); else WW_GEMM_LAUNCH(2, 1, 1);
     } else {
-        if (cfg == 2) WW_GEMM_LAUNCH(false, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(false, 2, 1); else WW_GEMM_LAUNCH(false, 1, 1);
+        if (cfg == 2) WW_GEMM_LAUNCH(0, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(0, 2, 1); else WW_GEMM_LAUNCH(0, 1, 1);
     }
 #undef WW_GEMM_LAUNCH
     WW_LAUNCH_CHECK();
@@ -361,7 +371,7 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
 }
 
 int check_dims(const char *who, int mode, int M, int K, int N) {
-    WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16, WW_E_INVALID, "%s: unknown mode %d", who, mode);
+    WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16 || mode == WW_ACT_F16, WW_E_INVALID, "%s: unknown mode %d", who, mode);
     WW_REQUIRE(M >= 1 && K >= 1 && N >= 1, WW_E_INVALID, "%s: bad shape M=%d K=%d N=%d", who, M, K, N);
     return WW_OK;
 }

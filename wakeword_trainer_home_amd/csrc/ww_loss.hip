@@ -12,10 +12,15 @@ namespace {
 __global__ __launch_bounds__(1024) void k_ce2_loss(const float *__restrict__ logits, const int64_t *__restrict__ targets,
                                                    int B, int kind, float eps, float alpha, float gamma,
                                                    float *__restrict__ loss_out, float *__restrict__ dlogits,
-                                                   ww_step_stats *__restrict__ stats, float *__restrict__ found_inf_out) {
+                                                   ww_step_stats *__restrict__ stats, float *__restrict__ found_inf_out,
+                                                   const ww_loss_scale *__restrict__ ls, int ls_slot,
+                                                   const ww_step_ctl *__restrict__ ctl) {
     __shared__ double shl[1024];
     __shared__ int shc[6][1024];
-    const float invB = 1.0f / (float)B;
+    // fp16 storage: dL/dlogits leaves this kernel times the dynamic loss scale (GradScaler.scale(loss).backward(),
+    // src/training/trainer.py:182); the loss value itself is reported unscaled
+    const float gscale = ls ? ls->scale[(ctl ? ctl->parity : ls_slot) & 1] : 1.0f;
+    const float invB = gscale / (float)B;
     const float PT_MIN = 1e-7f, PT_MAX = (float)(1.0 - 1e-7);
     double lsum = 0.0;
     int correct = 0, tp = 0, tn = 0, fp = 0, fn = 0, bad = 0;
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(1024) void k_ce2_loss(const float *__restrict__ log
 
 extern "C" int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64_t *targets, int B, int loss_kind,
                                    float label_smoothing, float focal_alpha, float focal_gamma, float *loss_out,
-                                   float *dlogits, ww_step_stats *stats, float *found_inf_out, ww_stream_t stream) {
+                                   float *dlogits, ww_step_stats *stats, float *found_inf_out, const ww_loss_scale *loss_scale,
+                                   int loss_scale_slot, ww_stream_t stream) {
     WW_REQUIRE(ctx && logits && targets && dlogits, WW_E_INVALID, "ww_ce2_loss_fwd_bwd: null argument");
     WW_REQUIRE(B >= 1, WW_E_INVALID, "ww_ce2_loss_fwd_bwd: B=%d", B);
     WW_REQUIRE(loss_kind == WW_LOSS_CE || loss_kind == WW_LOSS_FOCAL, WW_E_INVALID,
@@ -111,9 +117,11 @@ extern "C" int ww_ce2_loss_fwd_bwd(ww_ctx *ctx, const float *logits, const int64
                "Label smoothing must be in [0, 1], got %g", label_smoothing);
     WW_REQUIRE(focal_alpha >= 0.f && focal_alpha <= 1.f, WW_E_INVALID, "Alpha must be in [0, 1], got %g", focal_alpha);
     WW_REQUIRE(focal_gamma >= 0.f, WW_E_INVALID, "Gamma must be non-negative, got %g", focal_gamma);
+    WW_REQUIRE(loss_scale_slot == 0 || loss_scale_slot == 1, WW_E_INVALID, "ww_ce2_loss_fwd_bwd: loss_scale_slot must be 0 or 1");
     ww_prof_scope ps_(ctx, WW_K_HEAD_LOSS, (hipStream_t)stream);
     hipLaunchKernelGGL(k_ce2_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, targets, B, loss_kind,
-                       label_smoothing, focal_alpha, focal_gamma, loss_out, dlogits, stats, found_inf_out);
+                       label_smoothing, focal_alpha, focal_gamma, loss_out, dlogits, stats, found_inf_out, loss_scale,
+                       loss_scale_slot, ctx->step_ctl);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

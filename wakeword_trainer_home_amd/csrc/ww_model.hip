@@ -21,7 +21,7 @@ Layout make_layout(int B, int F, int T, int act_dtype) {
     L.Ho = (F + 1) / 2;
     L.Wo = (T + 1) / 2;
     L.A = (size_t)B * L.Ho * L.Wo * 64;
-    const size_t esz = act_dtype == WW_ACT_BF16 ? 2 : 4;
+    const size_t esz = act_dtype == WW_ACT_F32 ? 4 : 2;
     size_t o = 0;
     auto takeb = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     auto take = [&](size_t nfloat) { return takeb(nfloat * sizeof(float)); };
@@ -56,7 +56,7 @@ ww_bn_t make_bn(void *const *p, int l, int training, float mom, float eps) {
 
 int check_common(const char *who, ww_ctx *ctx, int act_dtype, void *const *params, const void *x, int B, int F, int T,
                  void *ws, size_t ws_bytes, int nparams = WW_CNN_SMALL_NPTR) {
-    WW_REQUIRE(act_dtype == WW_ACT_F32 || act_dtype == WW_ACT_BF16, WW_E_INVALID, "%s: unknown act_dtype %d", who,
+    WW_REQUIRE(act_dtype == WW_ACT_F32 || act_dtype == WW_ACT_BF16 || act_dtype == WW_ACT_F16, WW_E_INVALID, "%s: unknown act_dtype %d", who,
                act_dtype);
     WW_REQUIRE(ctx && params && x && ws, WW_E_INVALID, "%s: null argument", who);
     WW_REQUIRE(B >= 1 && F >= 1 && T >= 1, WW_E_INVALID, "%s: bad shape (%d,1,%d,%d)", who, B, F, T);
@@ -261,6 +261,9 @@ extern "C" int ww_cnn_front_fwd(ww_ctx *ctx, int act_dtype, void *const *params,
     if (act_dtype == WW_ACT_BF16)
         hipLaunchKernelGGL(k_freqpool_fwd<ww_bf16>, dim3(grid), dim3(256), 0, st, (const ww_bf16 *)(w + L.y[8]),
                            (const float *)(w + L.ss[8]), B, L.Ho, L.Wo, seq);
+    else if (act_dtype == WW_ACT_F16)
+        hipLaunchKernelGGL(k_freqpool_fwd<ww_f16>, dim3(grid), dim3(256), 0, st, (const ww_f16 *)(w + L.y[8]),
+                           (const float *)(w + L.ss[8]), B, L.Ho, L.Wo, seq);
     else
         hipLaunchKernelGGL(k_freqpool_fwd<float>, dim3(grid), dim3(256), 0, st, (const float *)(w + L.y[8]),
                            (const float *)(w + L.ss[8]), B, L.Ho, L.Wo, seq);
@@ -285,6 +288,9 @@ extern "C" int ww_cnn_front_bwd(ww_ctx *ctx, int act_dtype, void *const *params,
     if (act_dtype == WW_ACT_BF16)
         hipLaunchKernelGGL(k_freqpool_bwd<ww_bf16>, dim3(grid), dim3(256), 0, st, dseq, (const ww_bf16 *)(w + L.y[8]),
                            (const float *)(w + L.ss[8]), (const float *)(w + L.mr[8]), B, L.Ho, L.Wo, (ww_bf16 *)(w + L.g[0]), stat);
+    else if (act_dtype == WW_ACT_F16)
+        hipLaunchKernelGGL(k_freqpool_bwd<ww_f16>, dim3(grid), dim3(256), 0, st, dseq, (const ww_f16 *)(w + L.y[8]),
+                           (const float *)(w + L.ss[8]), (const float *)(w + L.mr[8]), B, L.Ho, L.Wo, (ww_f16 *)(w + L.g[0]), stat);
     else
         hipLaunchKernelGGL(k_freqpool_bwd<float>, dim3(grid), dim3(256), 0, st, dseq, (const float *)(w + L.y[8]),
                            (const float *)(w + L.ss[8]), (const float *)(w + L.mr[8]), B, L.Ho, L.Wo, (float *)(w + L.g[0]), stat);

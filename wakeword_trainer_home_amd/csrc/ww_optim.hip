@@ -16,7 +16,21 @@ struct OptimArgs {
     int kind;
     float lr, beta1, beta2, eps, wd, momentum, max_norm;
     const ww_step_ctl *ctl;       // bound control block: lr and the step_state slot come from device memory (HIP graph replay)
+    ww_loss_scale *ls;            // fp16 mode: gradients arrive times ls->scale[slot]; unscaled here, scale updated for slot^1
 };
+// torch.amp.GradScaler's update rule (unscale_ -> step -> update, src/training/trainer.py:186-193), decided on the device:
+// gradients not finite -> scale *= backoff, tracker = 0; a step that was applied -> tracker + 1, and scale *= growth when it
+// reaches the interval; a batch skipped for its loss / targets (before the scaler in the reference) leaves both alone
+__device__ __forceinline__ void loss_scale_update(ww_loss_scale *ls, int slot, bool grads_nonfinite, bool skipped) {
+    float sc = ls->scale[slot];
+    int tr = ls->growth_tracker[slot];
+    if (grads_nonfinite) { sc *= ls->backoff_factor; tr = 0; }
+    else if (!skipped) {
+        if (++tr >= ls->growth_interval) { sc *= ls->growth_factor; tr = 0; }
+    }
+    ls->scale[slot ^ 1] = sc;
+    ls->growth_tracker[slot ^ 1] = tr;
+}
 // learning rate / slot of this launch: by value, or the bound control block's (read at run time)
 __device__ __forceinline__ void optim_resolve(OptimArgs &a, int &parity) {
     if (a.ctl) { a.lr = a.ctl->lr; parity = a.ctl->parity & 1; }
@@ -64,11 +78,12 @@ __global__ __launch_bounds__(1024) void k_clip_optim_small(OptimArgs a, float *_
     __shared__ double sh[1024];
     __shared__ float coef_sh, ss_sh, bc_sh;
     __shared__ int skip_sh;
+    const float inv_scale = a.ls ? 1.0f / a.ls->scale[parity] : 1.0f;     // GradScaler.unscale_
     float gr[OPT_EPT];
 #pragma unroll
     for (int k = 0; k < OPT_EPT; ++k) {
         const size_t i = threadIdx.x + (size_t)k * 1024;
-        gr[k] = i < n ? g[i] : 0.f;
+        gr[k] = i < n ? g[i] * inv_scale : 0.f;
     }
     double acc = 0.0;
 #pragma unroll
@@ -83,6 +98,7 @@ __global__ __launch_bounds__(1024) void k_clip_optim_small(OptimArgs a, float *_
         const float norm = (float)sqrt(sh[0]);
         if (norm_out) *norm_out = norm;
         bool skip = !isfinite(norm) || (found_inf_extra && *found_inf_extra != 0.0f);   // extra: another rank's bad batch
+        const bool loss_bad = (stats && stats->found_inf != 0.0f) || (found_inf_extra && *found_inf_extra != 0.0f);
         if (stats) {
             stats->grad_norm = norm;
             if (skip) stats->found_inf = 1.0f;
@@ -96,10 +112,11 @@ __global__ __launch_bounds__(1024) void k_clip_optim_small(OptimArgs a, float *_
         step_state[parity ^ 1] = skip ? t0 : t0 + 1;
         skip_sh = skip;
         bias_terms(a, t0 + 1, ss_sh, bc_sh);
+        if (a.ls) loss_scale_update(a.ls, parity, !loss_bad && !isfinite(norm), skip);
     }
     __syncthreads();
     const float c = coef_sh, step_size = ss_sh, bc2_sqrt = bc_sh;
-    const bool skip = skip_sh, clip = a.max_norm > 0.f;
+    const bool skip = skip_sh, clip = a.max_norm > 0.f || a.ls != nullptr;     // unscaled gradients are written back
 #pragma unroll
     for (int k0 = 0; k0 < OPT_EPT; k0 += 8) {
         float pr[8], mr[8], vr[8];
@@ -140,9 +157,11 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
     if (parity && stats_host_alt) stats_host = stats_host_alt;
     double t = 0.0;
     for (int i = 0; i < nparts; ++i) t += parts[i];
-    const float norm = (float)sqrt(t);
+    const float inv_scale = a.ls ? 1.0f / a.ls->scale[parity] : 1.0f;      // GradScaler.unscale_; the partial sums are of scaled values
+    const float norm = (float)sqrt(t) * inv_scale;
     const bool extra = found_inf_extra && *found_inf_extra != 0.0f;
-    const bool skip = (stats && stats->found_inf != 0.0f) || !isfinite(norm) || extra;
+    const bool loss_bad = (stats && stats->found_inf != 0.0f) || extra;
+    const bool skip = loss_bad || !isfinite(norm);
     const long long t0 = step_state[parity];
     const bool clip = a.max_norm > 0.f;
     float c = 1.f;
@@ -152,6 +171,7 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         step_state[parity ^ 1] = skip ? t0 : t0 + 1;
+        if (a.ls) loss_scale_update(a.ls, parity, !loss_bad && !isfinite(norm), skip);
         if (norm_out) *norm_out = norm;
         if (stats) {
             stats->grad_norm = norm;
@@ -167,8 +187,8 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
     float step_size, bc2_sqrt;
     bias_terms(a, t0 + 1, step_size, bc2_sqrt);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float gi = g[i];
-        if (clip) { gi *= c; g[i] = gi; }           // clip_grad_norm_ leaves the clipped gradients behind
+        float gi = g[i] * inv_scale;
+        if (clip || a.ls) { gi *= c; g[i] = gi; }   // clip_grad_norm_ / unscale_ leave the clipped, unscaled gradients behind
         if (skip) continue;
         float pi = p[i], mi = m ? m[i] : 0.f, vi = v ? v[i] : 0.f;
         optim_update(a, pi, gi, mi, vi, step_size, bc2_sqrt);
@@ -183,7 +203,8 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
 extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *flat_params, float *flat_grads,
                                   float *exp_avg, float *exp_avg_sq, size_t n, int64_t *step_state, int parity,
                                   float *norm_out, ww_step_stats *stats, ww_step_stats *stats_host,
-                                  ww_step_stats *stats_host_alt, const float *found_inf_extra, ww_stream_t stream) {
+                                  ww_step_stats *stats_host_alt, const float *found_inf_extra, ww_loss_scale *loss_scale,
+                                  ww_stream_t stream) {
     WW_REQUIRE(ctx && cfg && flat_params && flat_grads && step_state, WW_E_INVALID, "ww_clip_optim_step: null argument");
     ww_step_stats *stats_host_dev = nullptr, *stats_host_alt_dev = nullptr;
     if (stats_host) {
@@ -211,7 +232,7 @@ extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *f
     }
     if (n == 0) return WW_OK;
     OptimArgs a{cfg->kind, cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->momentum, cfg->max_norm,
-                ctx->step_ctl};
+                ctx->step_ctl, loss_scale};
     hipStream_t st = (hipStream_t)stream;
     if (n <= (size_t)OPT_EPT * 1024) {
         ww_prof_scope ps_(ctx, WW_K_CLIP, st);

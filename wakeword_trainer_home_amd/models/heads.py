@@ -48,7 +48,7 @@ class MFMALinear(nn.Module):
         self.in_features, self.out_features = in_features, out_features
         self._act = nat.LIN_HARDSWISH if activation == "hardswish" else nat.LIN_NONE
         self.dropout, self.dropout_seed = float(dropout), dropout_seed
-        self.mode = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(mode, mode)
+        self.mode = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}.get(mode, mode)
         nat.act_code(self.mode)
         self.dropout_step = 0          # advanced once per training forward
         self.sample_offset = 0         # global index of the batch's first sample (data parallel shards)

@@ -16,7 +16,8 @@ class _CE2Fn(torch.autograd.Function):
     def forward(ctx, logits, targets, mod):
         loss, dl, stats = nat.ce2_loss_fwd_bwd(logits.contiguous(), targets.contiguous(), mod._kind, mod._eps,
                                                mod._alpha, mod._gamma, stats=mod._stats_for(logits.device),
-                                               found_inf_out=mod.found_inf_out)
+                                               found_inf_out=mod.found_inf_out, loss_scale=mod.loss_scale,
+                                               loss_scale_slot=mod.loss_scale_slot)
         mod.last_stats = stats
         ctx.save_for_backward(dl)
         return loss.reshape(())
@@ -42,6 +43,8 @@ class _NativeLoss(nn.Module):
         self.validate_targets = True      # reference behaviour: raise at once (costs a host sync)
         self.last_stats = None            # device uint8[48] = ww_step_stats of the last call
         self.found_inf_out = None         # float32[1] device tensor that also receives found_inf (data-parallel bucket slot)
+        self.loss_scale = None            # device ww_loss_scale (fp16 storage): dL/dlogits leaves the kernel times scale[slot]
+        self.loss_scale_slot = 0
         self._stats = {}
 
     def _stats_for(self, dev):
@@ -56,7 +59,8 @@ class _NativeLoss(nn.Module):
             raise ValueError(f"expected logits (B,2) and targets (B,), got {tuple(logits.shape)} and {tuple(target.shape)}")
         _, dl, stats = nat.ce2_loss_fwd_bwd(logits.contiguous(), target.long().contiguous(), self._kind, self._eps,
                                             self._alpha, self._gamma, stats=self._stats_for(logits.device),
-                                            found_inf_out=found_inf_out)
+                                            found_inf_out=found_inf_out, loss_scale=self.loss_scale,
+                                            loss_scale_slot=self.loss_scale_slot)
         self.last_stats = stats
         return stats, dl
 

@@ -300,7 +300,7 @@ class MobileNetV3Wakeword(FlatBuckets, nn.Module):
             raise ValueError("pretrained ImageNet weights cannot be downloaded in this build (pass pretrained=False)")
         if input_channels != 1:
             raise ValueError(f"mobilenetv3: the native stem takes one-channel spectrograms, got input_channels={input_channels}")
-        m = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(mode, mode)
+        m = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}.get(mode, mode)
         nat.act_code(m)
         self.mobilenet = _MobileNet(num_classes, dropout, m, dropout_seed)
 

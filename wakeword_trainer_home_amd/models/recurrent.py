@@ -117,7 +117,7 @@ class NativeGRU(nn.Module):
     def __init__(self, input_size, hidden_size=128, num_layers=2, bidirectional=True, dropout=0.0, dropout_seed=0,
                  mode="fp32"):
         super().__init__()
-        self.mode = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(mode, mode)   # matrix type of the projection GEMMs
+        self.mode = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}.get(mode, mode)   # matrix type of the projection GEMMs
         nat.act_code(self.mode)
         if hidden_size != 128:
             raise nat.NativeError(f"the HIP GRU kernels implement hidden_size == 128 (the reference default), got {hidden_size}")
@@ -202,7 +202,7 @@ class CRNNWakeword(FlatBuckets, nn.Module):
         self.front = CNNSmallWakeword(num_classes=2, dropout=0.0, act_dtype=act_dtype, features_only=True)
         self.rnn = _GRUWakewordBase(input_size=CNNSmallWakeword.CH, hidden_size=hidden_size, num_layers=num_layers,
                                num_classes=num_classes, bidirectional=bidirectional, dropout=dropout, dropout_seed=dropout_seed,
-                               mode="bf16" if nat.act_code(act_dtype) == nat.ACT_BF16 else "fp32")
+                               mode={nat.ACT_BF16: "bf16", nat.ACT_F16: "fp16"}.get(nat.act_code(act_dtype), "fp32"))
 
     @property
     def sample_offset(self):

@@ -97,12 +97,14 @@ class FlatFusedOptimizer(optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, max_norm: float = 0.0, stats=None, stats_host=None, gathered: bool = False,
-             found_inf_extra=None, stats_host_alt=None):
+             found_inf_extra=None, stats_host_alt=None, loss_scale=None):
         """``max_norm > 0`` also clips (clip_grad_norm_ semantics, in place on the bucket); ``stats`` is the step's
         device ``ww_step_stats`` (found_inf gate, grad_norm output); ``stats_host`` a pinned 48-byte tensor the kernel
         copies it to; ``gathered``: ``flat_grad`` already holds this step's (all-reduced) gradients; ``found_inf_extra``:
         float32[1] device tensor, non-zero = skip (the all-reduced verdict of the other ranks); ``stats_host_alt``: second
-        pinned buffer, used instead of ``stats_host`` when a bound step control block says parity 1 (graph replay)."""
+        pinned buffer, used instead of ``stats_host`` when a bound step control block says parity 1 (graph replay);
+        ``loss_scale``: device ``ww_loss_scale`` of the fp16 storage mode (gradients are unscaled first, the scale is
+        updated by GradScaler's rule; its slot is this optimizer's parity -- ``scale_slot``)."""
         if closure is not None:
             raise ValueError("FlatFusedOptimizer does not support closures")
         model = self._model
@@ -124,9 +126,15 @@ class FlatFusedOptimizer(optim.Optimizer):
                 off += n
         self._nat.clip_optim_step_(self._cfg(max_norm), model.flat_param, model.flat_grad, self._m, self._v,
                                    self._step_state, self._parity, norm_out=self.grad_norm, stats=stats,
-                                   stats_host=stats_host, found_inf_extra=found_inf_extra, stats_host_alt=stats_host_alt)
+                                   stats_host=stats_host, found_inf_extra=found_inf_extra, stats_host_alt=stats_host_alt,
+                                   loss_scale=loss_scale)
         self._parity ^= 1
         return None
+
+    @property
+    def scale_slot(self) -> int:
+        """Slot of ``ww_loss_scale`` the NEXT step reads (the loss kernel of that step must use the same one)."""
+        return self._parity
 
     def step_count(self) -> int:
         """Number of applied (not skipped) updates; synchronises."""
@@ -263,3 +271,36 @@ def clip_gradients(model: nn.Module, max_norm: float, norm_type: float = 2.0) ->
     if norm_type <= 0:
         raise ValueError(f"norm_type must be positive, got {norm_type}")
     return torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm, norm_type=norm_type).item()
+
+
+class DeviceGradScaler:
+    """What ``trainer.scaler`` is in the fp16 storage mode: torch.amp.GradScaler's state (scale, growth tracker and its
+    three hyper-parameters: create_grad_scaler, src/training/optimizer_factory.py:403-420) living in a device
+    ``ww_loss_scale`` that the loss kernel reads and the fused optimizer updates -- scale / unscale_ / step / update
+    (src/training/trainer.py:182-193) without a host round trip.  ``state_dict()`` has GradScaler's keys, so the
+    checkpoint's ``scaler_state_dict`` entry keeps its schema."""
+
+    def __init__(self, device, optimizer, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        from .. import _native as nat
+        self._nat, self._opt = nat, optimizer
+        self.state = nat.loss_scale_new(device, init_scale, growth_factor, backoff_factor, growth_interval)
+
+    def is_enabled(self) -> bool:
+        return True
+
+    def _read(self):
+        return self._nat.loss_scale_read(self.state, self._opt.scale_slot)
+
+    def get_scale(self) -> float:
+        return float(self._read()["scale"])
+
+    def state_dict(self):
+        r = self._read()
+        return {"scale": float(r["scale"]), "growth_factor": r["growth_factor"], "backoff_factor": r["backoff_factor"],
+                "growth_interval": r["growth_interval"], "_growth_tracker": int(r["growth_tracker"])}
+
+    def load_state_dict(self, sd):
+        if not sd:
+            return
+        self.state.copy_(self._nat.loss_scale_new("cpu", sd["scale"], sd["growth_factor"], sd["backoff_factor"],
+                                                  sd["growth_interval"], sd.get("_growth_tracker", 0)))

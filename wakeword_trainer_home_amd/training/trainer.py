@@ -95,12 +95,18 @@ class Trainer:
 
         self.optimizer, self.scheduler = create_optimizer_and_scheduler(self.model, config)
         self.use_mixed_precision = config.optimizer.mixed_precision
+        hip_backed = self.native or bool(getattr(self.model, "hip_backed", False))
         if self.native and self.use_mixed_precision:
-            # the reference's AMP switch (fp16 autocast + GradScaler, trainer.py:92,172) maps to the HIP path's
-            # reduced-precision mode: bf16 activation/gradient storage, fp32 arithmetic, no loss scaling needed
-            self.model.set_act_dtype("bf16")
-            logger.info("mixed_precision=True -> bf16 activation storage on the HIP path")
-        self.scaler = create_grad_scaler(enabled=self.use_mixed_precision and not self.native)
+            # the reference's AMP switch (fp16 autocast + GradScaler, trainer.py:92,172) maps to the HIP path's reduced-
+            # precision modes: 16-bit activation/gradient storage, fp32 arithmetic.  amp_dtype "bf16" (default; fp32's
+            # range, no loss scaling) or "fp16" (the reference's own type, with the device-side GradScaler below)
+            amp = str(getattr(config.optimizer, "amp_dtype", "bf16")).lower()
+            self.model.set_act_dtype(amp)
+            logger.info("mixed_precision=True -> %s activation storage on the HIP path", amp)
+        # HIP-backed models carry their precision mode themselves (act_dtype / mode at construction): never autocast
+        self._autocast = self.use_mixed_precision and not hip_backed
+        self.scaler = create_grad_scaler(enabled=self._autocast)
+        self.loss_scale = None             # device ww_loss_scale when the model stores fp16 (set below, needs the optimizer)
         self.gradient_clip = config.optimizer.gradient_clip
 
         self.train_metrics_tracker = MetricsTracker(device=device)
@@ -134,13 +140,21 @@ class Trainer:
         # host read sits between backward and optimizer.step(); with deferred_metrics a step's 48-byte stats are
         # resolved while the NEXT step is already running (callbacks fire one step late, same order and content).
         self._fused_optimizer = isinstance(self.optimizer, FlatFusedOptimizer)    # clip + update = one launch
+        if self._stores_fp16():
+            # fp16 storage: gradients travel times a dynamic loss scale; trainer.scaler keeps GradScaler's interface
+            if not (self._fused_optimizer and self._native_loss):
+                raise nat.NativeError("fp16 storage needs the fused clip + optimizer step and the native loss (adam / adamw / "
+                                      "sgd on a bucketed HIP model): the loss scale lives on the device between them")
+            from .optimizer_factory import DeviceGradScaler
+            self.scaler = DeviceGradScaler(self.device, self.optimizer)
+            self.loss_scale = self.scaler.state
+            self.criterion.loss_scale = self.loss_scale
         self._skip_on_device = self._fused_optimizer or bool(getattr(self.optimizer, "_step_supports_amp_scaling", False))
         # HIP-backed models that go through autograd (gru, crnn, mobilenetv3) get the same sync-free step: native loss stats,
         # device-side clip and skip decision, one deferred 48-byte read (the reference's step reads loss/acc/grad-norm back
         # three times per batch, trainer.py:177-209)
         self._async_autograd = (not self.native and self._native_loss and self._skip_on_device
-                                and bool(getattr(self.model, "hip_backed", False)) and not self.use_mixed_precision
-                                and torch.device(device).type == "cuda")
+                                and bool(getattr(self.model, "hip_backed", False)) and torch.device(device).type == "cuda")
         self.deferred_metrics = (bool(getattr(config.training, "deferred_metrics", True))
                                  and (self.native or self._async_autograd) and self._native_loss and self._skip_on_device)
         self._pending = None
@@ -312,7 +326,10 @@ class Trainer:
             logger.error("Unexpected error at batch %d: Target values must be in [0, 1]", batch_idx)
             return None
         if s["found_inf"] != 0.0:
-            logger.error("Non-finite loss detected at batch %d: %s", batch_idx, s["loss"])
+            if s["nonfinite"] or self.loss_scale is None:
+                logger.error("Non-finite loss detected at batch %d: %s", batch_idx, s["loss"])
+            else:      # GradScaler's skipped step: finite loss, gradients overflowed fp16 -- the scale has backed off
+                logger.warning("Gradient overflow at batch %d (loss %.6f): step skipped, loss scale reduced", batch_idx, s["loss"])
             return None
         self.train_metrics_tracker.update_counts(s["tp"], s["tn"], s["fp"], s["fn"])
         self.last_grad_norm = s["grad_norm"]
@@ -359,6 +376,8 @@ class Trainer:
         self.model.sample_offset = self.rank * inputs.shape[0]
         self.optimizer.zero_grad(set_to_none=True)
         flag = None
+        if self.loss_scale is not None:
+            self.criterion.loss_scale_slot = self.optimizer.scale_slot      # the loss kernel and the optimizer agree on it
         if not self._dist:
             stats = self.model.train_step_native(inputs, targets, self.criterion)     # fwd, loss, bwd: three C-ABI calls
         else:
@@ -388,7 +407,7 @@ class Trainer:
             # clip_gradients + "skip a non-finite batch" + optimizer.step() (trainer.py:177-193) in ONE launch, which also
             # writes the step's 48-byte record into pinned host memory
             self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats, stats_host=buf,
-                                found_inf_extra=flag)
+                                found_inf_extra=flag, loss_scale=self.loss_scale)
         else:
             if flag is not None:                   # some rank's bad batch -> every rank's found_inf
                 sv = stats.view(torch.float32)
@@ -477,7 +496,8 @@ class Trainer:
                 if self._dist:
                     self._reduce_inline(self.model.flat_grad_ext)
                 self.optimizer.step(max_norm=max_norm, stats=stats, stats_host=self._host_bufs[0],
-                                    stats_host_alt=self._host_bufs[1], found_inf_extra=flag, gathered=not self.native)
+                                    stats_host_alt=self._host_bufs[1], found_inf_extra=flag, gathered=not self.native,
+                                    loss_scale=self.loss_scale)
         finally:
             nat.bind_step_ctl(dev, None)
             for m in forked:
@@ -525,6 +545,10 @@ class Trainer:
         self._pending = launched
         return done
 
+    def _stores_fp16(self) -> bool:
+        return any(getattr(m, "act", None) == nat.ACT_F16 or getattr(m, "mode", None) == torch.float16
+                   for m in self.model.modules())
+
     def _graph_mode_key(self):
         """What a captured graph bakes besides shapes: the storage / matrix modes of the model's HIP modules."""
         return tuple((getattr(m, "act", None), str(getattr(m, "mode", None))) for m in self.model.modules()
@@ -563,6 +587,8 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         flag = self._dp_flag_slot()                # the loss kernel drops its skip flag behind the gradient bucket
         self.criterion.found_inf_out = flag
+        if self.loss_scale is not None:
+            self.criterion.loss_scale_slot = self.optimizer.scale_slot
         self.criterion(self.model(inputs), targets).backward()     # no reference to the autograd graph survives this line: a
         stats = self.criterion.last_stats                          # later graph capture needs fresh AccumulateGrad nodes
         if self._host_bufs is None:
@@ -577,7 +603,7 @@ class Trainer:
             if self._dist:
                 self._reduce_inline(self.model.flat_grad_ext)
             self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats, stats_host=buf, gathered=True,
-                                found_inf_extra=flag)
+                                found_inf_extra=flag, loss_scale=self.loss_scale)
         else:
             self._allreduce_grads()
             sv = stats.view(torch.float32)
@@ -624,7 +650,7 @@ class Trainer:
             targets = targets.to(self.device, non_blocking=True)
             if hasattr(self.model, "sample_offset"):
                 self.model.sample_offset = self.rank * inputs.shape[0]
-            with torch.autocast(dev_type, enabled=self.use_mixed_precision and dev_type == "cuda"):
+            with torch.autocast(dev_type, enabled=self._autocast and dev_type == "cuda"):
                 outputs = self.model(inputs)
                 loss = self.criterion(outputs, targets)
             finite = bool(torch.isfinite(loss))
@@ -672,7 +698,7 @@ class Trainer:
         inputs = self._to_model_input(inputs, training=False)
         targets = targets.to(self.device, non_blocking=True)
         dev_type = torch.device(self.device).type
-        with torch.autocast(dev_type, enabled=self.use_mixed_precision and dev_type == "cuda"):
+        with torch.autocast(dev_type, enabled=self._autocast and dev_type == "cuda"):
             outputs = self.model(inputs)
             loss = self.criterion(outputs, targets)
         if not torch.isfinite(loss):
