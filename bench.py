@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=512, help="clips per GPU per step")
-    ap.add_argument("--dtype", choices=("bf16", "f32"), default="bf16",
+    ap.add_argument("--dtype", choices=("bf16", "f32", "f16"), default="bf16",
                     help="storage of the conv-stack activations/gradients (arithmetic is fp32 either way); "
                          "BASELINE config 2 names bf16, f32 is the 1e-3 parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -216,8 +216,8 @@ def main():
     cfg.training.dp_overlap = args.dp_overlap
     torch.manual_seed(1234)                                   # same initial weights on every rank
     model = create_model("cnn_small", num_classes=2, pretrained=False, dropout=cfg.model.dropout,
-                         act_dtype="bf16" if args.dtype == "bf16" else "fp32")
-    esz = 2 if args.dtype == "bf16" else 4
+                         act_dtype={"bf16": "bf16", "f16": "fp16"}.get(args.dtype, "fp32"))
+    esz = 4 if args.dtype == "f32" else 2
     import contextlib
     import tempfile
     with contextlib.redirect_stdout(sys.stderr):          # stdout carries exactly ONE JSON line

@@ -194,3 +194,31 @@ def test_model_moved_after_optimizer_creation_fails_loudly():
     _set_grads(model, ref, torch.zeros(model.flat_param.numel()))
     with pytest.raises(nat.NativeError, match="moved after the optimizer was created"):
         opt.step()
+
+
+def test_frozen_parameters_go_to_torch_optim_not_the_fused_kernel():
+    """torch.optim skips a parameter without a gradient (no decay, no moment update); the fused kernel walks the whole
+    bucket.  So a model with a frozen parameter gets torch.optim from create_optimizer, the fused class refuses it, and a
+    bucketed model whose backward left a parameter without a gradient raises instead of updating it with a zero gradient."""
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training.optimizer_factory import FlatFusedOptimizer, create_optimizer
+    model = create_model("cnn_small", dropout=0.0).to(DEV)
+    model.stem.conv.weight.requires_grad_(False)
+    opt = create_optimizer(model, "adamw", learning_rate=1e-3, weight_decay=1e-2)
+    assert isinstance(opt, torch.optim.AdamW) and not isinstance(opt, FlatFusedOptimizer)
+    with pytest.raises(ValueError, match="frozen"):
+        FlatFusedOptimizer(model, "adamw", 1e-3)
+    m2 = create_model("mobilenetv3", dropout=0.0).to(DEV)
+    o2 = create_optimizer(m2, "adamw", learning_rate=1e-3, weight_decay=1e-2)
+    assert isinstance(o2, FlatFusedOptimizer)
+    m2.train()
+    m2(torch.randn(2, 1, 40, 51, device=DEV)).sum().backward()
+    next(iter(m2.parameters())).grad = None
+    with pytest.raises(RuntimeError, match="no gradient"):
+        m2.gather_grads()
+    sgd = create_optimizer(create_model("cnn_small", dropout=0.0).to(DEV), "sgd", learning_rate=0.1, momentum=0.0)
+    x = torch.randn(4, 1, 40, 51, device=DEV)
+    sgd._model.train()
+    sgd._model(x).sum().backward()
+    sgd.step()
+    assert all(st["momentum_buffer"] is None for st in sgd.state_dict()["state"].values())      # as torch.optim.SGD saves it

@@ -314,7 +314,8 @@ def test_library_exports_the_whole_c_abi():
 
 def test_flat_buckets_mixin_on_cpu():
     """models/flat_buckets.py (device-agnostic host logic): parameters become views of one flat tensor in parameters()
-    order, state_dict round-trips through the views, gather_grads fills missing gradients with zeros, _apply rebuilds."""
+    order, state_dict round-trips through the views, gather_grads copies every gradient and refuses a missing one (torch.optim
+    would skip that parameter; the bucketed step cannot), _apply rebuilds."""
     import torch.nn as nn
     from wakeword_trainer_home_amd.models.flat_buckets import FlatBuckets
 
@@ -339,11 +340,13 @@ def test_flat_buckets_mixin_on_cpu():
     assert torch.equal(flat[:12].view(4, 3), ref["a.weight"]) and net.flat_param.data_ptr() == flat.data_ptr()
     out = net.b(torch.relu(net.a(torch.ones(5, 3)))).sum()
     out.backward()
-    net.b.bias.grad = None                                         # a parameter without gradient -> zeros in its slot
     net.flat_grad.fill_(7.0)
     g = net.gather_grads()
-    assert torch.equal(g[:12].view(4, 3), net.a.weight.grad) and torch.equal(g[-2:], torch.zeros(2))
+    assert torch.equal(g[:12].view(4, 3), net.a.weight.grad) and torch.equal(g[-2:], net.b.bias.grad)
     assert not net.grads_in_bucket()
+    net.b.bias.grad = None                                         # a parameter without gradient: refused, not zero-filled
+    with pytest.raises(RuntimeError, match="no gradient"):
+        net.gather_grads()
     net.to("cpu", torch.float32)                                   # _apply -> rebuilt lazily
     assert net._fb_param is None and net.flat_param.numel() == flat.numel()
     import copy

@@ -19,11 +19,14 @@ from wakeword_trainer_home_amd.training import Trainer
 dev = "cuda:0"
 CONFIGS = (("crnn", 512, "bf16"), ("crnn", 4096, "bf16"), ("gru", 4096, "fp32"), ("mobilenetv3", 256, "bf16"),
            ("mobilenetv3", 2048, "bf16"))
-if len(sys.argv) > 1:                         # e.g.  bench_models.py crnn 4096 bf16
-    CONFIGS = ((sys.argv[1], int(sys.argv[2]), sys.argv[3]),)
+GRAPH = "--graph" in sys.argv                 # replay the step as a captured HIP graph (Trainer hip_graph mode)
+argv = [a for a in sys.argv[1:] if a != "--graph"]
+if argv:                                      # e.g.  bench_models.py crnn 4096 fp16 [--graph]
+    CONFIGS = ((argv[0], int(argv[1]), argv[2]),)
 for arch, B, act in CONFIGS:
     cfg = get_preset("cnn_small_logmel40")
     cfg.training.batch_size = B
+    cfg.training.hip_graph = GRAPH
     torch.manual_seed(0)
     kw = {"act_dtype": act} if arch == "crnn" else ({"mode": act} if arch == "mobilenetv3" else {})
     model = create_model(arch, dropout=0.3, **kw)
@@ -37,21 +40,24 @@ for arch, B, act in CONFIGS:
     def step(i):
         (tr._step_autograd_async if tr._async_autograd else tr._step_generic)(*pool[i % 2], i)
 
-    for i in range(3):
+    for i in range(5):
         step(i)
     torch.cuda.synchronize()
     n = 30 if B <= 1024 else 12
     t0 = time.perf_counter()
     for i in range(n):
-        step(3 + i)
+        step(5 + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     nat.prof_enable(dev, classes)
+    tr.use_hip_graph = False                   # the per-class event timing needs host-issued launches
     step(100)
     torch.cuda.synchronize()
     prof = {k: round(v[0], 3) for k, v in nat.prof_collect(dev).items()}
     nat.prof_enable(dev, [])
-    print(json.dumps({"model": arch, "batch": B, "conv_storage": act if arch == "crnn" else None, "ms_per_step": round(dt * 1e3, 3),
+    print(json.dumps({"model": arch, "batch": B, "conv_storage": act if arch == "crnn" else None, "matrix_mode": act,
+                      "hip_graph": tr._graph is not None, "loss_scale": tr.scaler.get_scale() if tr.loss_scale is not None else None,
+                      "ms_per_step": round(dt * 1e3, 3),
                       "samples_per_s": round(B / dt, 1), "class_ms_one_step": prof}))
     del tr, model, pool
     torch.cuda.empty_cache()

@@ -76,18 +76,13 @@ class FlatBuckets:
 
     @torch.no_grad()
     def gather_grads(self):
-        """Copy every ``.grad`` into its slot of ``flat_grad`` (two multi-tensor launches); a parameter without a
-        gradient contributes zeros, as it would to ``clip_grad_norm_`` and the optimizer."""
+        """Copy every ``.grad`` into its slot of ``flat_grad`` (one multi-tensor launch).  Every parameter must have a
+        gradient: the fused optimizer updates the whole bucket (decay and moments included), where torch.optim would skip a
+        parameter without one -- silently treating it as a zero gradient would make the two differ."""
         self._fb_ready()
-        dst, src, missing = [], [], []
-        for p, v in zip(self._fb_plist, self._fb_views):
-            if p.grad is None:
-                missing.append(v)
-            else:
-                dst.append(v)
-                src.append(p.grad)
+        missing = [i for i, p in enumerate(self._fb_plist) if p.grad is None]
         if missing:
-            torch._foreach_zero_(missing)
-        if dst:
-            torch._foreach_copy_(dst, src)
+            raise RuntimeError(f"gather_grads: {len(missing)} parameter(s) have no gradient (first index {missing[0]}); frozen or "
+                               "unused parameters are not supported by the bucketed optimizer step")
+        torch._foreach_copy_(self._fb_views, [p.grad for p in self._fb_plist])
         return self._fb_grad

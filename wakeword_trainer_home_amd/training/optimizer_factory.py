@@ -76,6 +76,12 @@ class FlatFusedOptimizer(optim.Optimizer):
         else:
             defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
                             foreach=None, capturable=False, differentiable=False, fused=None)
+        frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+        if frozen:
+            # the fused kernel walks the WHOLE bucket (decay and moment updates included); torch.optim skips parameters
+            # without a gradient -- create_optimizer() hands such models to torch.optim instead
+            raise ValueError(f"FlatFusedOptimizer updates every parameter of the bucket; frozen parameters {frozen[:3]}... "
+                             "are not supported (create_optimizer falls back to torch.optim for them)")
         super().__init__(list(model.parameters()), defaults)
         self._model = model
         flat = model.flat_param
@@ -122,7 +128,10 @@ class FlatFusedOptimizer(optim.Optimizer):
             off = 0
             for p in self.param_groups[0]["params"]:
                 n = p.numel()
-                model.flat_grad[off:off + n].copy_(p.grad.reshape(-1) if p.grad is not None else torch.zeros(n, device=p.device))
+                if p.grad is None:
+                    raise RuntimeError("FlatFusedOptimizer.step(): a parameter has no gradient; torch.optim would skip it, the "
+                                       "fused kernel cannot (it updates the whole bucket)")
+                model.flat_grad[off:off + n].copy_(p.grad.reshape(-1))
                 off += n
         self._nat.clip_optim_step_(self._cfg(max_norm), model.flat_param, model.flat_grad, self._m, self._v,
                                    self._step_state, self._parity, norm_out=self.grad_norm, stats=stats,
@@ -154,8 +163,9 @@ class FlatFusedOptimizer(optim.Optimizer):
         if t > 0:
             params = self.param_groups[0]["params"]
             if self._kind == self._nat.OPT_SGD:
+                mom = self.param_groups[0].get("momentum", 0.0) != 0.0
                 for p, m in zip(params, self._views(self._m)):
-                    self.state[p] = {"momentum_buffer": m.clone()}
+                    self.state[p] = {"momentum_buffer": m.clone() if mom else None}      # torch.optim.SGD: None without momentum
             else:
                 for p, m, v in zip(params, self._views(self._m), self._views(self._v)):
                     self.state[p] = {"step": torch.tensor(float(t)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
@@ -199,7 +209,7 @@ def create_optimizer(model: nn.Module, optimizer_name: str = "adam", learning_ra
     name = optimizer_name.lower()
     params = list(model.parameters())
     if (name in ("adam", "adamw", "sgd") and not kwargs and hasattr(model, "flat_param") and params
-            and all(p.is_cuda for p in params)):
+            and all(p.is_cuda and p.requires_grad for p in params)):
         # HIP-backed model: clip + update in one launch on the flat buckets (same update rules, same state_dict layout)
         return FlatFusedOptimizer(model, name, learning_rate, betas=betas, weight_decay=weight_decay, momentum=momentum)
     if name in ("adam", "adamw") and "fused" not in kwargs and params and all(p.is_cuda for p in params):
