@@ -28,7 +28,7 @@ for arch, B, act in CONFIGS:
     cfg.training.batch_size = B
     cfg.training.hip_graph = GRAPH
     torch.manual_seed(0)
-    kw = {"act_dtype": act} if arch == "crnn" else ({"mode": act} if arch == "mobilenetv3" else {})
+    kw = {"act_dtype": act} if arch == "crnn" else {"mode": act}
     model = create_model(arch, dropout=0.3, **kw)
     with contextlib.redirect_stdout(sys.stderr):
         tr = Trainer(model, [], [], cfg, checkpoint_dir=Path(tempfile.mkdtemp()), device=dev)

@@ -546,13 +546,15 @@ class Trainer:
         return done
 
     def _stores_fp16(self) -> bool:
-        return any(getattr(m, "act", None) == nat.ACT_F16 or getattr(m, "mode", None) == torch.float16
+        # (`act` is the storage code of the conv stack only -- the generic layers of MobileNetV3 use that name for their
+        # activation function)
+        return any((isinstance(m, CNNSmallWakeword) and m.act == nat.ACT_F16) or getattr(m, "mode", None) is torch.float16
                    for m in self.model.modules())
 
     def _graph_mode_key(self):
         """What a captured graph bakes besides shapes: the storage / matrix modes of the model's HIP modules."""
-        return tuple((getattr(m, "act", None), str(getattr(m, "mode", None))) for m in self.model.modules()
-                     if hasattr(m, "act") or hasattr(m, "mode"))
+        return tuple((m.act if isinstance(m, CNNSmallWakeword) else None, str(getattr(m, "mode", None)))
+                     for m in self.model.modules() if isinstance(m, CNNSmallWakeword) or hasattr(m, "mode"))
 
     def _graph_step_or_capture(self, feats, targets, step_index, batch_idx):
         """Graph mode of a sync-free step: replay when a graph for this feature shape exists, else None (the caller runs
