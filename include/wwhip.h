@@ -79,7 +79,8 @@ int ww_step_ctl_advance(ww_ctx *ctx, ww_stream_t stream);
  * log(mel+eps); MFCC = orthonormal DCT-II).  n_mfcc == 0 selects log-mel.            */
 typedef struct {
     int32_t sample_rate; /* src/config/defaults.py:15  (16000) */
-    int32_t n_fft;       /* :18 (1024; the only size implemented) */
+    int32_t n_fft;       /* :18 (1024: the size the fused kernel is built for; any other power of two in [64, 4096]
+                            takes a general radix-2 kernel -- validator.py:129 accepts 256 ... 4096) */
     int32_t hop;         /* :19 (160) */
     int32_t n_mels;      /* :20 (128; BASELINE config 2 uses 40); <= 128 */
     int32_t n_mfcc;      /* :17 ; 0 = log-mel output, else <= n_mels */

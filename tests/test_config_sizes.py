@@ -130,10 +130,10 @@ def test_config3_mobilenetv3_training_step_at_per_gpu_batch_256(mode):
         r = ((b.cpu().double() - ob[n].double()).abs() / 0.01 / var_b.sqrt()).max().item()
         worst_rs = max(worst_rs, r)
         assert r <= (1e-4 if mode == "fp32" else 2e-2), (n, r)
-        rv = (model.get_buffer(n.replace("running_mean", "running_var")).cpu().double() - ob[n.replace("running_mean", "running_var")].double()).abs() / 0.01 / var_b
-        # (the batch variance is recovered from fp32 running_var ~ 1: one ulp of it is 6e-6 of variance, i.e. up to ~2e-3
-        # of a small channel variance -- the floor of this check)
-        assert rv.max().item() <= (5e-3 if mode == "fp32" else 5e-2), (n, rv.max().item())
+        # (the batch variance is recovered from fp32 running_var ~ 1: one ulp of it is 6e-6 of variance -- percent-sized next
+        # to the 2e-4 variance of a nearly dead channel; the denominator is floored at 0.05 so those do not set the bound)
+        rv = (model.get_buffer(n.replace("running_mean", "running_var")).cpu().double() - ob[n.replace("running_mean", "running_var")].double()).abs() / 0.01 / (var_b + 0.05)
+        assert rv.max().item() <= (1e-3 if mode == "fp32" else 5e-2), (n, rv.max().item())
     print(f"config 3 mobilenetv3 B=256 {mode}: logits err {derr:.2e}, loss {loss.item():.6f} vs {lo.item():.6f}, grad rel {rel:.2e}, "
           f"cos {_cos(gd, go):.6f}, running stats worst rel {worst_rs:.2e}")
 

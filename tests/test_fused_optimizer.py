@@ -190,7 +190,9 @@ def test_model_moved_after_optimizer_creation_fails_loudly():
     from wakeword_trainer_home_amd import _native as nat
     model, ref = _model_pair(3)
     opt = create_optimizer(model, "adamw", learning_rate=1e-3)
-    model.float().to(DEV)                 # _apply: the parameters are re-created -> a new bucket
+    model.to("cpu")                       # a real move: every parameter gets storage of its own ...
+    model.to(DEV)                         # ... so the model builds a NEW bucket (a no-op .to() keeps the old one: the
+                                          # parameters still sit back to back in it and are adopted as they are)
     _set_grads(model, ref, torch.zeros(model.flat_param.numel()))
     with pytest.raises(nat.NativeError, match="moved after the optimizer was created"):
         opt.step()

@@ -123,6 +123,33 @@ def test_logmel_matches_oracle(nat, B, N, kw):
     _assert_logmel_close(out, ref, x, hop=hop, n_mels=n_mels, f_min=kw.get("f_min", 0.0), f_max=kw.get("f_max") or None)
 
 
+@pytest.mark.parametrize("n_fft,hop,n_mels,N", [(256, 64, 40, 8000), (512, 160, 40, 24000), (2048, 512, 64, 24000),
+                                                (4096, 160, 40, 24000), (512, 128, 128, 5000)])
+def test_logmel_other_fft_sizes_match_oracle(nat, n_fft, hop, n_mels, N):
+    """n_fft other than the reference default 1024 (its validator accepts 256 ... 4096, src/config/validator.py:129): the
+    general radix-2 kernel, same spec and bound; also int16 input, MFCC and the fused SpecAugment on that path."""
+    from oracle import features as OF
+    from oracle.specaugment import specaug_indices, specaug_apply
+    x = _waves(4, N, seed=n_fft)
+    cfg = nat.make_feat_cfg(n_fft=n_fft, hop=hop, n_mels=n_mels)
+    out = nat.logmel_fwd(cu(x), cfg).cpu().numpy()
+    ref = OF.logmel(x, n_fft=n_fft, hop=hop, n_mels=n_mels)
+    assert out.shape == ref.shape == (4, 1, n_mels, 1 + N // hop)
+    _assert_logmel_close(out, ref, x, n_fft=n_fft, hop=hop, n_mels=n_mels)
+    xi = np.round(x * 32767).astype(np.int16)
+    oi = nat.logmel_fwd(cu(xi, torch.int16), cfg).cpu().numpy()
+    _assert_logmel_close(oi, OF.logmel(xi.astype(np.float64) / 32768.0, n_fft=n_fft, hop=hop, n_mels=n_mels),
+                         xi.astype(np.float32) / 32768.0, n_fft=n_fft, hop=hop, n_mels=n_mels)
+    mf = nat.logmel_fwd(cu(x), nat.make_feat_cfg(n_fft=n_fft, hop=hop, n_mels=n_mels, n_mfcc=13)).cpu().numpy()
+    assert np.abs(mf - OF.mfcc(x, n_fft=n_fft, hop=hop, n_mels=n_mels, n_mfcc=13)).max() < 3e-3
+    T = 1 + N // hop
+    sa = dict(freq_mask_param=15, time_mask_param=min(35, T), n_freq_masks=2, n_time_masks=2, freq_mask_prob=0.7, time_mask_prob=0.7)
+    fused, idx = nat.logmel_fwd(cu(x), cfg, nat.make_specaug_cfg(**sa), seed=3, step=9, sample_offset=5, want_idx=True)
+    ridx = specaug_indices(4, n_mels, T, seed=3, step=9, sample_offset=5, **sa)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(fused.cpu().numpy(), specaug_apply(out, ridx, 2))
+
+
 def test_logmel_int16_and_mfcc_and_fused_specaug(nat):
     from oracle import features as OF
     from oracle.specaugment import specaug_indices, specaug_apply
@@ -149,7 +176,9 @@ def test_logmel_rejects_bad_input(nat):
     with pytest.raises(ValueError):
         nat.logmel_fwd(cu(np.zeros((2, 100), np.float32)), nat.make_feat_cfg())      # N <= n_fft/2
     with pytest.raises(nat.NativeError):
-        nat.logmel_fwd(cu(np.zeros((2, 4000), np.float32)), nat.make_feat_cfg(n_fft=512))
+        nat.logmel_fwd(cu(np.zeros((2, 4000), np.float32)), nat.make_feat_cfg(n_fft=1000))     # not a power of two
+    with pytest.raises(nat.NativeError):
+        nat.logmel_fwd(cu(np.zeros((2, 40000), np.float32)), nat.make_feat_cfg(n_fft=8192))   # beyond 4096
     with pytest.raises(nat.NativeError):
         nat.logmel_fwd(torch.zeros(2, 4000), nat.make_feat_cfg())                    # CPU tensor: no fallback
 

@@ -262,6 +262,85 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
     }
 }
 
+// ---- any other power-of-two n_fft (the reference's validator accepts 256 ... 4096, src/config/validator.py:129; 1024 is its
+// default and the size k_logmel is built for).  Plain and general rather than fast: one workgroup per (clip, frame), the
+// windowed frame bit-reversed into LDS as a complex sequence, log2(n_fft) radix-2 stages with the table twiddles, then the
+// same power -> mel -> log (-> DCT) -> SpecAugment law as k_logmel.
+template <typename WaveT>
+__global__ __launch_bounds__(256) void k_logmel_any(const WaveT *__restrict__ wave, FeatArgs a, int n_fft, int log2n,
+                                                    float *__restrict__ out, int use_mask, ww_mask_params mp,
+                                                    int32_t *__restrict__ mask_idx) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2 *buf = reinterpret_cast<float2 *>(smem);                   // n_fft
+    float *pw = reinterpret_cast<float *>(buf + n_fft);               // n_fft/2 + 1 (+ pad)
+    float *lmv = pw + n_fft / 2 + 4;                                  // M
+    float *fv = lmv + a.M;                                            // F (MFCC) -- == lmv otherwise
+    int *msk = reinterpret_cast<int *>(fv + (a.use_dct ? a.F : 0));   // 2*WW_MAX_MASKS
+    if (!a.use_dct) fv = lmv;
+    const int tid = threadIdx.x, b = blockIdx.y, t = blockIdx.x;
+    const WaveT *x = wave + (size_t)b * a.N;
+    const int K = use_mask ? (mp.n_f + mp.n_t) : 0;
+    if (tid < K) {
+        int s, w;
+        ww_specaug_mask(mp, (uint32_t)(mp.sample_offset + (uint64_t)b), tid, a.F, a.T, s, w);
+        msk[2 * tid] = s;
+        msk[2 * tid + 1] = w;
+        if (mask_idx && t == 0) {
+            mask_idx[((size_t)b * K + tid) * 2] = s;
+            mask_idx[((size_t)b * K + tid) * 2 + 1] = w;
+        }
+    }
+    const long base = (long)t * a.hop - n_fft / 2;
+    for (int i = tid; i < n_fft; i += 256) {
+        long idx = base + i;
+        if (idx < 0) idx = -idx;
+        if (idx >= a.N) idx = 2L * (a.N - 1) - idx;
+        const float v = a.window[i] * load_sample(x, (size_t)idx);
+        const int j = (int)(__brev((unsigned)i) >> (32 - log2n));
+        buf[j] = make_float2(v, 0.f);
+    }
+    __syncthreads();
+    for (int s = 0; s < log2n; ++s) {
+        const int half = 1 << s, tstep = n_fft >> (s + 1);
+        for (int k = tid; k < n_fft / 2; k += 256) {
+            const int pos = k & (half - 1), i0 = ((k >> s) << (s + 1)) + pos, i1 = i0 + half;
+            const float2 w = a.twiddle[pos * tstep], u = buf[i0], v = buf[i1];
+            const float vr = v.x * w.x - v.y * w.y, vi = v.x * w.y + v.y * w.x;
+            buf[i0] = make_float2(u.x + vr, u.y + vi);
+            buf[i1] = make_float2(u.x - vr, u.y - vi);
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j <= n_fft / 2; j += 256) pw[j] = buf[j].x * buf[j].x + buf[j].y * buf[j].y;
+    __syncthreads();
+    for (int m = tid; m < a.M; m += 256) {
+        const int s0 = a.mel_start[m], L = a.mel_len[m];
+        const float *wp = a.mel_w + a.mel_off[m];
+        float acc = 0.f;
+        for (int j = 0; j < L; ++j) acc = fmaf(wp[j], pw[s0 + j], acc);
+        lmv[m] = logf(acc + a.log_eps);
+    }
+    __syncthreads();
+    if (a.use_dct) {
+        for (int c = tid; c < a.F; c += 256) {
+            const float *d = a.dct + (size_t)c * a.M;
+            float acc = 0.f;
+            for (int m = 0; m < a.M; ++m) acc = fmaf(d[m], lmv[m], acc);
+            fv[c] = acc;
+        }
+        __syncthreads();
+    }
+    for (int f = tid; f < a.F; f += 256) {
+        float v = fv[f];
+        for (int k = 0; k < K; ++k) {
+            const int s = msk[2 * k], w = msk[2 * k + 1];
+            const int pos = k < mp.n_f ? f : t;
+            if (pos >= s && pos < s + w) v = 0.f;
+        }
+        out[((size_t)b * a.F + f) * a.T + t] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_specaug_apply(float *__restrict__ x, int B, int F, int T, ww_mask_params mp,
                                                        int32_t *__restrict__ mask_idx) {
     __shared__ int msk[2 * WW_MAX_MASKS];
@@ -322,8 +401,9 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
                              uint64_t sample_offset, int32_t *mask_idx, ww_stream_t stream) {
     WW_REQUIRE(ctx && wave && cfg && out, WW_E_INVALID, "ww_logmel_fwd: null argument");
     WW_REQUIRE(B >= 0 && N >= 0, WW_E_INVALID, "ww_logmel_fwd: negative shape");
-    WW_REQUIRE(cfg->n_fft == WW_NFFT, WW_E_UNSUPPORTED, "ww_logmel_fwd: n_fft=%d (only %d is implemented)",
-               cfg->n_fft, WW_NFFT);
+    WW_REQUIRE(cfg->n_fft >= 64 && cfg->n_fft <= 4096 && (cfg->n_fft & (cfg->n_fft - 1)) == 0, WW_E_UNSUPPORTED,
+               "ww_logmel_fwd: n_fft=%d (a power of two in [64, 4096] is implemented; the reference accepts 256 ... 4096)",
+               cfg->n_fft);
     WW_REQUIRE(cfg->hop >= 1 && cfg->hop <= WW_MAX_HOP, WW_E_UNSUPPORTED, "ww_logmel_fwd: hop=%d not in [1,%d]",
                cfg->hop, WW_MAX_HOP);
     WW_REQUIRE(cfg->n_mels >= 1 && cfg->n_mels <= WW_MAX_MELS, WW_E_UNSUPPORTED,
@@ -335,8 +415,8 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
                "ww_logmel_fwd: wave_dtype %d", wave_dtype);
     if (B == 0) return WW_OK;
     // reflect padding needs pad < N, as torch.stft(center=True, pad_mode='reflect') does
-    WW_REQUIRE(N > WW_NFFT / 2, WW_E_INVALID, "ww_logmel_fwd: N=%d must exceed n_fft/2=%d for reflect padding", N,
-               WW_NFFT / 2);
+    WW_REQUIRE(N > cfg->n_fft / 2, WW_E_INVALID, "ww_logmel_fwd: N=%d must exceed n_fft/2=%d for reflect padding", N,
+               cfg->n_fft / 2);
     ww_feat_tables *tb = nullptr;
     int rc = ww_get_feat_tables(ctx, cfg, &tb);
     if (rc) return rc;
@@ -355,6 +435,24 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
     if (sa) {
         if ((rc = resolve_mask(ctx, sa, seed, step, sample_offset, &mp))) return rc;
         use_mask = (mp.n_f + mp.n_t) > 0;
+    }
+    if (cfg->n_fft != WW_NFFT) {                       // the general radix-2 kernel: one workgroup per (clip, frame)
+        int log2n = 0;
+        while ((1 << log2n) < cfg->n_fft) ++log2n;
+        const size_t smem_any = (size_t)cfg->n_fft * sizeof(float2) + (size_t)(cfg->n_fft / 2 + 4) * sizeof(float) +
+                                (size_t)a.M * sizeof(float) + (a.use_dct ? (size_t)a.F * sizeof(float) : 0) +
+                                2 * WW_MAX_MASKS * sizeof(int);
+        hipStream_t st_any = (hipStream_t)stream;
+        ww_prof_scope ps_any(ctx, WW_K_LOGMEL, st_any);
+        dim3 grid_any(a.T, B);
+        if (wave_dtype == WW_WAVE_F32)
+            hipLaunchKernelGGL(k_logmel_any<float>, grid_any, dim3(256), smem_any, st_any, (const float *)wave, a, cfg->n_fft,
+                               log2n, out, use_mask, mp, mask_idx);
+        else
+            hipLaunchKernelGGL(k_logmel_any<int16_t>, grid_any, dim3(256), smem_any, st_any, (const int16_t *)wave, a,
+                               cfg->n_fft, log2n, out, use_mask, mp, mask_idx);
+        WW_LAUNCH_CHECK();
+        return WW_OK;
     }
     const size_t smem = (size_t)4 * BUF_ELEMS * sizeof(float2) + (size_t)4 * 2 * PB_LD * sizeof(float) +
                         (size_t)FR * a.M * sizeof(float) + (a.use_dct ? (size_t)FR * a.F * sizeof(float) : 0) +

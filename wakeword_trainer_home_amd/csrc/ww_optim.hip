@@ -6,9 +6,11 @@
 //   Adam / AdamW / SGD-Nesterov update, torch.optim's single-tensor formulas in fp32, bias corrections in double.
 // The step counter lives on the device (two slots, read slot[parity], write slot[parity^1]) so that a skipped step does
 // not advance it -- as in the reference, where optimizer.step() is simply not called -- without the host knowing.
-// Small buckets (<= 32 768 floats; cnn_small has 20 546) take ONE single-block launch for norm + clip + update with the
-// gradient held in registers; larger ones use k_grad_norm_clip followed by a grid-wide update.
+// Small buckets (<= 4 096 floats) take ONE single-block launch for norm + clip + update with the gradient held in
+// registers; larger ones (cnn_small has 20 546) block partial sums of squares followed by a grid-wide update.
 #include "ww_internal.h"
+#include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -234,7 +236,15 @@ extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *f
     OptimArgs a{cfg->kind, cfg->lr, cfg->beta1, cfg->beta2, cfg->eps, cfg->weight_decay, cfg->momentum, cfg->max_norm,
                 ctx->step_ctl, loss_scale};
     hipStream_t st = (hipStream_t)stream;
-    if (n <= (size_t)OPT_EPT * 1024) {
+    // Buckets of a few thousand parameters take ONE single-block launch; anything larger two grid-wide ones (block partial
+    // sums of squares, then every block of the update reduces them in the same order).  cnn_small's 20 546 parameters used
+    // to take the single block too: 33 us of a 1.39 ms step, latency-bound (one block cannot overlap its four dependent
+    // rounds of loads); the two-launch form is 14 us (r02: 1.387 -> 1.364 ms per step).  WW_OPTIM_SMALL_MAX overrides.
+    static const size_t small_max = []() {
+        const char *e = getenv("WW_OPTIM_SMALL_MAX");
+        return e ? (size_t)atol(e) : (size_t)4096;
+    }();
+    if (n <= std::min(small_max, (size_t)OPT_EPT * 1024)) {
         ww_prof_scope ps_(ctx, WW_K_CLIP, st);
         hipLaunchKernelGGL(k_clip_optim_small, dim3(1), dim3(1024), 0, st, a, flat_params, flat_grads, exp_avg, exp_avg_sq,
                            n, (long long *)step_state, parity, norm_out, stats, stats_host_dev, stats_host_alt_dev, found_inf_extra);
