@@ -13,6 +13,7 @@
 // Weight-gradient and statistic partials are per-block slabs summed in double by the
 // finalize kernels (bit-reproducible; no float atomics).
 #include "ww_internal.h"
+#include <stdlib.h>
 #include "ww_act.h"
 
 namespace {
