@@ -111,6 +111,7 @@ def test_mobilenetv3_matches_oracle():
     assert ((gd - go).norm() / go.norm()).item() <= 2e-3
     for (n, p), q in zip(model.named_parameters(), oracle.parameters()):        # and no tensor is off by itself
         assert (p.grad.cpu().double() - q.grad).norm().item() <= 1e-2 * q.grad.norm().item() + 1e-7, n
+    model.state_dict()                      # folds the host-side num_batches_tracked counts into the buffers
     for (n, b), (_, c) in zip(model.named_buffers(), oracle.named_buffers()):   # running statistics after one training step
         assert (b.cpu().double() - c.double()).abs().max().item() <= 1e-4 * c.double().abs().max().item() + 1e-7, n
     model.eval()
