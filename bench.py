@@ -51,13 +51,18 @@ LOGMEL_FLOPS = 4.41e6        # per clip: 151 frames x (rFFT-1024 + power + spars
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak, MI355X_MICROARCH.md
 
 
+BENCH_KERNEL_SOURCES = ("ww_frontend.hip", "ww_conv_fwd.hip", "ww_conv_bwd.hip", "ww_model.hip", "ww_act.h", "ww_fft.h",
+                        "ww_internal.h")
+
+
 def kernel_source_digest():
-    """sha1 over csrc/*.hip|*.h: ties a PMC traffic figure to the kernels it was measured on."""
+    """sha1 over the sources of the kernels this benchmark runs (front end + conv stack): ties a PMC traffic figure to the
+    kernels it was measured on."""
     import hashlib
     h = hashlib.sha1()
-    for f in sorted((ROOT / "wakeword_trainer_home_amd" / "csrc").glob("*.h*")):
-        h.update(f.name.encode())
-        h.update(f.read_bytes())
+    for name in BENCH_KERNEL_SOURCES:
+        h.update(name.encode())
+        h.update((ROOT / "wakeword_trainer_home_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()[:12]
 
 

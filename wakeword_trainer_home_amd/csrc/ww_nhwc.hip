@@ -344,14 +344,24 @@ __global__ __launch_bounds__(512) void k_dwg_bwd_dw4(const float *__restrict__ x
 }
 
 // ---- squeeze-excitation / pooling pieces on (B, HW, C)
-__global__ __launch_bounds__(256) void k_pool_fwd(const float *__restrict__ x, int B, int HW, int C, float *__restrict__ s) {
-    const long n = (long)B * C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C), b = (int)(i / C);
+// one workgroup per (image, group of 64 channels): 16 row lanes walk HW, fixed-order sum in LDS (a thread per (b, c)
+// walking HW alone was latency-bound: 16 us per call at B = 256)
+__global__ __launch_bounds__(1024) void k_pool_fwd(const float *__restrict__ x, int B, int HW, int C, float *__restrict__ s) {
+    __shared__ double sh[16][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6, cg = (C + 63) / 64;
+    const int b = blockIdx.x / cg, c = (blockIdx.x % cg) * 64 + cl;
+    double a = 0.0;
+    if (c < C) {
         const float *p = x + (size_t)b * HW * C + c;
-        double a = 0.0;
-        for (int h = 0; h < HW; ++h) a += p[(size_t)h * C];
-        s[i] = (float)(a / HW);
+        for (int h = part; h < HW; h += 16) a += p[(size_t)h * C];
+    }
+    sh[part][cl] = a;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sh[i][cl];
+        s[(size_t)b * C + c] = (float)(t / HW);
     }
 }
 // y = x * g[b][c]
@@ -364,16 +374,24 @@ __global__ __launch_bounds__(256) void k_scale_fwd(const float *__restrict__ x, 
         y[i] = x[i] * gte[b * C + c];
     }
 }
-// dg[b][c] = sum_hw dy * x
-__global__ __launch_bounds__(256) void k_scale_bwd_gate(const float *__restrict__ x, const float *__restrict__ dy, int B, int HW,
-                                                        int C, float *__restrict__ dg) {
-    const long n = (long)B * C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C), b = (int)(i / C);
+// dg[b][c] = sum_hw dy * x   (same thread map as k_pool_fwd)
+__global__ __launch_bounds__(1024) void k_scale_bwd_gate(const float *__restrict__ x, const float *__restrict__ dy, int B, int HW,
+                                                         int C, float *__restrict__ dg) {
+    __shared__ double sh[16][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6, cg = (C + 63) / 64;
+    const int b = blockIdx.x / cg, c = (blockIdx.x % cg) * 64 + cl;
+    double a = 0.0;
+    if (c < C) {
         const size_t o = (size_t)b * HW * C + c;
-        double a = 0.0;
-        for (int h = 0; h < HW; ++h) a += (double)dy[o + (size_t)h * C] * (double)x[o + (size_t)h * C];
-        dg[i] = (float)a;
+        for (int h = part; h < HW; h += 16) a += (double)dy[o + (size_t)h * C] * (double)x[o + (size_t)h * C];
+    }
+    sh[part][cl] = a;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sh[i][cl];
+        dg[(size_t)b * C + c] = (float)t;
     }
 }
 // dx = dy * g[b][c] + dpool[b][c] / HW     (dy nullable: plain pooling backward; dpool nullable: plain scaling backward)
@@ -515,7 +533,7 @@ extern "C" int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, c
 
 extern "C" int ww_pool_hw_fwd(ww_ctx *ctx, const float *x, int B, int HW, int C, float *s, ww_stream_t stream) {
     WW_REQUIRE(ctx && x && s && B >= 1 && HW >= 1 && C >= 1, WW_E_INVALID, "ww_pool_hw_fwd: bad argument");
-    hipLaunchKernelGGL(k_pool_fwd, dim3(egrid((long)B * C)), dim3(256), 0, (hipStream_t)stream, x, B, HW, C, s);
+    hipLaunchKernelGGL(k_pool_fwd, dim3(B * ((C + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, x, B, HW, C, s);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -528,7 +546,7 @@ extern "C" int ww_scale_bc_fwd(ww_ctx *ctx, const float *x, const float *gate, i
 extern "C" int ww_scale_bc_bwd_gate(ww_ctx *ctx, const float *x, const float *dy, int B, int HW, int C, float *dgate,
                                     ww_stream_t stream) {
     WW_REQUIRE(ctx && x && dy && dgate && B >= 1 && HW >= 1 && C >= 1, WW_E_INVALID, "ww_scale_bc_bwd_gate: bad argument");
-    hipLaunchKernelGGL(k_scale_bwd_gate, dim3(egrid((long)B * C)), dim3(256), 0, (hipStream_t)stream, x, dy, B, HW, C, dgate);
+    hipLaunchKernelGGL(k_scale_bwd_gate, dim3(B * ((C + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, x, dy, B, HW, C, dgate);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
