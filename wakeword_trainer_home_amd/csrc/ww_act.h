@@ -29,6 +29,11 @@ template <> struct Act<float> {
     static __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
     static __device__ __forceinline__ float round1(float v) { return v; }
     static __device__ __forceinline__ float2 round2(float2 v) { return v; }
+    static __device__ __forceinline__ float4 round4(float4 v) { return v; }
+    static __device__ __forceinline__ void st8(float *p, float4 a, float4 b) {      // 8 consecutive elements
+        *reinterpret_cast<float4 *>(p) = a;
+        *reinterpret_cast<float4 *>(p + 4) = b;
+    }
 };
 
 template <> struct Act<ww_bf16> {
@@ -54,6 +59,10 @@ template <> struct Act<ww_bf16> {
     }
     static __device__ __forceinline__ float2 round2(float2 v) { return cvt2(pack2(v.x, v.y)); }
     static __device__ __forceinline__ float round1(float v) { return __uint_as_float(pack2(v, 0.f) << 16); }
+    static __device__ __forceinline__ float4 round4(float4 v) { return cvt4(make_uint2(pack2(v.x, v.y), pack2(v.z, v.w))); }
+    static __device__ __forceinline__ void st8(ww_bf16 *p, float4 a, float4 b) {    // 8 consecutive elements: one 16-byte store
+        *reinterpret_cast<uint4 *>(p) = make_uint4(pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w));
+    }
 };
 
 template <> struct Act<ww_f16> {
@@ -80,6 +89,10 @@ template <> struct Act<ww_f16> {
     }
     static __device__ __forceinline__ float2 round2(float2 v) { return cvt2(pack2(v.x, v.y)); }
     static __device__ __forceinline__ float round1(float v) { return (float)(ww_f16)v; }
+    static __device__ __forceinline__ float4 round4(float4 v) { return cvt4(make_uint2(pack2(v.x, v.y), pack2(v.z, v.w))); }
+    static __device__ __forceinline__ void st8(ww_f16 *p, float4 a, float4 b) {
+        *reinterpret_cast<uint4 *>(p) = make_uint4(pack2(a.x, a.y), pack2(a.z, a.w), pack2(b.x, b.y), pack2(b.z, b.w));
+    }
 };
 
 // matrix-core forms of the two 16-bit types (8-element operands, fp32 accumulation; same cycles per instruction)

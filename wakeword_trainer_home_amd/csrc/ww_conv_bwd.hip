@@ -646,42 +646,79 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const
         w1[t] = RECOMP ? w[(2 * cl + 1) * 9 + t] : 0.f;
     }
     const long nrows = (long)B * Ho;
+    // the three input rows of an item are fetched into registers one item AHEAD and written to LDS at the top of the item
+    // (3 * ld <= 2 * 256 values; wider inputs are staged in place); the row's gradient pixels of a slot are loaded in ONE
+    // batch of up to ten before they are used -- one exposed HBM latency per row instead of one per pixel
+    float pre[2];
+    auto fetch = [&](long item) {
+        const int fb_ = (int)(item / Ho), foh = (int)(item - (long)fb_ * Ho);
+        const float *xb = x + (size_t)fb_ * Hin * Win;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + 256 * k;
+            const int kh = i / ld, c = i - kh * ld;
+            const int ih = 2 * foh - 1 + kh, iw = c - 1;
+            pre[k] = (i < 3 * ld && ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+        }
+    };
+    const bool ahead = 3 * ld <= 2 * 256;
+    if (ahead && (long)blockIdx.x < nrows) fetch(blockIdx.x);
     for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int b = (int)(row / Ho), oh = (int)(row - (long)b * Ho);
-        const float *xb = x + (size_t)b * Hin * Win;
         __syncthreads();
-        for (int i = tid; i < 3 * ld; i += 256) {
-            const int kh = i / ld, c = i - kh * ld;
-            const int ih = 2 * oh - 1 + kh, iw = c - 1;
-            xs[i] = (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+        if (ahead) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (tid + 256 * k < 3 * ld) xs[tid + 256 * k] = pre[k];
+        } else {
+            const float *xb = x + (size_t)b * Hin * Win;
+            for (int i = tid; i < 3 * ld; i += 256) {
+                const int kh = i / ld, c = i - kh * ld;
+                const int ih = 2 * oh - 1 + kh, iw = c - 1;
+                xs[i] = (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+            }
         }
         __syncthreads();
-        for (int ow = slot; ow < Wo; ow += 8) {
-            const size_t o = ((size_t)row * Wo + ow) * 64 + 2 * cl;
-            const float2 gz = Act<T>::cvt2(Act<T>::ldraw2(g + o));
-            float v[9];
+        if (ahead && row + gridDim.x < nrows) fetch(row + gridDim.x);
+        for (int ow0 = slot; ow0 < Wo; ow0 += 80) {
+            typename Act<T>::raw2 gr[10], yr[10];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) v[kh * 3 + kw] = xs[kh * ld + 2 * ow + kw];
-            float2 yo;
-            if constexpr (RECOMP) {
-                float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {            // k_stem_fwd's accumulation order
-                    a0 = fmaf(v[t], w0[t], a0);
-                    a1 = fmaf(v[t], w1[t], a1);
-                }
-                yo = Act<T>::round2(make_float2(a0, a1));
-            } else {
-                yo = Act<T>::cvt2(Act<T>::ldraw2(y_out + o));
+            for (int j = 0; j < 10; ++j) {
+                const int ow = min(ow0 + 8 * j, Wo - 1);
+                const size_t o = ((size_t)row * Wo + ow) * 64 + 2 * cl;
+                gr[j] = Act<T>::ldraw2(g + o);
+                if constexpr (!RECOMP) yr[j] = Act<T>::ldraw2(y_out + o);
             }
-            const float d0 = fmaf(cA.x, gz.x, fmaf(cB.x, yo.x, cC.x));
-            const float d1 = fmaf(cA.y, gz.y, fmaf(cB.y, yo.y, cC.y));
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                dwa[t] = fmaf(d0, v[t], dwa[t]);
-                dwb[t] = fmaf(d1, v[t], dwb[t]);
+            for (int j = 0; j < 10; ++j) {
+                const int ow = ow0 + 8 * j;
+                if (ow < Wo) {
+                    const float2 gz = Act<T>::cvt2(gr[j]);
+                    float v[9];
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) v[kh * 3 + kw] = xs[kh * ld + 2 * ow + kw];
+                    float2 yo;
+                    if constexpr (RECOMP) {
+                        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) {            // k_stem_fwd's accumulation order
+                            a0 = fmaf(v[t], w0[t], a0);
+                            a1 = fmaf(v[t], w1[t], a1);
+                        }
+                        yo = Act<T>::round2(make_float2(a0, a1));
+                    } else {
+                        yo = Act<T>::cvt2(yr[j]);
+                    }
+                    const float d0 = fmaf(cA.x, gz.x, fmaf(cB.x, yo.x, cC.x));
+                    const float d1 = fmaf(cA.y, gz.y, fmaf(cB.y, yo.y, cC.y));
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        dwa[t] = fmaf(d0, v[t], dwa[t]);
+                        dwb[t] = fmaf(d1, v[t], dwb[t]);
+                    }
+                }
             }
         }
     }

@@ -51,52 +51,100 @@ __device__ __forceinline__ void reduce_stats_slots(float s0, float s1, float q0,
 }
 
 // ------------------------------------------------------------------------------------- stem
-// x (B,Hin,Win) -> y (B,Ho,Wo,64) ; 3x3 stride 2 pad 1 ; one (b,oh) output row per iteration.
-// The three input rows are staged zero-padded in LDS, so the inner loop is 9 LDS broadcast reads + 18 FMAs per
-// pixel (the first version re-derived bounds per tap from global memory and was instruction-issue-bound).
+// x (B,Hin,Win) -> y (B,Ho,Wo,64) ; 3x3 stride 2 pad 1 ; TWO (b,oh) output rows per iteration.
+// The five input rows are staged zero-padded in LDS (one barrier pair per two rows).  Thread map: 8 lanes = one pixel, a
+// lane owns 8 consecutive channels -- 9 LDS broadcast reads feed 72 FMAs, and the result leaves as ONE 16-byte (16-bit
+// storage) or two 16-byte (fp32) stores per lane, 1 KB per wave-instruction.  (r01: 2 channels per lane, 4-byte stores, one
+// row per barrier pair -- 39.7 us for 100 MB of output, store-issue-bound.)  The nine taps are accumulated in the fixed
+// order kh-major / kw-minor: k_stem_bwd recomputes this tensor with the same chain.
 template <typename T>
 __global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ x, const float *__restrict__ w, int B,
                                                   int Hin, int Win, int Ho, int Wo, T *__restrict__ y,
                                                   float *__restrict__ partials) {
-    __shared__ float sh[8 * 128];
-    extern __shared__ float xs[];            // [3][Win + 2] : xs[kh][iw + 1], zero outside the image
-    const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
+    __shared__ float sh[32 * 128];
+    extern __shared__ float xs[];            // [5][Win + 2] : xs[r][iw + 1], zero outside the image
+    const int tid = threadIdx.x, px = tid >> 3, c8 = tid & 7;
     const int ld = Win + 2;
-    float w0[9], w1[9];
+    float wr[8][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        w0[t] = w[(2 * cl) * 9 + t];
-        w1[t] = w[(2 * cl + 1) * 9 + t];
-    }
-    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-    const long nrows = (long)B * Ho;
-    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
-        const int b = (int)(row / Ho), oh = (int)(row - (long)b * Ho);
-        const float *xb = x + (size_t)b * Hin * Win;
-        __syncthreads();                     // previous row's readers are done
-        for (int i = tid; i < 3 * ld; i += 256) {
-            const int kh = i / ld, c = i - kh * ld;
-            const int ih = 2 * oh - 1 + kh, iw = c - 1;
-            xs[i] = (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[j][t] = w[(8 * c8 + j) * 9 + t];
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    const long npairs = (long)B * ((Ho + 1) / 2);
+    // the five input rows of an item are fetched into registers one item AHEAD (their HBM latency hides behind the
+    // previous item's FMAs) and written to LDS at the top of the item: 5 * ld <= 4 * 256 values
+    float pre[4];
+    auto fetch = [&](long item) {
+        const int fb_ = (int)(item / ((Ho + 1) / 2)), foh = 2 * (int)(item - (long)fb_ * ((Ho + 1) / 2));
+        const float *xb = x + (size_t)fb_ * Hin * Win;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + 256 * k;
+            const int r = i / ld, c = i - r * ld;
+            const int ih = 2 * foh - 1 + r, iw = c - 1;
+            pre[k] = (i < 5 * ld && ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+        }
+    };
+    const bool ahead = 5 * ld <= 4 * 256;    // wider inputs (T > 202 frames) are staged in place
+    if (ahead && (long)blockIdx.x < npairs) fetch(blockIdx.x);
+    for (long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
+        const int b = (int)(pr / ((Ho + 1) / 2)), oh0 = 2 * (int)(pr - (long)b * ((Ho + 1) / 2));
+        __syncthreads();                     // previous pair's readers are done
+        if (ahead) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (tid + 256 * k < 5 * ld) xs[tid + 256 * k] = pre[k];
+        } else {
+            const float *xb = x + (size_t)b * Hin * Win;
+            for (int i = tid; i < 5 * ld; i += 256) {
+                const int r = i / ld, c = i - r * ld;
+                const int ih = 2 * oh0 - 1 + r, iw = c - 1;
+                xs[i] = (ih >= 0 && ih < Hin && iw >= 0 && iw < Win) ? xb[(size_t)ih * Win + iw] : 0.f;
+            }
         }
         __syncthreads();
-        for (int ow = slot; ow < Wo; ow += 8) {
-            float a0 = 0.f, a1 = 0.f;
+        if (ahead && pr + gridDim.x < npairs) fetch(pr + gridDim.x);
+        const int nrow = min(2, Ho - oh0);
+        for (int it = px; it < nrow * Wo; it += 32) {
+            const int rr = it >= Wo ? 1 : 0, ow = it - rr * Wo;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const float v = xs[kh * ld + 2 * ow + kw];
-                    a0 = fmaf(v, w0[kh * 3 + kw], a0);
-                    a1 = fmaf(v, w1[kh * 3 + kw], a1);
+                    const float v = xs[(2 * rr + kh) * ld + 2 * ow + kw];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, wr[j][kh * 3 + kw], acc[j]);
                 }
-            const float2 o = Act<T>::round2(make_float2(a0, a1));
-            Act<T>::st2(y + ((size_t)row * Wo + ow) * 64 + 2 * cl, o);
-            s0 += o.x; s1 += o.y;
-            q0 = fmaf(o.x, o.x, q0); q1 = fmaf(o.y, o.y, q1);
+            T *dst = y + (((size_t)b * Ho + oh0 + rr) * Wo + ow) * 64 + 8 * c8;
+            float4 o0 = Act<T>::round4(make_float4(acc[0], acc[1], acc[2], acc[3]));
+            float4 o1 = Act<T>::round4(make_float4(acc[4], acc[5], acc[6], acc[7]));
+            Act<T>::st8(dst, o0, o1);
+            s[0] += o0.x; s[1] += o0.y; s[2] += o0.z; s[3] += o0.w; s[4] += o1.x; s[5] += o1.y; s[6] += o1.z; s[7] += o1.w;
+            q[0] = fmaf(o0.x, o0.x, q[0]); q[1] = fmaf(o0.y, o0.y, q[1]); q[2] = fmaf(o0.z, o0.z, q[2]); q[3] = fmaf(o0.w, o0.w, q[3]);
+            q[4] = fmaf(o1.x, o1.x, q[4]); q[5] = fmaf(o1.y, o1.y, q[5]); q[6] = fmaf(o1.z, o1.z, q[6]); q[7] = fmaf(o1.w, o1.w, q[7]);
         }
     }
-    if (partials) reduce_stats_slots(s0, s1, q0, q1, sh, partials + (size_t)blockIdx.x * 128);
+    if (partials) {                          // 32 pixel lanes x [sum(64) | sumsq(64)] -> one partial row, fixed order
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sh[px * 128 + 8 * c8 + j] = s[j];
+            sh[px * 128 + 64 + 8 * c8 + j] = q[j];
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) t += sh[i * 128 + tid];
+            partials[(size_t)blockIdx.x * 128 + tid] = t;
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------- depthwise
@@ -517,8 +565,8 @@ template <typename T>
 int launch_stem_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int Hin, int Win, void *y, float *partials,
                     int *grid_out, hipStream_t st) {
     const int Ho = (Hin + 1) / 2, Wo = (Win + 1) / 2;
-    const long nrows = (long)B * Ho;
-    const size_t smem = (size_t)3 * (Win + 2) * sizeof(float);
+    const long nrows = (long)B * ((Ho + 1) / 2);          // work items: pairs of output rows
+    const size_t smem = (size_t)5 * (Win + 2) * sizeof(float);
     const int grid = ww_occupancy_grid((const void *)k_stem_fwd<T>, 256, smem, nrows, WW_MAX_PARTIALS);
     {
         ww_prof_scope ps_(ctx, WW_K_STEM_FWD, st);
