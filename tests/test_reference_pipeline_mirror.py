@@ -119,7 +119,7 @@ def test_8_to_10_training_loop_checkpointing_and_loading(tmp_path, arch):
     config.training.batch_size = 8
     config.training.early_stopping_patience = 10
     # the defaults' warmup_epochs (3) is not < epochs (3): create_scheduler raises on that -- in the reference too
-    # (optimizer_factory.py:297-300; its test script logs the step as failed).  Pin the behaviour, then train with a valid one.
+    # (optimizer_factory.py:253; its test script logs the step as failed).  Pin the behaviour, then train with a valid one.
     with pytest.raises(ValueError, match=r"Warmup epochs \(3\) must be less than total epochs \(3\)"):
         Trainer(model=create_model(arch, num_classes=2, pretrained=False), train_loader=[], val_loader=[], config=config,
                 checkpoint_dir=tmp_path / "never", device=DEV)
