@@ -360,9 +360,11 @@ def main():
                          # rooflines -- latency/LDS-bound FFT; algorithmic 120 160 B and 4.41 MFLOP per clip
                          "side_stream": {"kernel": "logmel_specaug",
                                          "algorithmic_bytes_per_launch": ALGO_BYTES["logmel_specaug"] * args.batch,
-                                         "alone": logmel_leg(alone, "idle GPU, before the timed region"),
+                                         "alone": logmel_leg(alone, "idle GPU, before the timed region, full-device grid"),
                                          "in_step": logmel_leg(prof.get("logmel_specaug", (0.0, 0)),
-                                                               "timed region, sharing the CUs with the conv kernels")}},
+                                                               "timed region, sharing the CUs with the conv kernels, "
+                                                               f"{trainer.input_stage_workgroups} persistent workgroups "
+                                                               "(Trainer.input_stage_workgroups: one per CU)")}},
             # HIP-event SPANS around each class's launches during the warm-up steps (all classes on): they include queue
             # gaps and the stretch of running beside the other stream, so they do not add up to ms_per_step
             "event_span_ms_per_step_warmup": {k: round(v[0] / max(args.warmup, 1), 4) for k, v in sorted(warm.items())},

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 7
+#define WW_ABI_VERSION 8
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -111,6 +111,12 @@ int ww_feat_num_frames(int n_samples, int hop);
 int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int B, int N, const ww_feat_cfg *cfg,
                   float *out, const ww_specaug_cfg *sa, uint64_t seed, uint64_t step,
                   uint64_t sample_offset, int32_t *mask_idx, ww_stream_t stream);
+
+/* How many persistent workgroups the log-mel kernel is launched with from now on: 0 (default) = one full residency round
+ * of the device -- the front end running alone (feature extraction, validation); n > 0 = at most n -- a front end that
+ * runs on a side stream BESIDE a training step, where its resident workgroups take registers / LDS from the conv kernels
+ * (Trainer: one per CU).  A launch parameter only: results are identical for every n.            */
+int ww_ctx_set_logmel_workgroups(ww_ctx *ctx, int n);
 
 /* In-place SpecAugment on ready-made features x (B,1,F,T).                             */
 int ww_specaug_apply(ww_ctx *ctx, float *x, int B, int F, int T, const ww_specaug_cfg *sa,

@@ -172,6 +172,31 @@ def test_logmel_int16_and_mfcc_and_fused_specaug(nat):
     assert np.array_equal(fused.cpu().numpy(), specaug_apply(plain, ridx, 2))
 
 
+def test_logmel_persistent_grid_size_does_not_change_results(nat):
+    """ww_ctx_set_logmel_workgroups is a launch parameter: one workgroup walking every (clip, frame block) item, three, one
+    per item and the full-device default all give the same bits -- features, MFCC and the SpecAugment rows (which only the
+    first block of a clip reports)."""
+    x = cu(_waves(7, 24000, seed=21))
+    xi = cu(np.round(_waves(3, 9000, seed=22) * 32767).astype(np.int16), torch.int16)
+    sa = nat.make_specaug_cfg(freq_mask_param=15, time_mask_param=35, n_freq_masks=2, n_time_masks=2, freq_mask_prob=0.6,
+                              time_mask_prob=0.6)
+
+    def run():
+        f, idx = nat.logmel_fwd(x, nat.make_feat_cfg(), sa, seed=5, step=2, sample_offset=40, want_idx=True)
+        return f, idx, nat.logmel_fwd(x, nat.make_feat_cfg(n_mfcc=13)), nat.logmel_fwd(xi, nat.make_feat_cfg(n_mels=64))
+
+    ref = run()
+    try:
+        for n in (1, 3, 64, 70, 100000):
+            nat.set_logmel_workgroups("cuda:0", n)
+            for a, b in zip(run(), ref):
+                assert torch.equal(a, b), n
+        with pytest.raises(ValueError):
+            nat.set_logmel_workgroups("cuda:0", -1)
+    finally:
+        nat.set_logmel_workgroups("cuda:0", 0)
+
+
 def test_logmel_rejects_bad_input(nat):
     with pytest.raises(ValueError):
         nat.logmel_fwd(cu(np.zeros((2, 100), np.float32)), nat.make_feat_cfg())      # N <= n_fft/2

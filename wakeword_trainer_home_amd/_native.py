@@ -13,7 +13,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 BWD_ALL, BWD_LATE, BWD_EARLY = 0, 1, 2
 ACT_F32, ACT_BF16, ACT_F16 = 0, 1, 2
 LOSS_CE, LOSS_FOCAL = 0, 1
@@ -104,6 +104,7 @@ _SIGS = {
     "ww_ctx_create": (C.c_int, [_i, C.POINTER(_vp)]),
     "ww_ctx_destroy": (C.c_int, [_vp]),
     "ww_ctx_bind_step_ctl": (C.c_int, [_vp, _vp]),
+    "ww_ctx_set_logmel_workgroups": (C.c_int, [_vp, C.c_int]),
     "ww_step_ctl_advance": (C.c_int, [_vp, _vp]),
     "ww_feat_num_frames": (C.c_int, [_i, _i]),
     "ww_logmel_fwd": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(FeatCfg), _vp, C.POINTER(SpecAugCfg), _u64, _u64, _u64,
@@ -641,6 +642,12 @@ def step_ctl_write(ctl, step=None, lr=None, parity=None):
 def step_ctl_read(ctl) -> dict:
     s = StepCtl.from_buffer_copy(bytes(ctl.cpu().numpy().tobytes()))
     return {"step": s.step, "lr": s.lr, "parity": s.parity, "loss_scale": s.loss_scale, "growth_tracker": s.growth_tracker}
+
+
+def set_logmel_workgroups(dev, n: int):
+    """Persistent workgroups of the log-mel kernel for the launches that follow on ``dev``: 0 = fill the device (the front
+    end alone), n > 0 = at most n (a front end running beside a training step; results do not depend on it)."""
+    _check(load().ww_ctx_set_logmel_workgroups(ctx(dev), int(n)), "ww_ctx_set_logmel_workgroups")
 
 
 def bind_step_ctl(dev, ctl):

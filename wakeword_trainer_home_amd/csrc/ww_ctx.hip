@@ -50,6 +50,7 @@ extern "C" int ww_ctx_create(int device, ww_ctx **out) {
     c->tables = nullptr;
     c->prof_mask = 0;
     c->step_ctl = nullptr;
+    c->logmel_wgs = 0;
     c->tw16k = nullptr;
     c->norm_partials = nullptr;
     c->prof_recs = new std::vector<ww_prof_rec>();
@@ -68,6 +69,13 @@ extern "C" int ww_ctx_bind_step_ctl(ww_ctx *ctx, const ww_step_ctl *ctl_dev) {
     WW_REQUIRE(ctx != nullptr, WW_E_INVALID, "ww_ctx_bind_step_ctl: ctx is null");
     WW_REQUIRE(((uintptr_t)ctl_dev & 7) == 0, WW_E_INVALID, "ww_ctx_bind_step_ctl: the control block must be 8-byte aligned");
     ctx->step_ctl = ctl_dev;
+    return WW_OK;
+}
+
+extern "C" int ww_ctx_set_logmel_workgroups(ww_ctx *ctx, int n) {
+    WW_REQUIRE(ctx != nullptr, WW_E_INVALID, "ww_ctx_set_logmel_workgroups: ctx is null");
+    WW_REQUIRE(n >= 0, WW_E_INVALID, "ww_ctx_set_logmel_workgroups: n=%d must be >= 0", n);
+    ctx->logmel_wgs = n;
     return WW_OK;
 }
 

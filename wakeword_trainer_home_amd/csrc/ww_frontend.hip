@@ -5,23 +5,19 @@
 // padded at the clip edges) is read ONCE from HBM with coalesced loads into LDS; every later
 // access (6.4x frame overlap at hop 160) is served from LDS.  Each wavefront transforms TWO
 // real frames as one 1024-point complex FFT held 16 points/lane, decomposed 16 x 16 x 4:
-//   pass 1  radix-16 in registers over n2 (n = lane + 64*n2), twiddle W1024^(lane*kb) -> LDS
+//   pass 1  radix-16 in registers over n2 (n = lane + 64*n2), twiddle W1024^(lane*kb) -> LDS (re plane, then im plane)
 //   pass 2  radix-16 in registers over m  (lane = kb*4+q, n1 = 4m+q), twiddle W64^(q*kc) -> LDS (in place: each lane
-//           rewrites exactly the 16 slots it read, so one 8.7 KB buffer per wavefront suffices)
+//           rewrites exactly the 16 slots it read, so one 4.4 KB tile per wavefront suffices)
 //   pass 3  radix-4 butterflies X[16kc + 256kd + kb], run in PAIRS that produce X[k] and X[N-k] in the same lane: the two
 //           real spectra are separated in registers and |.|^2 goes straight to the power buffers (no return to LDS)
-// The window samples and the twiddle factors a lane needs are the same for every frame: they are loaded once into
-// registers (16 + 24 VGPRs; the kernel runs two workgroups per CU on its LDS footprint, so VGPRs are free).  Every mel
-// band is then summed by two adjacent lanes (half a band each, weights staged in LDS, combined with one shuffle), and the
-// 16 x F tile is transposed through LDS so the (B,1,F,T) output is written in 64-byte runs along T.
+// Every mel band is then summed by two adjacent lanes (half a band each, weights staged in LDS, combined with one
+// shuffle), and the 16 x F tile is transposed through LDS so the (B,1,F,T) output is written in 64-byte runs along T.
 // Index algebra verified against numpy (tests/test_frontend_index_algebra.py).
 #include "ww_internal.h"
 
 namespace {
 
 constexpr int FR = WW_FRAMES_PER_BLOCK;
-constexpr int BUF_STRIDE = 68;               // float2 per kb row (64 + 4 pad)
-constexpr int BUF_ELEMS = 16 * BUF_STRIDE;   // 1088 float2 per buffer
 constexpr int PB_LD = 548;                   // floats per power spectrum: bin j sits at j + (j >> 4) (bank spreading)
 
 #include "ww_fft.h"
@@ -65,40 +61,49 @@ __device__ __forceinline__ Tw6 load_tw6(const float2 *__restrict__ tw, int base)
     }
     return t;
 }
-template <typename Dst>
-__device__ __forceinline__ void twiddle_store16(float (&re)[16], float (&im)[16], const Tw6 &t, Dst dst) {
+// Built for a SMALL per-CU footprint: in training the front end runs on a side stream beside the conv stack, and what it
+// costs the step there is the registers and LDS its resident workgroups hold (the r01 form of this kernel -- complex
+// exchange tiles, window and twiddles in registers: 242 VGPRs, 73 KB -- left a SIMD room for ONE 168-VGPR
+// depthwise-backward wave instead of three).  The FFT passes exchange re and im one after the other through ONE 4.4 KB tile
+// per wavefront (the power rows reuse it), the window lives in LDS and the twiddle factors of a pass are loaded from the
+// L1-resident table right before it: 119 VGPRs, 41 KB LDS per workgroup.  The grid is PERSISTENT (a workgroup walks items
+// = (clip, block of FR frames) in steps of gridDim.x; window / mel tables staged once), and its size is the caller's
+// choice (ww_ctx_set_logmel_workgroups): the whole device when the front end runs alone, one workgroup per CU beside a
+// training step.
+constexpr int PROW = 68;                     // floats per kb row of the exchange tile (64 + 4 pad: conflict-free both ways)
+constexpr int XB = 2 * PB_LD;                // floats per wavefront tile (>= 16 * PROW = 1088)
+static_assert(XB >= 16 * PROW, "tile too small for the exchange planes");
+
+__device__ __forceinline__ void twiddle16(float (&re)[16], float (&im)[16], const Tw6 &t) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        float r = re[F16_SLOT(k)], i = im[F16_SLOT(k)];
+    for (int k = 1; k < 16; ++k) {
         const int a = k >> 2, b = k & 3;
         float wr, wi;
         if (a == 0) { wr = t.t1[b].x; wi = t.t1[b].y; }
         else if (b == 0) { wr = t.t4[a].x; wi = t.t4[a].y; }
         else { wr = t.t4[a].x; wi = t.t4[a].y; cmul_c(wr, wi, t.t1[b].x, t.t1[b].y); }
-        if (k) cmul_c(r, i, wr, wi);
-        *dst(k) = make_float2(r, i);
+        cmul_c(re[F16_SLOT(k)], im[F16_SLOT(k)], wr, wi);
     }
 }
 
 template <typename WaveT>
-__global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ out,
-                                                int use_mask, ww_mask_params mp, int32_t *__restrict__ mask_idx) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ out, int use_mask, ww_mask_params mp,
+                     int32_t *__restrict__ mask_idx, int nblk, long nitems) {
     extern __shared__ __align__(16) unsigned char smem[];
-    float2 *fbuf = reinterpret_cast<float2 *>(smem);                  // 4 waves x BUF_ELEMS
-    float *pb = reinterpret_cast<float *>(fbuf + 4 * BUF_ELEMS);      // 4 waves x 2 x PB_LD power spectra
-    float *lm = pb + 4 * 2 * PB_LD;                                    // FR x M
+    float *xball = reinterpret_cast<float *>(smem);                   // 4 waves x XB
+    float *wl = xball + 4 * XB;                                       // the 1024 window samples
+    float *span = wl + WW_NFFT;                                       // span_len (16-byte aligned: vector staging)
+    float *lm = span + ((a.span_len + 3) & ~3);                       // FR x M (raw mel sums, then their logs)
     float *feat = lm + FR * a.M;                                      // FR x F (== lm when !use_dct)
     int *msk = reinterpret_cast<int *>(feat + (a.use_dct ? FR * a.F : 0));  // 2*WW_MAX_MASKS
     int *mtab = msk + 2 * WW_MAX_MASKS;                               // 3*M : start, len, offset
     float *mw = reinterpret_cast<float *>(mtab + 3 * a.M);            // n_mel_w band weights
-    float *span = mw + a.n_mel_w;                                     // span_len
     if (!a.use_dct) feat = lm;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b = blockIdx.y, t0 = blockIdx.x * FR;
-    const WaveT *x = wave + (size_t)b * a.N;
-
-    // ---- stage twiddles, SpecAugment masks and the sample span
+    // ---- once per workgroup (persistent grid): window and mel tables
+    reinterpret_cast<float4 *>(wl)[tid] = reinterpret_cast<const float4 *>(a.window)[tid];
     for (int i = tid; i < a.M; i += 256) {
         mtab[3 * i] = a.mel_start[i];
         mtab[3 * i + 1] = a.mel_len[i];
@@ -106,161 +111,212 @@ __global__ __launch_bounds__(256) void k_logmel(const WaveT *__restrict__ wave, 
     }
     for (int i = tid; i < a.n_mel_w; i += 256) mw[i] = a.mel_w[i];
     const int K = use_mask ? (mp.n_f + mp.n_t) : 0;
-    if (tid < K) {
-        int s, w;
-        ww_specaug_mask(mp, (uint32_t)(mp.sample_offset + (uint64_t)b), tid, a.F, a.T, s, w);
-        msk[2 * tid] = s;
-        msk[2 * tid + 1] = w;
-        if (mask_idx && blockIdx.x == 0) {
-            mask_idx[((size_t)b * K + tid) * 2] = s;
-            mask_idx[((size_t)b * K + tid) * 2 + 1] = w;
-        }
-    }
-    {
-        const long base = (long)t0 * a.hop - WW_NFFT / 2;
-        for (int i = tid; i < a.span_len; i += 256) {
-            long idx = base + i;
-            if (idx < 0) idx = -idx;
-            if (idx >= a.N) idx = 2L * (a.N - 1) - idx;
-            idx = idx < 0 ? 0 : (idx >= a.N ? a.N - 1 : idx);  // only frames >= T can get here
-            span[i] = load_sample(x, (size_t)idx);
-        }
-    }
-    __syncthreads();
 
-    float2 *buf = fbuf + wv * BUF_ELEMS;
-    float *pbuf = pb + wv * 2 * PB_LD;
-    // per-lane constants of both rounds: the window samples n = lane + 64 j and the twiddle factors of passes 1 and 2
-    float win[16];
+    float *xb = xball + wv * XB;
+    float *const p1 = xb + lane;                               // pass-1 layout: slot [kb][lane]       -> p1[kb * PROW]
+    float *const p2 = xb + (lane >> 2) * PROW + (lane & 3);    // pass-2 layout: slot [kb2][4 m + q]   -> p2[4 m]
+    // pass 3: butterfly (kb, kc) turns slots [kb][4kc + q] into X[16kc + 256kd + kb], kd = 0..3; X[1024 - k] comes out of
+    // butterfly (16 - kb, 15 - kc) (kb = 0: (0, 16 - kc)) at kd' = 3 - kd, so a lane that runs both has each (X[k], X[N-k])
+    // pair in registers.  128 units = 127 butterfly pairs + one unit holding the self-paired butterflies (0,0) and (0,8).
+    int offA[2], offB[2], kbase[2];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) win[j] = a.window[lane + 64 * j];
-    const Tw6 tw1 = load_tw6(a.twiddle, lane), tw2 = load_tw6(a.twiddle, 16 * (lane & 3));
+    for (int u = 0; u < 2; ++u) {
+        const int idx = lane + 64 * u;
+        int kbA, kcA, kbB, kcB;
+        if (idx < 112) { kbA = 1 + (idx >> 4); kcA = idx & 15; kbB = 16 - kbA; kcB = 15 - kcA; }
+        else if (idx < 120) { kbA = 8; kcA = idx - 112; kbB = 8; kcB = 15 - kcA; }
+        else if (idx < 127) { kbA = 0; kcA = idx - 119; kbB = 0; kcB = 16 - kcA; }
+        else { kbA = 0; kcA = 0; kbB = 0; kcB = 8; }
+        offA[u] = kbA * PROW + 4 * kcA;
+        offB[u] = kbB * PROW + 4 * kcB;
+        kbase[u] = 16 * kcA + kbA;
+    }
+    const bool special = lane == 63;                           // unit 127 (u = 1)
 
-    for (int round = 0; round < 2; ++round) {
-        const int fa = round * 8 + 2 * wv, fb = fa + 1;  // local frame indices of this wave's pair
-        float re[16], im[16];
-        // ---- pass 1: windowed load, radix-16 over n2, twiddle W1024^(lane*kb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int n = lane + 64 * j;
-            const float w = win[j];
-            re[j] = w * span[fa * a.hop + n];
-            im[j] = w * span[fb * a.hop + n];
+    for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int b = (int)(item / nblk), blk = (int)(item - (long)b * nblk), t0 = blk * FR;
+        const WaveT *x = wave + (size_t)b * a.N;
+        if (tid < K) {
+            int s, w;
+            ww_specaug_mask(mp, (uint32_t)(mp.sample_offset + (uint64_t)b), tid, a.F, a.T, s, w);
+            msk[2 * tid] = s;
+            msk[2 * tid + 1] = w;
+            if (mask_idx && blk == 0) {
+                mask_idx[((size_t)b * K + tid) * 2] = s;
+                mask_idx[((size_t)b * K + tid) * 2 + 1] = w;
+            }
         }
-        fft16(re, im);
-        twiddle_store16(re, im, tw1, [&](int kb) { return buf + kb * BUF_STRIDE + lane; });
-        wave_sync();
-        // ---- pass 2: lane = kb*4 + q ; radix-16 over m (n1 = 4m + q), twiddle W64^(q*kc)
-        const int kb2 = lane >> 2, q = lane & 3;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const float2 v = buf[kb2 * BUF_STRIDE + 4 * m + q];
-            re[m] = v.x;
-            im[m] = v.y;
-        }
-        fft16(re, im);
-        twiddle_store16(re, im, tw2, [&](int kc) { return buf + kb2 * BUF_STRIDE + kc * 4 + q; });
-        wave_sync();
-        // ---- pass 3 fused with the separation of the two real spectra.  Butterfly (kb, kc) turns slots [kb][4kc + q] into
-        // X[16kc + 256kd + kb], kd = 0..3; X[1024 - k] comes out of butterfly (16 - kb, 15 - kc) (kb = 0: (0, 16 - kc)) at
-        // kd' = 3 - kd, so a lane that runs both has each (X[k], X[N-k]) pair in registers and writes |.|^2 of both frames
-        // straight to the power buffers: the transform never returns to LDS.  128 units = 127 butterfly pairs + one unit
-        // holding the two self-paired butterflies (0,0) and (0,8); two units per lane.
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = lane + 64 * u;
-            int kbA, kcA, kbB, kcB;
-            if (idx < 112) { kbA = 1 + (idx >> 4); kcA = idx & 15; kbB = 16 - kbA; kcB = 15 - kcA; }
-            else if (idx < 120) { kbA = 8; kcA = idx - 112; kbB = 8; kcB = 15 - kcA; }
-            else if (idx < 127) { kbA = 0; kcA = idx - 119; kbB = 0; kcB = 16 - kcA; }
-            else { kbA = 0; kcA = 0; kbB = 0; kcB = 8; }
-            const bool special = u == 1 && idx == 127;
-            float ar[4], ai[4], br[4], bi[4];
-            {
-                const float2 *sa = buf + kbA * BUF_STRIDE + 4 * kcA, *sb = buf + kbB * BUF_STRIDE + 4 * kcB;
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const float2 va = sa[qq], vb = sb[qq];
-                    ar[qq] = va.x; ai[qq] = va.y; br[qq] = vb.x; bi[qq] = vb.y;
+        {
+            const long base = (long)t0 * a.hop - WW_NFFT / 2;
+            bool fast = false;
+            if constexpr (sizeof(WaveT) == 4) {
+                // interior span on a 16-byte boundary (hop 160, N 24000: every item but the first and last of a clip)
+                fast = base >= 0 && base + a.span_len <= a.N && (((size_t)b * a.N + (size_t)base) & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(wave) & 15) == 0;
+                if (fast) {
+                    const float4 *src = reinterpret_cast<const float4 *>(x + base);
+                    const int n4 = a.span_len >> 2;
+                    for (int i = tid; i < n4; i += 256) reinterpret_cast<float4 *>(span)[i] = src[i];
+                    for (int i = 4 * n4 + tid; i < a.span_len; i += 256) span[i] = x[base + i];
                 }
             }
-            fft4(ar[0], ai[0], ar[1], ai[1], ar[2], ai[2], ar[3], ai[3]);
-            fft4(br[0], bi[0], br[1], bi[1], br[2], bi[2], br[3], bi[3]);
-            const int kbase = 16 * kcA + kbA;
-            auto emit = [&](float xr_, float xi_, float yr_, float yi_, int k) {   // X = X[k], Y = X[N-k]
-                const int j = k <= 512 ? k : 1024 - k;
-                const int pj = j + (j >> 4);
-                const float pr = xr_ + yr_, pi = xi_ - yi_;     // 2 * spectrum of frame a
-                const float qr = xi_ + yi_, qi = xr_ - yr_;     // 2 * spectrum of frame b (up to the sign of its imaginary part)
-                pbuf[pj] = 0.25f * (pr * pr + pi * pi);
-                pbuf[PB_LD + pj] = 0.25f * (qr * qr + qi * qi);
-            };
-            if (!special) {
-#pragma unroll
-                for (int kd = 0; kd < 4; ++kd) emit(ar[kd], ai[kd], br[3 - kd], bi[3 - kd], kbase + 256 * kd);
-            } else {
-                emit(ar[0], ai[0], ar[0], ai[0], 0);
-                emit(ar[1], ai[1], ar[3], ai[3], 256);
-                emit(ar[2], ai[2], ar[2], ai[2], 512);
-                emit(br[0], bi[0], br[3], bi[3], 128);
-                emit(br[1], bi[1], br[2], bi[2], 384);
-            }
-        }
-        wave_sync();
-        // ---- mel band sums: item = ((frame, mel), half); the two halves of a band sit in adjacent lanes
-        for (int it0 = 0; it0 < 4 * a.M; it0 += 64) {
-            const int it = it0 + lane;
-            const bool act = it < 4 * a.M;
-            const int pair = act ? it >> 1 : 0, half = it & 1;
-            const int fr = pair >= a.M ? 1 : 0;
-            const int m = pair - fr * a.M;
-            const int s = mtab[3 * m], L = mtab[3 * m + 1];
-            const int h0 = (L + 1) >> 1;
-            const int j0 = half ? h0 : 0, j1 = half ? L : h0;
-            const float *wp = mw + mtab[3 * m + 2];
-            const float *pp = pbuf + fr * PB_LD;
-            float acc = 0.f;
-            if (act) {
-#pragma unroll 4
-                for (int j = j0; j < j1; ++j) {
-                    const int bin = s + j;
-                    acc = fmaf(wp[j], pp[bin + (bin >> 4)], acc);
+            if (!fast) {
+                for (int i = tid; i < a.span_len; i += 256) {
+                    long idx = base + i;
+                    if (idx < 0) idx = -idx;
+                    if (idx >= a.N) idx = 2L * (a.N - 1) - idx;
+                    idx = idx < 0 ? 0 : (idx >= a.N ? a.N - 1 : idx);  // only frames >= T can get here
+                    span[i] = load_sample(x, (size_t)idx);
                 }
             }
-            acc += __shfl_xor(acc, 1);
-            if (act && half == 0) lm[(fa + fr) * a.M + m] = logf(acc + a.log_eps);
-        }
-        wave_sync();
-    }
-    __syncthreads();
-
-    if (a.use_dct) {
-        for (int it = tid; it < FR * a.F; it += 256) {
-            const int fr = it / a.F, c = it - fr * a.F;
-            const float *d = a.dct + (size_t)c * a.M;
-            const float *l = lm + fr * a.M;
-            float acc = 0.f;
-            for (int m = 0; m < a.M; ++m) acc = fmaf(d[m], l[m], acc);
-            feat[it] = acc;
         }
         __syncthreads();
-    }
 
-    // ---- masked, transposed write-out: out[b][0][f][t0 + i]
-    for (int it = tid; it < a.F * FR; it += 256) {
-        const int f = it / FR, i = it - f * FR;
-        const int t = t0 + i;
-        if (t < a.T) {
-            float v = feat[i * a.F + f];
-            for (int k = 0; k < K; ++k) {
-                const int s = msk[2 * k], w = msk[2 * k + 1];
-                const int pos = k < mp.n_f ? f : t;
-                if (pos >= s && pos < s + w) v = 0.f;
+        for (int round = 0; round < 2; ++round) {
+            const int fa = round * 8 + 2 * wv, fb = fa + 1;  // local frame indices of this wave's pair
+            float re[16], im[16];
+            // ---- pass 1: windowed load, radix-16 over n2, twiddle W1024^(lane*kb)
+            int tb1 = lane, tb2 = 16 * (lane & 3);
+            asm volatile("" : "+v"(tb1), "+v"(tb2));             // keep the table loads inside the round
+            {
+                const float *sa = span + fa * a.hop + lane, *sb = span + fb * a.hop + lane, *wp = wl + lane;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const float w = wp[64 * j];
+                    re[j] = w * sa[64 * j];
+                    im[j] = w * sb[64 * j];
+                }
             }
-            out[((size_t)b * a.F + f) * a.T + t] = v;
+            fft16(re, im);
+            {
+                const Tw6 tw1 = load_tw6(a.twiddle, tb1);
+                twiddle16(re, im, tw1);
+            }
+            // exchange 1 (planar): real parts through the tile, then the imaginary parts
+#pragma unroll
+            for (int k = 0; k < 16; ++k) p1[k * PROW] = re[F16_SLOT(k)];
+            wave_sync();
+#pragma unroll
+            for (int m = 0; m < 16; ++m) re[m] = p2[4 * m];
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) p1[k * PROW] = im[F16_SLOT(k)];
+            wave_sync();
+#pragma unroll
+            for (int m = 0; m < 16; ++m) im[m] = p2[4 * m];
+            wave_sync();
+            // ---- pass 2: lane = kb*4 + q ; radix-16 over m (n1 = 4m + q), twiddle W64^(q*kc); written back in place
+            fft16(re, im);
+            {
+                const Tw6 tw2 = load_tw6(a.twiddle, tb2);
+                twiddle16(re, im, tw2);
+            }
+            // exchange 2 (planar) straight into the pass-3 butterflies' registers
+            float4 ar[2], ai[2], br[2], bi[2];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) p2[4 * k] = re[F16_SLOT(k)];
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ar[u] = *reinterpret_cast<const float4 *>(xb + offA[u]);
+                br[u] = *reinterpret_cast<const float4 *>(xb + offB[u]);
+            }
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) p2[4 * k] = im[F16_SLOT(k)];
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                ai[u] = *reinterpret_cast<const float4 *>(xb + offA[u]);
+                bi[u] = *reinterpret_cast<const float4 *>(xb + offB[u]);
+            }
+            wave_sync();
+            // ---- pass 3 fused with the separation of the two real spectra; |.|^2 of both frames into the tile's power rows
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                fft4(ar[u].x, ai[u].x, ar[u].y, ai[u].y, ar[u].z, ai[u].z, ar[u].w, ai[u].w);
+                fft4(br[u].x, bi[u].x, br[u].y, bi[u].y, br[u].z, bi[u].z, br[u].w, bi[u].w);
+                auto emit = [&](float xr_, float xi_, float yr_, float yi_, int k) {   // X = X[k], Y = X[N-k]
+                    const int j = k <= 512 ? k : 1024 - k;
+                    const int pj = j + (j >> 4);
+                    const float pr = xr_ + yr_, pi = xi_ - yi_;     // 2 * spectrum of frame a
+                    const float qr = xi_ + yi_, qi = xr_ - yr_;     // 2 * spectrum of frame b (up to the sign of its imaginary part)
+                    xb[pj] = 0.25f * (pr * pr + pi * pi);
+                    xb[PB_LD + pj] = 0.25f * (qr * qr + qi * qi);
+                };
+                if (!(u == 1 && special)) {
+                    emit(ar[u].x, ai[u].x, br[u].w, bi[u].w, kbase[u]);
+                    emit(ar[u].y, ai[u].y, br[u].z, bi[u].z, kbase[u] + 256);
+                    emit(ar[u].z, ai[u].z, br[u].y, bi[u].y, kbase[u] + 512);
+                    emit(ar[u].w, ai[u].w, br[u].x, bi[u].x, kbase[u] + 768);
+                } else {
+                    emit(ar[u].x, ai[u].x, ar[u].x, ai[u].x, 0);
+                    emit(ar[u].y, ai[u].y, ar[u].w, ai[u].w, 256);
+                    emit(ar[u].z, ai[u].z, ar[u].z, ai[u].z, 512);
+                    emit(br[u].x, bi[u].x, br[u].w, bi[u].w, 128);
+                    emit(br[u].y, bi[u].y, br[u].z, bi[u].z, 384);
+                }
+            }
+            wave_sync();
+            // ---- mel band sums: item = ((frame, mel), half); the two halves of a band sit in adjacent lanes
+            for (int it0 = 0; it0 < 4 * a.M; it0 += 64) {
+                const int it = it0 + lane;
+                const bool act = it < 4 * a.M;
+                const int pair = act ? it >> 1 : 0, half = it & 1;
+                const int fr = pair >= a.M ? 1 : 0;
+                const int m = pair - fr * a.M;
+                const int s = mtab[3 * m], L = mtab[3 * m + 1];
+                const int h0 = (L + 1) >> 1;
+                const int j0 = half ? h0 : 0, j1 = half ? L : h0;
+                const float *wp = mw + mtab[3 * m + 2];
+                const float *pp = xb + fr * PB_LD;
+                float acc = 0.f;
+                if (act) {
+#pragma unroll 4
+                    for (int j = j0; j < j1; ++j) {
+                        const int bin = s + j;
+                        acc = fmaf(wp[j], pp[bin + (bin >> 4)], acc);
+                    }
+                }
+                acc += __shfl_xor(acc, 1);
+                if (act && half == 0) lm[(fa + fr) * a.M + m] = acc;
+            }
+            wave_sync();
         }
+        __syncthreads();
+        for (int it = tid; it < FR * a.M; it += 256) lm[it] = logf(lm[it] + a.log_eps);
+        __syncthreads();
+
+        if (a.use_dct) {
+            for (int it = tid; it < FR * a.F; it += 256) {
+                const int fr = it / a.F, c = it - fr * a.F;
+                const float *d = a.dct + (size_t)c * a.M;
+                const float *l = lm + fr * a.M;
+                float acc = 0.f;
+                for (int m = 0; m < a.M; ++m) acc = fmaf(d[m], l[m], acc);
+                feat[it] = acc;
+            }
+            __syncthreads();
+        }
+
+        // ---- masked, transposed write-out: out[b][0][f][t0 + i]
+        for (int it = tid; it < a.F * FR; it += 256) {
+            const int f = it / FR, i = it - f * FR;
+            const int t = t0 + i;
+            if (t < a.T) {
+                float v = feat[i * a.F + f];
+                for (int k = 0; k < K; ++k) {
+                    const int s = msk[2 * k], w = msk[2 * k + 1];
+                    const int pos = k < mp.n_f ? f : t;
+                    if (pos >= s && pos < s + w) v = 0.f;
+                }
+                out[((size_t)b * a.F + f) * a.T + t] = v;
+            }
+        }
+        __syncthreads();   // the next item restages span / masks / lm
     }
 }
+
 
 // ---- any other power-of-two n_fft (the reference's validator accepts 256 ... 4096, src/config/validator.py:129; 1024 is its
 // default and the size k_logmel is built for).  Plain and general rather than fast: one workgroup per (clip, frame), the
@@ -454,24 +510,26 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
         WW_LAUNCH_CHECK();
         return WW_OK;
     }
-    const size_t smem = (size_t)4 * BUF_ELEMS * sizeof(float2) + (size_t)4 * 2 * PB_LD * sizeof(float) +
-                        (size_t)FR * a.M * sizeof(float) + (a.use_dct ? (size_t)FR * a.F * sizeof(float) : 0) +
-                        2 * WW_MAX_MASKS * sizeof(int) + (size_t)3 * a.M * sizeof(int) + (size_t)a.n_mel_w * sizeof(float) +
-                        (size_t)a.span_len * sizeof(float);
-    dim3 grid((a.T + FR - 1) / FR, B);
+    const size_t smem = ((size_t)4 * XB + WW_NFFT + ((a.span_len + 3) & ~3) + (size_t)FR * a.M +
+                         (a.use_dct ? (size_t)FR * a.F : 0) + 2 * WW_MAX_MASKS + (size_t)3 * a.M + a.n_mel_w) * sizeof(float);
+    // Persistent grid: ctx->logmel_wgs workgroups (ww_ctx_set_logmel_workgroups; WW_LOGMEL_WGS overrides it for tuning),
+    // 0 = one full residency round of the device.
+    const int nblk = (a.T + FR - 1) / FR;
+    const long nitems = (long)nblk * B;
+    static const long wgs_env = [] { const char *e = getenv("WW_LOGMEL_WGS"); return e ? atol(e) : 0L; }();
+    const void *fn = wave_dtype == WW_WAVE_F32 ? (const void *)k_logmel<float> : (const void *)k_logmel<int16_t>;
+    WW_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    long wgs = wgs_env > 0 ? wgs_env : ctx->logmel_wgs;
+    if (wgs <= 0) wgs = ww_occupancy_grid(fn, 256, smem, nitems, 1 << 20);
+    dim3 grid((unsigned)(nitems < wgs ? nitems : wgs));
     hipStream_t st = (hipStream_t)stream;
     ww_prof_scope ps_(ctx, WW_K_LOGMEL, st);
-    if (wave_dtype == WW_WAVE_F32) {
-        WW_HIP(hipFuncSetAttribute((const void *)k_logmel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)smem));
+    if (wave_dtype == WW_WAVE_F32)
         hipLaunchKernelGGL(k_logmel<float>, grid, dim3(256), smem, st, (const float *)wave, a, out, use_mask, mp,
-                           mask_idx);
-    } else {
-        WW_HIP(hipFuncSetAttribute((const void *)k_logmel<int16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)smem));
+                           mask_idx, nblk, nitems);
+    else
         hipLaunchKernelGGL(k_logmel<int16_t>, grid, dim3(256), smem, st, (const int16_t *)wave, a, out, use_mask, mp,
-                           mask_idx);
-    }
+                           mask_idx, nblk, nitems);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }

@@ -71,6 +71,7 @@ struct ww_ctx {
     float2 *tw16k;                         // (1024) exp(-2 pi i m / 16384), ww_audio.hip's FFT convolution; lazy
     double *norm_partials;                 // (WW_NORM_PARTS) block sums of squares of a large gradient bucket; lazy
     const ww_step_ctl *step_ctl;           // bound device control block (ww_ctx_bind_step_ctl) or NULL
+    int logmel_wgs;                        // persistent workgroups of k_logmel (ww_ctx_set_logmel_workgroups); 0 = fill the device
     uint32_t prof_mask;
     std::vector<ww_prof_rec> *prof_recs;   // recorded, not yet collected
     std::vector<ww_prof_rec> *prof_free;   // event pairs ready for reuse
