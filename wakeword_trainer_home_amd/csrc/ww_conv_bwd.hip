@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                      const float *__restrict__ ss_in, const float *__restrict__ mr_in,
                                                      const float *__restrict__ w, long M, int HW,
                                                      H *__restrict__ g_in, float *__restrict__ stat_partials,
-                                                     float *__restrict__ dw_partials) {
+                                                     float *__restrict__ dw_partials, int rev) {
     // dy, a = relu(bn(y_in)), and two y_in tiles (even / odd tile of the unrolled loop): g_in overwrites the raw y_in tile
     // in place and is stored from there while the next tile is staged into the other one.  36.9 KB -> 4 workgroups per CU.
     // + the 64x64 weights (bf16): both MFMA B operands come from this one copy (row reads forward, transposing reads for dX)
@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     float dpA0 = 0.f, dpB0 = 0.f;   // pooled gradient of the (at most two, when HW >= tile) images of a tile
     auto issue = [&](long ti, typename A16::raw4 (&rg)[4], typename A16::raw4 (&ri)[4], float &ndpA, float &ndpB) {
         if (ti >= ntiles) return;
+        if (rev) ti = ntiles - 1 - ti;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             long p = ti * PWB_TILE + (tid >> 4) + 16 * i;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     };
     auto tile = [&](long ti, H *yit, typename A16::raw4 (&rg)[4], typename A16::raw4 (&ri)[4], float &ndpA, float &ndpB) {
-        const long p0 = ti * PWB_TILE;
+        const long p0 = (rev ? ntiles - 1 - ti : ti) * PWB_TILE;
         const float dpA = ndpA, dpB = ndpB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -630,7 +631,7 @@ template <typename T, bool RECOMP>
 __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const T *__restrict__ y_out,
                                                   const float *__restrict__ w, const float *__restrict__ coef,
                                                   const float *__restrict__ x, int B, int Hin, int Win, int Ho, int Wo,
-                                                  float *__restrict__ dw_partials) {
+                                                  float *__restrict__ dw_partials, int rev) {
     __shared__ float sh[8 * 576];
     extern __shared__ float xs[];            // [3][Win + 2] zero-padded input rows (see k_stem_fwd)
     const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31;
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const
     // batch of up to ten before they are used -- one exposed HBM latency per row instead of one per pixel
     float pre[2];
     auto fetch = [&](long item) {
+        if (rev) item = nrows - 1 - item;
         const int fb_ = (int)(item / Ho), foh = (int)(item - (long)fb_ * Ho);
         const float *xb = x + (size_t)fb_ * Hin * Win;
 #pragma unroll
@@ -663,7 +665,8 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const
     };
     const bool ahead = 3 * ld <= 2 * 256;
     if (ahead && (long)blockIdx.x < nrows) fetch(blockIdx.x);
-    for (long row = blockIdx.x; row < nrows; row += gridDim.x) {
+    for (long rowi = blockIdx.x; rowi < nrows; rowi += gridDim.x) {
+        const long row = rev ? nrows - 1 - rowi : rowi;
         const int b = (int)(row / Ho), oh = (int)(row - (long)b * Ho);
         __syncthreads();
         if (ahead) {
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const
             }
         }
         __syncthreads();
-        if (ahead && row + gridDim.x < nrows) fetch(row + gridDim.x);
+        if (ahead && rowi + gridDim.x < nrows) fetch(rowi + gridDim.x);
         for (int ow0 = slot; ow0 < Wo; ow0 += 80) {
             typename Act<T>::raw2 gr[10], yr[10];
 #pragma unroll
@@ -776,8 +779,9 @@ int launch_pw_bwd_bf16(ww_ctx *ctx, const void *g, const float *dpool, const voi
     ww_prof_scope ps_(ctx, WW_K_PW_BWD, st);
     auto go = [&](auto kern) {
         grid = ww_occupancy_grid((const void *)kern, 256, 0, ntiles, WW_DW_SLAB_ROWS);
+        static const int rev = ww_env_int("WW_PW_BWD_REV", 1);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, (cp)g, dpool, ss_out, coef, (cp)y_in, ss_in, mr_in, w, M, HW,
-                           (H *)g_in, stat, dwp);
+                           (H *)g_in, stat, dwp, rev);
     };
     if (g) go(k_pw_bwd_bf16<H, false, true>);
     else if (HW >= PWB_TILE) go(k_pw_bwd_bf16<H, true, true>);
@@ -829,8 +833,9 @@ int launch_stem_bwd(ww_ctx *ctx, const void *g, const void *y_out, const float *
     auto go = [&](auto kern) {
         // only the weight-gradient slab is used (576 columns): room for 2048 rows -> full occupancy
         const int grid = ww_occupancy_grid((const void *)kern, 256, smem, nrows, 2048);
+        static const int rev = ww_env_int("WW_STEM_BWD_REV", 1);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, (const T *)g, (const T *)y_out, w, coef, x, B, Hin, Win, Ho,
-                           Wo, dwp);
+                           Wo, dwp, rev);
         *grid_out = grid;
     };
     if (w) go(k_stem_bwd<T, true>);

@@ -60,7 +60,7 @@ __device__ __forceinline__ void reduce_stats_slots(float s0, float s1, float q0,
 template <typename T>
 __global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ x, const float *__restrict__ w, int B,
                                                   int Hin, int Win, int Ho, int Wo, T *__restrict__ y,
-                                                  float *__restrict__ partials) {
+                                                  float *__restrict__ partials, int rev) {
     __shared__ float sh[32 * 128];
     extern __shared__ float xs[];            // [5][Win + 2] : xs[r][iw + 1], zero outside the image
     const int tid = threadIdx.x, px = tid >> 3, c8 = tid & 7;
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ x, c
     // previous item's FMAs) and written to LDS at the top of the item: 5 * ld <= 4 * 256 values
     float pre[4];
     auto fetch = [&](long item) {
+        if (rev) item = npairs - 1 - item;
         const int fb_ = (int)(item / ((Ho + 1) / 2)), foh = 2 * (int)(item - (long)fb_ * ((Ho + 1) / 2));
         const float *xb = x + (size_t)fb_ * Hin * Win;
 #pragma unroll
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(256) void k_stem_fwd(const float *__restrict__ x, c
     const bool ahead = 5 * ld <= 4 * 256;    // wider inputs (T > 202 frames) are staged in place
     if (ahead && (long)blockIdx.x < npairs) fetch(blockIdx.x);
     for (long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
-        const int b = (int)(pr / ((Ho + 1) / 2)), oh0 = 2 * (int)(pr - (long)b * ((Ho + 1) / 2));
+        const long prm = rev ? npairs - 1 - pr : pr;
+        const int b = (int)(prm / ((Ho + 1) / 2)), oh0 = 2 * (int)(prm - (long)b * ((Ho + 1) / 2));
         __syncthreads();                     // previous pair's readers are done
         if (ahead) {
 #pragma unroll
@@ -383,7 +385,7 @@ constexpr int PWH_LD = 72;      // 16-bit elements per LDS row (64 + 8 pad = 144
 template <typename H>
 __global__ __launch_bounds__(256) void k_pw_fwd_bf16(const H *__restrict__ yin, const float *__restrict__ ss,
                                                      const float *__restrict__ w, long M, H *__restrict__ y,
-                                                     float *__restrict__ partials) {
+                                                     float *__restrict__ partials, int rev) {
     extern __shared__ __align__(16) unsigned char pwh_lds[];
     H *atile = reinterpret_cast<H *>(pwh_lds);                       // [128][72] bf16
     H *otile = atile + PW_TILE * PWH_LD;                                   // [128][72] bf16: the output as it is stored
@@ -409,6 +411,7 @@ __global__ __launch_bounds__(256) void k_pw_fwd_bf16(const H *__restrict__ yin, 
     const long ntiles = (M + PW_TILE - 1) / PW_TILE;
     typename A16::raw4 raw[8];
     auto issue = [&](long ti) {
+        if (rev) ti = ntiles - 1 - ti;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             long p = ti * PW_TILE + (tid >> 4) + 16 * i;
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(256) void k_pw_fwd_bf16(const H *__restrict__ yin, 
     };
     if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
     for (long ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
-        const long p0 = ti * PW_TILE;
+        const long p0 = (rev ? ntiles - 1 - ti : ti) * PW_TILE;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = (tid >> 4) + 16 * i;
@@ -570,7 +573,8 @@ int launch_stem_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int Hin,
     const int grid = ww_occupancy_grid((const void *)k_stem_fwd<T>, 256, smem, nrows, WW_MAX_PARTIALS);
     {
         ww_prof_scope ps_(ctx, WW_K_STEM_FWD, st);
-        hipLaunchKernelGGL(k_stem_fwd<T>, dim3(grid), dim3(256), smem, st, x, w, B, Hin, Win, Ho, Wo, (T *)y, partials);
+        static const int rev = ww_env_int("WW_STEM_FWD_REV", 1);
+        hipLaunchKernelGGL(k_stem_fwd<T>, dim3(grid), dim3(256), smem, st, x, w, B, Hin, Win, Ho, Wo, (T *)y, partials, rev);
     }
     WW_LAUNCH_CHECK();
     *grid_out = grid;
@@ -599,7 +603,8 @@ int launch_pw_fwd_bf16(ww_ctx *ctx, const void *y_in, const float *ss_in, const 
     const int grid = ww_occupancy_grid((const void *)k_pw_fwd_bf16<H>, 256, smem, ntiles, WW_MAX_PARTIALS);
     {
         ww_prof_scope ps_(ctx, WW_K_PW_FWD, st);
-        hipLaunchKernelGGL(k_pw_fwd_bf16<H>, dim3(grid), dim3(256), smem, st, (const H *)y_in, ss_in, w, M, (H *)y, partials);
+        static const int rev = ww_env_int("WW_PW_FWD_REV", 1);
+        hipLaunchKernelGGL(k_pw_fwd_bf16<H>, dim3(grid), dim3(256), smem, st, (const H *)y_in, ss_in, w, M, (H *)y, partials, rev);
     }
     WW_LAUNCH_CHECK();
     *grid_out = grid;

@@ -121,6 +121,11 @@ int ww_colsum_rows(const float *a, long rows, int cols, float *out, float *part,
 int ww_colsum_pair(const float *a, int rows, int cols, float *out0, float *out1, hipStream_t st);
 int ww_colsum_rows_small(const float *a, int rows, int cols, float *out, hipStream_t st);
 int ww_occupancy_grid(const void *fn, int block, size_t smem, long want, int cap);
+// integer environment knob (tuning / A-B experiments); call sites cache the result in a function-local static
+static inline int ww_env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 // ww_conv_bwd.hip: ww_conv_stem_bwd with the stem weights (w != NULL: y_out is recomputed from x instead of read)
 int ww_stem_bwd_impl(ww_ctx *ctx, int act_dtype, const void *g, const void *y_out, const float *w, const float *coef,
                      const float *x, int B, int Hin, int Win, float *dw, void *scratch, ww_stream_t stream);
