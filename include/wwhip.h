@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 8
+#define WW_ABI_VERSION 9
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -312,6 +312,13 @@ size_t ww_linear_mfma_bwd_scratch_bytes(int M, int K, int N);
 int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const float *w, const float *pre /* nullable if no act */,
                        const float *dy, int M, int K, int N, const ww_linear_epi *epi, float *dx /* nullable */, float *dw,
                        float *db /* nullable */, void *scratch, size_t scratch_bytes, ww_stream_t stream);
+
+/* The GEMM core for callers that keep operands in 16 bits IN HBM: C (M,N) = A (M,K) . B (N,K)^T, A / B bf16 (WW_ACT_BF16) or fp16
+ * (WW_ACT_F16) row-major and 16-byte aligned, fp32 accumulation, C fp32 (c_f32 != 0) or the operand type.  K must be a
+ * multiple of 64; M and N are free.  128 x 128 tiles, LDS-DMA operand staging.  B is in nn.Linear.weight
+ * orientation, so y = x W^T needs no transpose; dx = dy W and dW = dy^T x take transposed copies of their right operand.   */
+int ww_gemm16_nt(ww_ctx *ctx, int dtype, const void *A, const void *B, void *C, int c_f32, long M, long N, long K,
+                 ww_stream_t stream);
 
 /* ------------------------------------------------------------------ generic channels-last layers
  * Building blocks of bodies with varying channel counts (torchvision's mobilenet_v3_small, as MobileNetV3Wakeword

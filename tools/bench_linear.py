@@ -43,3 +43,20 @@ def run(M, K, N, mode):
 for M, K, N in ((256, 576, 1024), (2048, 576, 1024), (16384, 1024, 1024)):
     for mode in ("fp32", "bf16"):
         print(json.dumps(run(M, K, N, mode)))
+
+
+def run16(M, K, N, dtype, out_dtype):
+    """ww_gemm16_nt: operands already 16-bit in HBM (random normal operands -- not zeros: the clock depends on the data)."""
+    a = (torch.randn(M, K, device=dev)).to(dtype)
+    b = (torch.randn(N, K, device=dev) / K ** 0.5).to(dtype)
+    t = timeit(lambda: nat.gemm16_nt(a, b, out_dtype=out_dtype))
+    t_ref = timeit(lambda: torch.nn.functional.linear(a, b))
+    fl = 2.0 * M * K * N
+    return {"kernel": "ww_gemm16_nt", "M": M, "K": K, "N": N, "operands": str(dtype).split(".")[-1], "out": str(out_dtype).split(".")[-1],
+            "us": round(t, 1), "TFLOPs": round(fl / t / 1e6, 1), "frac_of_2500_TF_dense_peak": round(fl / t / 1e6 / 2500, 3),
+            "torch_linear_us(hipBLASLt, same operands)": round(t_ref, 1), "torch_TFLOPs": round(fl / t_ref / 1e6, 1)}
+
+
+for M, K, N in ((16384, 1024, 1024), (8192, 8192, 8192), (4096, 4096, 4096), (19456, 64, 384), (2048, 576, 1024)):
+    for dtype, od in ((torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float16, torch.float32)):
+        print(json.dumps(run16(M, K, N, dtype, od)))

@@ -13,7 +13,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 BWD_ALL, BWD_LATE, BWD_EARLY = 0, 1, 2
 ACT_F32, ACT_BF16, ACT_F16 = 0, 1, 2
 LOSS_CE, LOSS_FOCAL = 0, 1
@@ -115,6 +115,7 @@ _SIGS = {
     "ww_audio_rir_spectra": (C.c_int, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
     "ww_audio_augment": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, C.POINTER(AudioAugCfg), _u64, _u64,
                                    _u64, _vp, _vp, _sz, _vp]),
+    "ww_gemm16_nt": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, C.c_long, C.c_long, C.c_long, _vp]),
     "ww_linear_mfma_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, C.POINTER(LinearEpi), _vp, _vp, _vp]),
     "ww_linear_mfma_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
     "ww_linear_mfma_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(LinearEpi), _vp, _vp, _vp, _vp, _sz,
@@ -420,6 +421,21 @@ def linear_mfma_fwd(x, w, bias=None, act=LIN_NONE, dropout_p=0.0, seed=0, step=0
         _check(load().ww_linear_mfma_fwd(ctx(dev), act_code(mode), _p(x.contiguous()), _p(w.contiguous()), _p(bias), M, K, N,
                                          C.byref(epi), _p(pre), _p(y), _stream(dev)), "ww_linear_mfma_fwd")
     return (y, pre) if want_pre else y
+
+
+def gemm16_nt(a, b, out_dtype=torch.float32):
+    """a (M,K) @ b (N,K).T for bf16 / fp16 operands resident in HBM (fp32 accumulation) -> (M,N) float32 or the operand type."""
+    dev = _dev(a, b)
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1] or a.dtype != b.dtype or a.dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError(f"gemm16_nt: need two bf16 or two fp16 matrices (M,K), (N,K), got {tuple(a.shape)} {a.dtype}, {tuple(b.shape)} {b.dtype}")
+    if out_dtype not in (torch.float32, a.dtype):
+        raise ValueError("gemm16_nt: out_dtype must be float32 or the operand type")
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=out_dtype, device=dev)
+    with _guard(dev):
+        _check(load().ww_gemm16_nt(ctx(dev), act_code(a.dtype), _p(a), _p(b), _p(out), int(out_dtype == torch.float32),
+                                   a.shape[0], b.shape[0], a.shape[1], _stream(dev)), "ww_gemm16_nt")
+    return out
 
 
 def linear_mfma_bwd(x, w, pre, dy, act=LIN_NONE, dropout_p=0.0, seed=0, step=0, sample_offset=0, mode=torch.float32,
