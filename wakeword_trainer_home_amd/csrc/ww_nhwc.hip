@@ -26,6 +26,7 @@ __device__ __forceinline__ float act_grad(int act, float z) {
 }
 
 constexpr int NCHUNK = 256;     // max row chunks of the column reductions (one workgroup each)
+constexpr int NCHUNK_DW = 1024; // max pixel chunks of the depthwise weight-gradient kernel
 
 // Column reductions over a tall (M, C) matrix with ANY C <= 1024: a block has C*R threads, thread t owns column t % C and rows
 // r0 + t / C (+R, +2R, ...), so consecutive threads read consecutive addresses whatever C is (a 64-column tiling would
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(1024) void k_colstats(const float *__restrict__ x, 
     const int c = threadIdx.x % C, r = threadIdx.x / C;
     const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
     double s = 0.0, q = 0.0;
-#pragma unroll 4
+#pragma unroll 8
     for (long row = r0 + r; row < r1; row += R) { const double v = x[row * C + c]; s += v; q += v * v; }
     red[r * C + c] = s; red[(R + r) * C + c] = q;
     __syncthreads();
@@ -98,6 +99,44 @@ __global__ __launch_bounds__(256) void k_bn_act_apply(const float *__restrict__ 
         y[i] = act_fwd(act, fmaf(x[i], ss[c], ss[C + c]));
     }
 }
+// the elementwise passes for C % 4 == 0 (every MobileNetV3 layer): a thread moves float4s, the channel index comes from a 32-bit
+// remainder per FOUR elements (the scalar forms pay a 64-bit one per element); same arithmetic per element, same bits
+__global__ __launch_bounds__(256) void k_bn_act_apply4(const float4 *__restrict__ x, const float *__restrict__ ss, uint32_t n4,
+                                                       int C, int act, float4 *__restrict__ y) {
+    const uint32_t C4 = (uint32_t)C >> 2;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        const int c = (int)(i % C4) * 4;
+        const float4 v = x[i], sc = *reinterpret_cast<const float4 *>(ss + c), sf = *reinterpret_cast<const float4 *>(ss + C + c);
+        y[i] = make_float4(act_fwd(act, fmaf(v.x, sc.x, sf.x)), act_fwd(act, fmaf(v.y, sc.y, sf.y)),
+                           act_fwd(act, fmaf(v.z, sc.z, sf.z)), act_fwd(act, fmaf(v.w, sc.w, sf.w)));
+    }
+}
+__device__ __forceinline__ float bnact_bwd_one(float xv, float dav, float sc, float sf, float mu, float rs, float s1, float s2,
+                                               float invM, int act, int training) {
+    const float dz = dav * act_grad(act, fmaf(xv, sc, sf));
+    if (!training) return sc * dz;
+    const float xh = (xv - mu) * rs;
+    return sc * (dz - s1 * invM - xh * s2 * invM);
+}
+__global__ __launch_bounds__(256) void k_bnact_bwd_apply4(const float4 *__restrict__ x, const float4 *__restrict__ da,
+                                                          const float *__restrict__ ss, const float *__restrict__ mr,
+                                                          const float *__restrict__ sums, long M, uint32_t n4, int C, int act,
+                                                          int training, float4 *__restrict__ dx) {
+    const uint32_t C4 = (uint32_t)C >> 2;
+    const float invM = 1.0f / (float)M;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        const int c = (int)(i % C4) * 4;
+        const float4 xv = x[i], dv = da[i];
+        const float4 sc = *reinterpret_cast<const float4 *>(ss + c), sf = *reinterpret_cast<const float4 *>(ss + C + c);
+        const float4 mu = *reinterpret_cast<const float4 *>(mr + c), rs = *reinterpret_cast<const float4 *>(mr + C + c);
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+        if (training) { s1 = *reinterpret_cast<const float4 *>(sums + c); s2 = *reinterpret_cast<const float4 *>(sums + C + c); }
+        dx[i] = make_float4(bnact_bwd_one(xv.x, dv.x, sc.x, sf.x, mu.x, rs.x, s1.x, s2.x, invM, act, training),
+                            bnact_bwd_one(xv.y, dv.y, sc.y, sf.y, mu.y, rs.y, s1.y, s2.y, invM, act, training),
+                            bnact_bwd_one(xv.z, dv.z, sc.z, sf.z, mu.z, rs.z, s1.z, s2.z, invM, act, training),
+                            bnact_bwd_one(xv.w, dv.w, sc.w, sf.w, mu.w, rs.w, s1.w, s2.w, invM, act, training));
+    }
+}
 // backward pass 1: dz = da * act'(z); partial sums of dz and dz*xhat (same thread layout as k_colstats)
 __global__ __launch_bounds__(1024) void k_bnact_bwd_stats(const float *__restrict__ x, const float *__restrict__ da,
                                                           const float *__restrict__ ss, const float *__restrict__ mr, long M,
@@ -107,7 +146,7 @@ __global__ __launch_bounds__(1024) void k_bnact_bwd_stats(const float *__restric
     const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
     const float sc = ss[c], sf = ss[C + c], mu = mr[c], rs = mr[C + c];
     double s1 = 0.0, s2 = 0.0;
-#pragma unroll 4
+#pragma unroll 8
     for (long row = r0 + r; row < r1; row += R) {
         const float xv = x[row * C + c];
         const float dz = da[row * C + c] * act_grad(act, fmaf(xv, sc, sf));
@@ -292,21 +331,25 @@ __global__ __launch_bounds__(1024) void k_dwg_bwd_dw(const float *__restrict__ x
         }
 }
 
-// the same for C % 4 == 0: a thread owns FOUR channels (float4 loads) and rows r, r+R, ...: block = (C/4)*R <= 512 threads
-__global__ __launch_bounds__(512) void k_dwg_bwd_dw4(const float *__restrict__ x, const float *__restrict__ dy, DwG g, int R,
-                                                      long px_per_chunk, float *__restrict__ part) {
-    extern __shared__ __align__(16) float redf[];           // [R][C]
+// the same for C % 4 == 0: a thread owns FOUR channels (float4 loads) and rows r, r+R, ...: block = (C/4)*R <= 512 threads.
+// Up to NCHUNK_DW blocks (four resident per CU); 32-bit pixel arithmetic; the row lanes of a block are summed through LDS
+// T taps at a time (T * R * C floats <= 48 KB), each (tap, channel quad) by one thread in fixed order.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_dwg_bwd_dw4(const float *__restrict__ x, const float *__restrict__ dy, DwG g, int R,
+                                                      uint32_t px_per_chunk, int T, float *__restrict__ part) {
+    extern __shared__ __align__(16) float redf[];           // [T][R][C]
     const int C4 = g.C / 4, cq = threadIdx.x % C4, r = threadIdx.x / C4, pad = g.k / 2, kk = g.k * g.k;
-    const long P = (long)g.B * g.Ho * g.Wo;
-    const long p0 = (long)blockIdx.x * px_per_chunk, p1 = min(P, p0 + px_per_chunk);
+    const uint32_t P = (uint32_t)g.B * g.Ho * g.Wo;
+    const uint32_t p0 = blockIdx.x * px_per_chunk, p1 = min(P, p0 + px_per_chunk);
     float ax[25], ay[25], az[25], aw[25];       // plain arrays: an array of HIP float4 structs is not promoted to registers
 #pragma unroll
     for (int t = 0; t < 25; ++t) { ax[t] = 0.f; ay[t] = 0.f; az[t] = 0.f; aw[t] = 0.f; }
-    for (long p = p0 + r; p < p1; p += R) {
-        const int wo = (int)(p % g.Wo);
-        const long q = p / g.Wo;
-        const int ho = (int)(q % g.Ho), b = (int)(q / g.Ho);
+    for (uint32_t p = p0 + r; p < p1; p += R) {
+        const uint32_t q = p / (uint32_t)g.Wo;
+        const int wo = (int)(p - q * g.Wo);
+        const uint32_t b = q / (uint32_t)g.Ho;
+        const int ho = (int)(q - b * g.Ho);
         const float4 d = *reinterpret_cast<const float4 *>(dy + (size_t)p * g.C + 4 * cq);
+        const float *xb = x + (size_t)b * g.H * g.W * g.C + 4 * cq;
 #pragma unroll
         for (int kh = 0; kh < 5; ++kh) {
             const int hi = ho * g.s + kh - pad;
@@ -315,32 +358,38 @@ __global__ __launch_bounds__(512) void k_dwg_bwd_dw4(const float *__restrict__ x
             for (int kw = 0; kw < 5; ++kw) {
                 const int wi = wo * g.s + kw - pad;
                 if (kw >= g.k || wi < 0 || wi >= g.W) continue;
-                const float4 xv = *reinterpret_cast<const float4 *>(x + (((size_t)b * g.H + hi) * g.W + wi) * g.C + 4 * cq);
+                const float4 xv = *reinterpret_cast<const float4 *>(xb + (uint32_t)((hi * g.W + wi) * g.C));
                 const int t = kh * 5 + kw;
                 ax[t] = fmaf(d.x, xv.x, ax[t]); ay[t] = fmaf(d.y, xv.y, ay[t]);
                 az[t] = fmaf(d.z, xv.z, az[t]); aw[t] = fmaf(d.w, xv.w, aw[t]);
             }
         }
     }
-    for (int kh = 0; kh < g.k; ++kh)
-        for (int kw = 0; kw < g.k; ++kw) {
-            __syncthreads();
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int slot = 0, base = 0;                     // taps base .. base + slot - 1 (in (kh, kw) order) sit in LDS
+    float *outp = part + (size_t)blockIdx.x * g.C * kk + (size_t)(4 * cq) * kk;
 #pragma unroll
-            for (int a5 = 0; a5 < 25; ++a5)
-                if (a5 == kh * 5 + kw) v = make_float4(ax[a5], ay[a5], az[a5], aw[a5]);
-            *reinterpret_cast<float4 *>(redf + r * g.C + 4 * cq) = v;
-            __syncthreads();
-            if (r == 0) {
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int i = 0; i < R; ++i) {
-                    const float4 u = *reinterpret_cast<const float4 *>(redf + i * g.C + 4 * cq);
-                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    for (int a5 = 0; a5 < 25; ++a5) {
+        const int kh = a5 / 5, kw = a5 % 5;     // compile-time: the accumulators are read by constant index
+        if (kh < g.k && kw < g.k) {             // uniform
+            *reinterpret_cast<float4 *>(redf + ((size_t)slot * R + r) * g.C + 4 * cq) = make_float4(ax[a5], ay[a5], az[a5], aw[a5]);
+            ++slot;
+            if (slot == T || (kh == g.k - 1 && kw == g.k - 1)) {
+                __syncthreads();
+                for (int sl = r; sl < slot; sl += R) {
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int i = 0; i < R; ++i) {
+                        const float4 u = *reinterpret_cast<const float4 *>(redf + ((size_t)sl * R + i) * g.C + 4 * cq);
+                        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                    }
+                    float *o = outp + base + sl;
+                    o[0] = t.x; o[kk] = t.y; o[2 * kk] = t.z; o[3 * kk] = t.w;
                 }
-                float *o = part + (size_t)blockIdx.x * g.C * kk + (size_t)(4 * cq) * kk + kh * g.k + kw;
-                o[0] = t.x; o[kk] = t.y; o[2 * kk] = t.z; o[3 * kk] = t.w;
+                __syncthreads();
+                base += slot;
+                slot = 0;
             }
         }
+    }
 }
 
 // ---- squeeze-excitation / pooling pieces on (B, HW, C)
@@ -353,6 +402,7 @@ __global__ __launch_bounds__(1024) void k_pool_fwd(const float *__restrict__ x, 
     double a = 0.0;
     if (c < C) {
         const float *p = x + (size_t)b * HW * C + c;
+#pragma unroll 8
         for (int h = part; h < HW; h += 16) a += p[(size_t)h * C];
     }
     sh[part][cl] = a;
@@ -374,6 +424,41 @@ __global__ __launch_bounds__(256) void k_scale_fwd(const float *__restrict__ x, 
         y[i] = x[i] * gte[b * C + c];
     }
 }
+__global__ __launch_bounds__(256) void k_scale_fwd4(const float4 *__restrict__ x, const float *__restrict__ gte, uint32_t n4,
+                                                    uint32_t HWC4, int C, float4 *__restrict__ y) {
+    const uint32_t C4 = (uint32_t)C >> 2;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        const uint32_t b = i / HWC4, c = (i % C4) * 4;
+        const float4 v = x[i], g = *reinterpret_cast<const float4 *>(gte + (size_t)b * C + c);
+        y[i] = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
+    }
+}
+__global__ __launch_bounds__(256) void k_scale_pool_bwd4(const float4 *__restrict__ dy, const float *__restrict__ gte,
+                                                         const float *__restrict__ dpool, uint32_t n4, uint32_t HWC4, int HW, int C,
+                                                         float4 *__restrict__ dx) {
+    const uint32_t C4 = (uint32_t)C >> 2;
+    const float inv = 1.0f / (float)HW;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        const uint32_t b = i / HWC4, c = (i % C4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dy) {
+            const float4 d = dy[i], g = *reinterpret_cast<const float4 *>(gte + (size_t)b * C + c);
+            v = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        }
+        if (dpool) {
+            const float4 dp = *reinterpret_cast<const float4 *>(dpool + (size_t)b * C + c);
+            v = make_float4(fmaf(dp.x, inv, v.x), fmaf(dp.y, inv, v.y), fmaf(dp.z, inv, v.z), fmaf(dp.w, inv, v.w));
+        }
+        dx[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_add4(const float4 *__restrict__ a, const float4 *__restrict__ b, uint32_t n4,
+                                              float4 *__restrict__ y) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        const float4 u = a[i], v = b[i];
+        y[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+}
 // dg[b][c] = sum_hw dy * x   (same thread map as k_pool_fwd)
 __global__ __launch_bounds__(1024) void k_scale_bwd_gate(const float *__restrict__ x, const float *__restrict__ dy, int B, int HW,
                                                          int C, float *__restrict__ dg) {
@@ -383,6 +468,7 @@ __global__ __launch_bounds__(1024) void k_scale_bwd_gate(const float *__restrict
     double a = 0.0;
     if (c < C) {
         const size_t o = (size_t)b * HW * C + c;
+#pragma unroll 8
         for (int h = part; h < HW; h += 16) a += (double)dy[o + (size_t)h * C] * (double)x[o + (size_t)h * C];
     }
     sh[part][cl] = a;
@@ -427,13 +513,20 @@ __global__ __launch_bounds__(256) void k_add(const float *__restrict__ a, const 
 }
 
 inline int egrid(long n) { return (int)std::min<long>((n + 255) / 256, 256 * 32); }
+// float4 form usable: channel count a multiple of 4, every base pointer 16-byte aligned, index fits 32 bits
+inline bool vec4_ok(long n, int C, std::initializer_list<const void *> ptrs) {
+    if ((C & 3) || (n & 3) || n / 4 >= (1L << 31)) return false;
+    for (const void *p : ptrs)
+        if ((uintptr_t)p & 15) return false;
+    return true;
+}
 inline int rows_r(int C) { return std::max(1, 1024 / C); }                       // row lanes R of a C*R-thread block
 inline int chunks_for(long M, int C) { return (int)std::max<long>(1, std::min<long>(NCHUNK, M / (4L * rows_r(C)))); }
 
 }  // namespace
 
 // scratch of one layer call: chunk partials (BatchNorm: 2C per chunk, depthwise weight gradient: up to 25C per chunk) + 2C sums
-extern "C" size_t ww_nhwc_scratch_bytes(int C) { return (size_t)(NCHUNK * 25 + 2) * std::max(C, 1) * sizeof(float); }
+extern "C" size_t ww_nhwc_scratch_bytes(int C) { return (size_t)(NCHUNK_DW * 25 + 2) * std::max(C, 1) * sizeof(float); }
 
 extern "C" int ww_bn_act_fwd(ww_ctx *ctx, const float *x, long M, int C, const ww_bn_t *bn, int act, float *y, float *ss,
                              float *mr, void *scratch, ww_stream_t stream) {
@@ -453,7 +546,11 @@ extern "C" int ww_bn_act_fwd(ww_ctx *ctx, const float *x, long M, int C, const w
     }
     hipLaunchKernelGGL(k_bn_finish, dim3((C + 63) / 64), dim3(1024), 0, st, part, chunks, M, C, *bn, ss, mr);
     WW_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bn_act_apply, dim3(egrid(M * C)), dim3(256), 0, st, x, ss, M * C, C, act, y);
+    if (vec4_ok(M * C, C, {x, y, ss}))
+        hipLaunchKernelGGL(k_bn_act_apply4, dim3(egrid(M * C / 4)), dim3(256), 0, st, (const float4 *)x, ss, (uint32_t)(M * C / 4), C,
+                           act, (float4 *)y);
+    else
+        hipLaunchKernelGGL(k_bn_act_apply, dim3(egrid(M * C)), dim3(256), 0, st, x, ss, M * C, C, act, y);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -472,7 +569,11 @@ extern "C" int ww_bn_act_bwd(ww_ctx *ctx, const float *x, const float *da, long 
     WW_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_bnact_bwd_finish, dim3((C + 63) / 64), dim3(1024), 0, st, part, chunks, C, sums, dgamma, dbeta);
     WW_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bnact_bwd_apply, dim3(egrid(M * C)), dim3(256), 0, st, x, da, ss, mr, sums, M, C, act, training, dx);
+    if (vec4_ok(M * C, C, {x, da, dx, ss, mr, sums}))
+        hipLaunchKernelGGL(k_bnact_bwd_apply4, dim3(egrid(M * C / 4)), dim3(256), 0, st, (const float4 *)x, (const float4 *)da, ss,
+                           mr, sums, M, (uint32_t)(M * C / 4), C, act, training, (float4 *)dx);
+    else
+        hipLaunchKernelGGL(k_bnact_bwd_apply, dim3(egrid(M * C)), dim3(256), 0, st, x, da, ss, mr, sums, M, C, act, training, dx);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -518,9 +619,11 @@ extern "C" int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, c
     int chunks;
     if ((C & 3) == 0) {
         const int R4 = std::max(1, std::min(32, 512 / (C / 4)));      // <= 512 threads: 100 accumulator registers per thread
-        chunks = (int)std::max<long>(1, std::min<long>(NCHUNK, P / (4L * R4)));
-        hipLaunchKernelGGL(k_dwg_bwd_dw4, dim3(chunks), dim3((C / 4) * R4), (size_t)R4 * C * sizeof(float), st, x, dy, g, R4,
-                           (P + chunks - 1) / chunks, part);
+        WW_REQUIRE(P < (1L << 31) && (long)H * W * C < (1L << 31), WW_E_UNSUPPORTED, "ww_dwconv_nhwc_bwd: tensor too large for 32-bit pixel indices");
+        chunks = (int)std::max<long>(1, std::min<long>(NCHUNK_DW, P / (4L * R4)));
+        const int T = std::max(1, std::min(k * k, 12288 / (R4 * C)));   // taps per LDS round: <= 48 KB
+        hipLaunchKernelGGL(k_dwg_bwd_dw4, dim3(chunks), dim3((C / 4) * R4), (size_t)T * R4 * C * sizeof(float), st, x, dy, g, R4,
+                           (uint32_t)((P + chunks - 1) / chunks), T, part);
     } else {
         const int R = rows_r(C);
         chunks = chunks_for(P, C);
@@ -539,7 +642,12 @@ extern "C" int ww_pool_hw_fwd(ww_ctx *ctx, const float *x, int B, int HW, int C,
 }
 extern "C" int ww_scale_bc_fwd(ww_ctx *ctx, const float *x, const float *gate, int B, int HW, int C, float *y, ww_stream_t stream) {
     WW_REQUIRE(ctx && x && gate && y && B >= 1 && HW >= 1 && C >= 1, WW_E_INVALID, "ww_scale_bc_fwd: bad argument");
-    hipLaunchKernelGGL(k_scale_fwd, dim3(egrid((long)B * HW * C)), dim3(256), 0, (hipStream_t)stream, x, gate, B, HW, C, y);
+    const long n = (long)B * HW * C;
+    if (vec4_ok(n, C, {x, gate, y}))
+        hipLaunchKernelGGL(k_scale_fwd4, dim3(egrid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4 *)x, gate, (uint32_t)(n / 4),
+                           (uint32_t)((long)HW * C / 4), C, (float4 *)y);
+    else
+        hipLaunchKernelGGL(k_scale_fwd, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, x, gate, B, HW, C, y);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -553,7 +661,12 @@ extern "C" int ww_scale_bc_bwd_gate(ww_ctx *ctx, const float *x, const float *dy
 extern "C" int ww_scale_pool_bwd(ww_ctx *ctx, const float *dy, const float *gate, const float *dpool, int B, int HW, int C,
                                  float *dx, ww_stream_t stream) {
     WW_REQUIRE(ctx && dx && (dy || dpool) && (!dy || gate) && B >= 1 && HW >= 1 && C >= 1, WW_E_INVALID, "ww_scale_pool_bwd: bad argument");
-    hipLaunchKernelGGL(k_scale_pool_bwd, dim3(egrid((long)B * HW * C)), dim3(256), 0, (hipStream_t)stream, dy, gate, dpool, B, HW, C, dx);
+    const long n = (long)B * HW * C;
+    if (vec4_ok(n, C, {dy, gate, dpool, dx}))
+        hipLaunchKernelGGL(k_scale_pool_bwd4, dim3(egrid(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4 *)dy, gate, dpool,
+                           (uint32_t)(n / 4), (uint32_t)((long)HW * C / 4), HW, C, (float4 *)dx);
+    else
+        hipLaunchKernelGGL(k_scale_pool_bwd, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dy, gate, dpool, B, HW, C, dx);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -567,7 +680,11 @@ extern "C" int ww_im2col3x3s2(ww_ctx *ctx, const float *x, int B, int H, int W, 
 extern "C" int ww_add_f32(ww_ctx *ctx, const float *a, const float *b, size_t n, float *y, ww_stream_t stream) {
     WW_REQUIRE(ctx && a && b && y, WW_E_INVALID, "ww_add_f32: null argument");
     if (n == 0) return WW_OK;
-    hipLaunchKernelGGL(k_add, dim3(egrid((long)n)), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, y);
+    if (vec4_ok((long)n, 4, {a, b, y}))
+        hipLaunchKernelGGL(k_add4, dim3(egrid((long)n / 4)), dim3(256), 0, (hipStream_t)stream, (const float4 *)a, (const float4 *)b,
+                           (uint32_t)(n / 4), (float4 *)y);
+    else
+        hipLaunchKernelGGL(k_add, dim3(egrid((long)n)), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, y);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
