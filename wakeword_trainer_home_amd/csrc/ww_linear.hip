@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void k_splitk_sum(const float *__restrict__ P,
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
         if (i + 3 < n) {
             float4 s = *reinterpret_cast<const float4 *>(P + i);
+#pragma unroll 8
             for (int z = 1; z < splits; ++z) {
                 const float4 t = *reinterpret_cast<const float4 *>(P + (long)z * n + i);
                 s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;

@@ -202,13 +202,14 @@ __global__ __launch_bounds__(256) void k_dwg_fwd(const float *__restrict__ x, co
     const bool vec = (g.C & 3) == 0;
     for (int i = threadIdx.x; i < g.C * kk; i += 256) wl[(i % kk) * g.C + i / kk] = w[i];
     __syncthreads();
-    const long n = (long)g.B * g.Ho * g.Wo * c4n;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int cq = (int)(i % c4n);
-        long p = i / c4n;
-        const int wo = (int)(p % g.Wo); p /= g.Wo;
-        const int ho = (int)(p % g.Ho);
-        const int b = (int)(p / g.Ho);
+    const uint32_t n = (uint32_t)g.B * g.Ho * g.Wo * c4n;      // < 2^31 (host check): 32-bit index arithmetic
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        uint32_t p = i / (uint32_t)c4n;
+        const int cq = (int)(i - p * c4n);
+        uint32_t q = p / (uint32_t)g.Wo;
+        const int wo = (int)(p - q * g.Wo);
+        const int b = (int)(q / (uint32_t)g.Ho);
+        const int ho = (int)(q - (uint32_t)b * g.Ho);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int kh = 0; kh < g.k; ++kh) {
             const int hi = ho * g.s + kh - pad;
@@ -247,13 +248,14 @@ __global__ __launch_bounds__(256) void k_dwg_bwd_dx(const float *__restrict__ dy
     const bool vec = (g.C & 3) == 0;
     for (int i = threadIdx.x; i < g.C * kk; i += 256) wl[(i % kk) * g.C + i / kk] = w[i];
     __syncthreads();
-    const long n = (long)g.B * g.H * g.W * c4n;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int cq = (int)(i % c4n);
-        long p = i / c4n;
-        const int wi = (int)(p % g.W); p /= g.W;
-        const int hi = (int)(p % g.H);
-        const int b = (int)(p / g.H);
+    const uint32_t n = (uint32_t)g.B * g.H * g.W * c4n;        // < 2^31 (host check): 32-bit index arithmetic
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        uint32_t p = i / (uint32_t)c4n;
+        const int cq = (int)(i - p * c4n);
+        uint32_t q = p / (uint32_t)g.W;
+        const int wi = (int)(p - q * g.W);
+        const int b = (int)(q / (uint32_t)g.H);
+        const int hi = (int)(q - (uint32_t)b * g.H);
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int kh = 0; kh < g.k; ++kh) {
             const int th = hi + pad - kh;
@@ -595,6 +597,7 @@ extern "C" int ww_dwconv_nhwc_fwd(ww_ctx *ctx, const float *x, const float *w, i
     ww_prof_scope ps_(ctx, WW_K_NHWC, (hipStream_t)stream);
     const size_t wbytes = (size_t)C * k * k * sizeof(float);
     WW_REQUIRE(wbytes <= 64 * 1024, WW_E_UNSUPPORTED, "ww_dwconv_nhwc_fwd: C*k*k = %d weights do not fit the LDS cache", C * k * k);
+    WW_REQUIRE((long)B * H * W * C < (1L << 31), WW_E_UNSUPPORTED, "ww_dwconv_nhwc_fwd: tensor too large for 32-bit indices");
     hipLaunchKernelGGL(k_dwg_fwd, dim3(egrid((long)B * g.Ho * g.Wo * ((C + 3) / 4))), dim3(256), wbytes, (hipStream_t)stream, x, w, g, y);
     WW_LAUNCH_CHECK();
     return WW_OK;
@@ -610,6 +613,7 @@ extern "C" int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, c
     if (dx) {
         const size_t wbytes = (size_t)C * k * k * sizeof(float);
         WW_REQUIRE(wbytes <= 64 * 1024, WW_E_UNSUPPORTED, "ww_dwconv_nhwc_bwd: C*k*k = %d weights do not fit the LDS cache", C * k * k);
+        WW_REQUIRE((long)B * H * W * C < (1L << 31), WW_E_UNSUPPORTED, "ww_dwconv_nhwc_bwd: tensor too large for 32-bit indices");
         hipLaunchKernelGGL(k_dwg_bwd_dx, dim3(egrid((long)B * H * W * ((C + 3) / 4))), dim3(256), wbytes, st, dy, w, g, dx);
         WW_LAUNCH_CHECK();
     }

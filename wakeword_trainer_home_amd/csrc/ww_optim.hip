@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
                                                       float *__restrict__ norm_out, ww_step_stats *__restrict__ stats,
                                                       ww_step_stats *__restrict__ stats_host,
                                                       ww_step_stats *__restrict__ stats_host_alt,
-                                                      const float *__restrict__ found_inf_extra) {
+                                                      const float *__restrict__ found_inf_extra, int vec) {
     optim_resolve(a, parity);
     if (parity && stats_host_alt) stats_host = stats_host_alt;
     double t = 0.0;
@@ -188,7 +188,28 @@ __global__ __launch_bounds__(256) void k_optim_update(OptimArgs a, float *__rest
     }
     float step_size, bc2_sqrt;
     bias_terms(a, t0 + 1, step_size, bc2_sqrt);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    // float4 body (the buckets are 16-byte aligned: host check) + scalar tail; per element the arithmetic of the scalar form
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 g4 = reinterpret_cast<const float4 *>(g)[i];
+        float ge[4] = {g4.x * inv_scale, g4.y * inv_scale, g4.z * inv_scale, g4.w * inv_scale};
+        if (clip || a.ls) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ge[e] *= c;
+            reinterpret_cast<float4 *>(g)[i] = make_float4(ge[0], ge[1], ge[2], ge[3]);
+        }
+        if (skip) continue;
+        const float4 p4 = reinterpret_cast<const float4 *>(p)[i];
+        const float4 m4 = m ? reinterpret_cast<const float4 *>(m)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v4 = v ? reinterpret_cast<const float4 *>(v)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float pe[4] = {p4.x, p4.y, p4.z, p4.w}, me[4] = {m4.x, m4.y, m4.z, m4.w}, ve[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) optim_update(a, pe[e], ge[e], me[e], ve[e], step_size, bc2_sqrt);
+        reinterpret_cast<float4 *>(p)[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
+        if (m) reinterpret_cast<float4 *>(m)[i] = make_float4(me[0], me[1], me[2], me[3]);
+        if (v) reinterpret_cast<float4 *>(v)[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+    }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float gi = g[i] * inv_scale;
         if (clip || a.ls) { gi *= c; g[i] = gi; }   // clip_grad_norm_ / unscale_ leave the clipped, unscaled gradients behind
         if (skip) continue;
@@ -255,10 +276,11 @@ extern "C" int ww_clip_optim_step(ww_ctx *ctx, const ww_optim_cfg *cfg, float *f
     int parts = 0;
     const int rc = ww_launch_sumsq_partials(ctx, flat_grads, n, &parts, st);
     if (rc) return rc;
-    const int grid = (int)std::min<size_t>((n + 255) / 256, 256 * 8);
+    const int vec = (((uintptr_t)flat_params | (uintptr_t)flat_grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0;
+    const int grid = (int)std::min<size_t>(((vec ? n / 4 + 3 : n) + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(k_optim_update, dim3(grid), dim3(256), 0, st, a, flat_params, flat_grads, exp_avg, exp_avg_sq, n,
                        (long long *)step_state, parity, ctx->norm_partials, parts, norm_out, stats, stats_host_dev,
-                       stats_host_alt_dev, found_inf_extra);
+                       stats_host_alt_dev, found_inf_extra, vec);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
