@@ -17,12 +17,15 @@ typedef float ww_f32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> struct Act;
 
+
 template <> struct Act<float> {
     typedef float2 raw2;
     typedef float4 raw4;
     static constexpr bool is_f32 = true;
     static __device__ __forceinline__ raw2 ldraw2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
     static __device__ __forceinline__ raw4 ldraw4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ raw2 ldraw2_nt(const float *p) { return ldraw2(p); }
+    static __device__ __forceinline__ raw4 ldraw4_nt(const float *p) { return ldraw4(p); }
     static __device__ __forceinline__ float2 cvt2(raw2 r) { return r; }
     static __device__ __forceinline__ float4 cvt4(raw4 r) { return r; }
     static __device__ __forceinline__ void st2(float *p, float2 v) { *reinterpret_cast<float2 *>(p) = v; }
@@ -42,6 +45,15 @@ template <> struct Act<ww_bf16> {
     static constexpr bool is_f32 = false;
     static __device__ __forceinline__ raw2 ldraw2(const ww_bf16 *p) { return *reinterpret_cast<const uint32_t *>(p); }
     static __device__ __forceinline__ raw4 ldraw4(const ww_bf16 *p) { return *reinterpret_cast<const uint2 *>(p); }
+    // single-use streams (read once per step by this kernel, dead afterwards): non-temporal, so they do not displace the
+    // lines the NEXT kernel will re-read from the Infinity Cache
+    static __device__ __forceinline__ raw2 ldraw2_nt(const ww_bf16 *p) { return __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p)); }
+    static __device__ __forceinline__ raw4 ldraw4_nt(const ww_bf16 *p) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        const u2 v = __builtin_nontemporal_load(reinterpret_cast<const u2 *>(q));
+        return make_uint2(v.x, v.y);
+    }
     static __device__ __forceinline__ float2 cvt2(raw2 r) {
         return make_float2(__uint_as_float(r << 16), __uint_as_float(r & 0xffff0000u));
     }
@@ -71,6 +83,15 @@ template <> struct Act<ww_f16> {
     static constexpr bool is_f32 = false;
     static __device__ __forceinline__ raw2 ldraw2(const ww_f16 *p) { return *reinterpret_cast<const uint32_t *>(p); }
     static __device__ __forceinline__ raw4 ldraw4(const ww_f16 *p) { return *reinterpret_cast<const uint2 *>(p); }
+    // single-use streams (read once per step by this kernel, dead afterwards): non-temporal, so they do not displace the
+    // lines the NEXT kernel will re-read from the Infinity Cache
+    static __device__ __forceinline__ raw2 ldraw2_nt(const ww_f16 *p) { return __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p)); }
+    static __device__ __forceinline__ raw4 ldraw4_nt(const ww_f16 *p) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        const u2 v = __builtin_nontemporal_load(reinterpret_cast<const u2 *>(q));
+        return make_uint2(v.x, v.y);
+    }
     static __device__ __forceinline__ float2 cvt2(raw2 r) {
         const ww_f32x2 f = __builtin_convertvector(__builtin_bit_cast(ww_f16x2, r), ww_f32x2);
         return make_float2(f.x, f.y);

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             long p = ti * PWB_TILE + (tid >> 4) + 16 * i;
             p = p < M ? p : M - 1;
             ri[i] = A16::ldraw4(y_in + (size_t)p * 64 + 4 * c4);
-            if (!FROM_POOL) rg[i] = A16::ldraw4(g + (size_t)p * 64 + 4 * c4);
+            if (!FROM_POOL) rg[i] = A16::ldraw4_nt(g + (size_t)p * 64 + 4 * c4);
         }
         if (FROM_POOL && WIDE_IMG) {
             const long b0 = (long)((uint32_t)(ti * PWB_TILE) / (uint32_t)HW);   // M < 2^31 (checked on the host): 32-bit division
@@ -484,7 +484,7 @@ __device__ __forceinline__ void dwb_issue_centre(const T *__restrict__ yin_img, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int wc = min(w0 + i, W - 1);
-        rc[i] = Act<T>::ldraw2(yin_img + (uint32_t)((hh * W + wc) * 64 + 2 * cl));
+        rc[i] = Act<T>::ldraw2_nt(yin_img + (uint32_t)((hh * W + wc) * 64 + 2 * cl));
     }
 }
 
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void k_stem_bwd(const T *__restrict__ g, const
             for (int j = 0; j < 10; ++j) {
                 const int ow = min(ow0 + 8 * j, Wo - 1);
                 const size_t o = ((size_t)row * Wo + ow) * 64 + 2 * cl;
-                gr[j] = Act<T>::ldraw2(g + o);
+                gr[j] = Act<T>::ldraw2_nt(g + o);
                 if constexpr (!RECOMP) yr[j] = Act<T>::ldraw2(y_out + o);
             }
 #pragma unroll

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_pw_fwd_bf16(const H *__restrict__ yin, 
         for (int i = 0; i < 8; ++i) {
             long p = ti * PW_TILE + (tid >> 4) + 16 * i;
             p = p < M ? p : M - 1;
-            raw[i] = A16::ldraw4(yin + (size_t)p * 64 + 4 * c4);
+            raw[i] = A16::ldraw4_nt(yin + (size_t)p * 64 + 4 * c4);
         }
     };
     if ((long)blockIdx.x < ntiles) issue(blockIdx.x);
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(1024) void k_gap_fwd(const T *__restrict__ y, const
     float a0 = 0.f, a1 = 0.f, h0 = 0.f, h1 = 0.f, c0 = 0.f, c1 = 0.f;
 #pragma unroll 4
     for (int p = slot; p < HW; p += 32) {
-        const float2 v = Act<T>::cvt2(Act<T>::ldraw2(yb + (size_t)p * 64 + 2 * cl));
+        const float2 v = Act<T>::cvt2(Act<T>::ldraw2_nt(yb + (size_t)p * 64 + 2 * cl));
         const float z0 = fmaf(v.x, sc.x, sf.x), z1 = fmaf(v.y, sc.y, sf.y);
         a0 += z0 < 0.f ? 0.f : z0;                       // NaN-propagating ReLU, as torch
         a1 += z1 < 0.f ? 0.f : z1;
