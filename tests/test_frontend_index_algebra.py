@@ -118,3 +118,33 @@ def test_mel_band_halves_cover_each_band_once():
         h0 = (L + 1) >> 1
         halves = list(range(0, h0)) + list(range(h0, L))
         assert halves == list(range(L))
+
+
+def test_gemm16_lds_image_swizzle_is_a_bijection_and_conflict_free():
+    """ww_gemm16.hip: an operand tile (128 rows x 64 16-bit elements = 8 chunks of 16 B per row) is written by LDS-DMA, whose
+    image is lane-linear (wave-instruction `piece` puts lane l at byte piece*1024 + 16*l), so the swizzle lives on the SOURCE
+    side: lane l of piece p fetches chunk (l & 7) ^ ((row >> 1) & 7) of row = 8p + (l >> 3).  A fragment read of (row, chunk)
+    goes to byte row*128 + 16*(chunk ^ ((row >> 1) & 7)).  Checked here: every (row, chunk) is found where the read looks for it,
+    and each 16-lane service group of a ds_read_b128 (MI355X: {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) touches 16 different
+    16-byte bank slots of the 256-byte LDS line for every fragment the kernel reads."""
+    image = {}
+    for piece in range(16):
+        for lane_ in range(64):
+            row = piece * 8 + (lane_ >> 3)
+            chunk = (lane_ & 7) ^ ((row >> 1) & 7)
+            image[piece * 1024 + 16 * lane_] = (row, chunk)
+    assert len(image) == 128 * 8 and len(set(image.values())) == 128 * 8
+
+    def addr(row, chunk):
+        return row * 128 + 16 * (chunk ^ ((row >> 1) & 7))
+
+    for row in range(128):
+        for chunk in range(8):
+            assert image[addr(row, chunk)] == (row, chunk)
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for rowbase in (0, 32, 64, 96):
+        for ks in range(4):
+            for g in groups:
+                slots = {(addr(rowbase + (l & 31), 2 * ks + (l >> 5)) % 256) // 16 for l in g}
+                assert len(slots) == 16, (rowbase, ks, g)

@@ -350,8 +350,10 @@ class Trainer:
 
     def _prepare_native(self, inputs, targets, step_index):
         """Input stage of a native step on its own HIP stream: H2D (if needed) + fused log-mel/SpecAugment.  It has no
-        dependency on the model, so for batch k+1 it runs while step k's conv stack (HBM-bound) is executing -- the
-        front end is LDS/latency-bound, the two overlap well.  Returns (features, targets, ready_event, step_index)."""
+        dependency on the model, so for batch k+1 it runs while step k's conv stack is executing.  The overlap is not free:
+        the resident log-mel workgroups take registers / LDS from the conv kernels, which is why the
+        kernel is launched with ``input_stage_workgroups`` persistent workgroups here (one per CU) instead of a full-device
+        grid.  Returns (features, targets, ready_event, step_index)."""
         if self._in_stream is None:
             self._in_stream = torch.cuda.Stream(device=self.device)
         with torch.cuda.stream(self._in_stream):
