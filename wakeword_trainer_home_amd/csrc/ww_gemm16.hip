@@ -122,11 +122,8 @@ template <typename H, typename CT>
 int launch(const void *A, const void *B, void *C, long M, long N, long K, hipStream_t st) {
     const int tiles_m = (int)((M + GB_M - 1) / GB_M), tiles_n = (int)((N + GB_N - 1) / GB_N);
     const size_t smem = 4 * TILE_BYTES;
-    static bool attr = false;             // per instantiation
-    if (!attr) {
-        WW_HIP(hipFuncSetAttribute((const void *)k_gemm16_nt<H, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
+    // every call: the attribute belongs to the (function, device) pair and a process may drive several devices
+    WW_HIP(hipFuncSetAttribute((const void *)k_gemm16_nt<H, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL((k_gemm16_nt<H, CT>), dim3(tiles_m * tiles_n), dim3(256), smem, st, (const H *)A, (const H *)B, (CT *)C, M,
                        N, K, tiles_m, tiles_n);
     WW_LAUNCH_CHECK();
