@@ -6,9 +6,15 @@
 #include <stdint.h>
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_corun(int mode, long iters, const float *__restrict__ src, float *__restrict__ out) {
+void k_corun(int mode, long iters, const float *__restrict__ src, float *__restrict__ out, unsigned *__restrict__ where) {
     extern __shared__ float lds[];                 // 41 KB
     const int tid = threadIdx.x;
+    if (where && tid == 0) {      // which CU this workgroup landed on: HW_ID (wave/simd/pipe/cu/sh/se) and XCC_ID
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        where[blockIdx.x] = ((xcc & 0xf) << 16) | (hw & 0xff00);      // XCC | SE SH CU
+    }
     float keep[96];                                // holds ~100 VGPRs live across the loop
 #pragma unroll
     for (int i = 0; i < 96; ++i) keep[i] = (float)(tid + i);
@@ -51,12 +57,12 @@ void k_corun(int mode, long iters, const float *__restrict__ src, float *__restr
     if (s == 12345.678f) out[tid] = s;
 }
 
-extern "C" int corun_launch(int mode, long iters, int grid, const float *src, float *out, void *stream) {
+extern "C" int corun_launch(int mode, long iters, int grid, const float *src, float *out, void *stream, unsigned *where) {
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void *)k_corun, hipFuncAttributeMaxDynamicSharedMemorySize, 41 * 1024) != hipSuccess) return 1;
         attr = true;
     }
-    hipLaunchKernelGGL(k_corun, dim3(grid), dim3(256), 41 * 1024, (hipStream_t)stream, mode, iters, src, out);
+    hipLaunchKernelGGL(k_corun, dim3(grid), dim3(256), 41 * 1024, (hipStream_t)stream, mode, iters, src, out, where);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -14,7 +14,7 @@ from wakeword_trainer_home_amd import _native as nat
 
 dev = "cuda:0"
 lib = C.CDLL(str(Path(__file__).resolve().parent / "corun" / "libcorun.so"))
-lib.corun_launch.argtypes = [C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+lib.corun_launch.argtypes = [C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 B = 512
 act = torch.bfloat16
 y_in = torch.randn(B, 20, 76, 64, device=dev).to(act)
@@ -39,8 +39,8 @@ side = torch.cuda.Stream(device=dev)
 n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
 
 
-def corun(mode, iters, grid):
-    rc = lib.corun_launch(mode, iters, grid, src.data_ptr(), out.data_ptr(), side.cuda_stream)
+def corun(mode, iters, grid, where=None):
+    rc = lib.corun_launch(mode, iters, grid, src.data_ptr(), out.data_ptr(), side.cuda_stream, where.data_ptr() if where is not None else None)
     assert rc == 0, rc
 
 
@@ -83,3 +83,21 @@ for name, fn in KERNELS.items():
             torch.cuda.synchronize()
             row[f"{label}_corunner_ms"] = round(t_side0.elapsed_time(t_side1), 2)     # must exceed the timed span (8 launches)
     print(json.dumps(row))
+
+
+# ---- where does the dispatcher put 256 persistent workgroups?  (a) on an idle GPU, (b) launched while a conv kernel is running
+from collections import Counter
+for label, busy in (("idle GPU", False), ("beside k_pw_bwd", True), ("beside k_dw_bwd", True)):
+    where = torch.zeros(n_cu, dtype=torch.int32, device=dev)
+    fn = KERNELS["dw_bwd"] if "dw" in label else KERNELS["pw_bwd"]
+    if busy:
+        for _ in range(6):
+            fn()
+    corun(0, 50, n_cu, where)
+    if busy:
+        for _ in range(6):
+            fn()
+    torch.cuda.synchronize()
+    per_cu = Counter(where.cpu().tolist())
+    hist = Counter(per_cu.values())
+    print(json.dumps({"placement": label, "workgroups": n_cu, "distinct_cus": len(per_cu), "cus_by_workgroups_hosted": dict(sorted(hist.items()))}))
