@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 9
+#define WW_ABI_VERSION 10
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -342,6 +342,18 @@ int ww_scale_bc_fwd(ww_ctx *ctx, const float *x, const float *gate, int B, int H
 int ww_scale_bc_bwd_gate(ww_ctx *ctx, const float *x, const float *dy, int B, int HW, int C, float *dgate, ww_stream_t stream);
 int ww_scale_pool_bwd(ww_ctx *ctx, const float *dy /* nullable */, const float *gate, const float *dpool /* nullable */, int B,
                       int HW, int C, float *dx, ww_stream_t stream);
+/* Squeeze-excitation as torchvision's mobilenet_v3_small builds it (the model src/models/architectures.py:91-102 instantiates):
+ * y = x * hardsigmoid(W2 relu(W1 mean_hw(x) + b1) + b2), x / y (B,HW,C), w1 (Cs,C), w2 (C,Cs) in nn.Conv2d(.,.,1) layout.  ONE launch
+ * forward (a workgroup owns whole images), TWO backward (dx + per-image pre-activation gradients, then the four parameter
+ * gradients as fixed-order sums over the batch); fp32 arithmetic whatever the model's matrix mode.  s (B,C), pre1 (B,Cs),
+ * pre2 (B,C) are kept for the backward.  C % 4 == 0, Cs % 4 == 0, C <= 1024, Cs <= 256, else WW_E_UNSUPPORTED (callers then compose the block
+ * from ww_pool_hw_fwd / ww_linear_mfma_* / ww_scale_bc_*).                                                              */
+size_t ww_se_bwd_scratch_bytes(int B, int C, int Cs);
+int ww_se_fwd(ww_ctx *ctx, const float *x, int B, int HW, int C, int Cs, const float *w1, const float *b1, const float *w2,
+              const float *b2, float *y, float *s, float *pre1, float *pre2, ww_stream_t stream);
+int ww_se_bwd(ww_ctx *ctx, const float *x, const float *dy, const float *s, const float *pre1, const float *pre2, const float *w1,
+              const float *w2, int B, int HW, int C, int Cs, float *dx, float *dw1, float *db1, float *dw2, float *db2,
+              void *scratch, size_t scratch_bytes, ww_stream_t stream);
 /* 3x3 stride-2 pad-1 patches of a one-channel image (B,H,W) -> (B*ceil(H/2)*ceil(W/2), 9): the stem conv becomes a GEMM */
 int ww_im2col3x3s2(ww_ctx *ctx, const float *x, int B, int H, int W, float *cols, ww_stream_t stream);
 int ww_add_f32(ww_ctx *ctx, const float *a, const float *b, size_t n, float *y, ww_stream_t stream);

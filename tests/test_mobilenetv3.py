@@ -47,7 +47,8 @@ def test_bn_act_layer(M, C, act, training):
 
 
 @pytest.mark.parametrize("B,H,W,C,k,s", [(3, 20, 76, 16, 3, 2), (2, 10, 38, 72, 3, 2), (2, 5, 19, 96, 5, 2), (2, 3, 10, 240, 5, 1),
-                                         (1, 2, 5, 576, 5, 1), (2, 7, 9, 10, 3, 1)])
+                                         (1, 2, 5, 576, 5, 1), (2, 7, 9, 10, 3, 1), (5, 5, 19, 88, 3, 1), (9, 3, 10, 288, 5, 2),
+                                         (21, 2, 5, 24, 5, 1), (3, 11, 11, 40, 3, 2)])
 def test_depthwise_layer(B, H, W, C, k, s):
     from wakeword_trainer_home_amd import _native as nat
     g = torch.Generator().manual_seed(H * W + C)
@@ -83,6 +84,39 @@ def test_se_pieces_and_stem_patches():
     cols = nat.im2col3x3s2(img[:, 0].contiguous().to(DEV)).cpu()
     ref = Fn.unfold(img, 3, padding=1, stride=2).transpose(1, 2).reshape(-1, 9)
     assert torch.equal(cols, ref)
+
+
+@pytest.mark.parametrize("B,HW,C,Cs", [(5, 190, 16, 8), (3, 30, 96, 24), (6, 30, 240, 64), (2, 10, 576, 144), (7, 9, 40, 12),
+                                       (130, 6, 24, 8), (41, 4, 32, 8), (129, 10, 576, 144), (34, 3, 1024, 256)])
+def test_se_block_one_launch_forward_two_backward(B, HW, C, Cs):
+    """ww_se_fwd / ww_se_bwd against the block in float64 torch (torchvision SqueezeExcitation semantics: avgpool -> fc1 ->
+    ReLU -> fc2 -> Hardsigmoid -> scale); the batch sizes cover the 1 / 2 / 4 images-per-workgroup variants and ragged tails."""
+    from wakeword_trainer_home_amd import _native as nat
+    g = torch.Generator().manual_seed(B + C)
+    x = torch.randn(B, HW, C, generator=g, dtype=torch.float64).requires_grad_(True)
+    w1 = (torch.randn(Cs, C, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    b1 = (torch.randn(Cs, generator=g, dtype=torch.float64) * 0.2).requires_grad_(True)
+    w2 = (torch.randn(C, Cs, generator=g, dtype=torch.float64) * 0.5).requires_grad_(True)
+    b2 = (torch.randn(C, generator=g, dtype=torch.float64) * 0.5).requires_grad_(True)
+    dy = torch.randn(B, HW, C, generator=g, dtype=torch.float64)
+    s_ref = x.mean(1)
+    pre1_ref = s_ref @ w1.T + b1
+    pre2_ref = torch.relu(pre1_ref) @ w2.T + b2
+    y_ref = x * Fn.hardsigmoid(pre2_ref)[:, None, :]
+    (y_ref * dy).sum().backward()
+    f = lambda t: t.detach().float().to(DEV).contiguous()
+    xd, w1d, b1d, w2d, b2d = f(x), f(w1), f(b1), f(w2), f(b2)
+    y, s, pre1, pre2 = nat.se_fwd(xd, w1d, b1d, w2d, b2d)
+    assert _rel(s.cpu().double(), s_ref.detach()) <= 1e-6
+    assert _rel(pre1.cpu().double(), pre1_ref.detach()) <= 5e-6 and _rel(pre2.cpu().double(), pre2_ref.detach()) <= 5e-6
+    assert _rel(y.cpu().double(), y_ref.detach()) <= 5e-6
+    dx, dw1, db1, dw2, db2 = nat.se_bwd(xd, f(dy), s, pre1, pre2, w1d, w2d)
+    assert _rel(dx.cpu().double(), x.grad) <= 1e-5
+    for got, want in ((dw1, w1.grad), (db1, b1.grad), (dw2, w2.grad), (db2, b2.grad)):
+        assert _rel(got.cpu().double(), want) <= 2e-5
+    y2, *_ = nat.se_fwd(xd, w1d, b1d, w2d, b2d)                 # fixed-order sums: the same bits on every launch
+    dx2, dw1b, *_ = nat.se_bwd(xd, f(dy), s, pre1, pre2, w1d, w2d)
+    assert torch.equal(y, y2) and torch.equal(dx, dx2) and torch.equal(dw1, dw1b)
 
 
 def test_mobilenetv3_matches_oracle():

@@ -13,7 +13,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 BWD_ALL, BWD_LATE, BWD_EARLY = 0, 1, 2
 ACT_F32, ACT_BF16, ACT_F16 = 0, 1, 2
 LOSS_CE, LOSS_FOCAL = 0, 1
@@ -130,6 +130,9 @@ _SIGS = {
     "ww_scale_bc_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ww_scale_bc_bwd_gate": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ww_scale_pool_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ww_se_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
+    "ww_se_fwd": (C.c_int, [_vp, _vp, _i, _i, _i, _i] + [_vp] * 9),
+    "ww_se_bwd": (C.c_int, [_vp] * 8 + [_i, _i, _i, _i] + [_vp] * 6 + [_sz, _vp]),
     "ww_im2col3x3s2": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ww_add_f32": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "ww_gru_workspace_bytes": (_sz, [_i, _i, _i, _i]),
@@ -575,6 +578,45 @@ def scale_pool_bwd(dy, gate, dpool, shape):
         _check(load().ww_scale_pool_bwd(ctx(dev), _p(dy), _p(gate), _p(dpool), B, HW, Cn, _p(dx), _stream(dev)),
                "ww_scale_pool_bwd")
     return dx
+
+
+def se_supported(Cn, Cs, *tensors):
+    """Shapes (and 16-byte alignment of the float4-read tensors) the one-launch squeeze-excitation kernels take -- ww_se_fwd's
+    documented limits."""
+    return (Cn % 4 == 0 and Cs % 4 == 0 and 4 <= Cn <= 1024 and 4 <= Cs <= 256
+            and all(t.data_ptr() % 16 == 0 for t in tensors))
+
+
+def se_fwd(x, w1, b1, w2, b2):
+    """x (B,HW,C), w1 (Cs,C), w2 (C,Cs) -> (y, s (B,C), pre1 (B,Cs), pre2 (B,C)); one launch."""
+    dev = _dev(x, w1, b1, w2, b2)
+    B, HW, Cn = x.shape
+    Cs = w1.shape[0]
+    y = torch.empty_like(x)
+    s = torch.empty((B, Cn), dtype=torch.float32, device=dev)
+    pre1 = torch.empty((B, Cs), dtype=torch.float32, device=dev)
+    pre2 = torch.empty((B, Cn), dtype=torch.float32, device=dev)
+    with _guard(dev):
+        _check(load().ww_se_fwd(ctx(dev), _p(x), B, HW, Cn, Cs, _p(w1), _p(b1), _p(w2), _p(b2), _p(y), _p(s), _p(pre1), _p(pre2),
+                                _stream(dev)), "ww_se_fwd")
+    return y, s, pre1, pre2
+
+
+def se_bwd(x, dy, s, pre1, pre2, w1, w2):
+    """-> (dx, dw1, db1, dw2, db2); two launches."""
+    dev = _dev(x, dy, s, pre1, pre2, w1, w2)
+    B, HW, Cn = x.shape
+    Cs = w1.shape[0]
+    dx = torch.empty_like(x)
+    dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+    db1 = torch.empty(Cs, dtype=torch.float32, device=dev)
+    db2 = torch.empty(Cn, dtype=torch.float32, device=dev)
+    nbytes = load().ww_se_bwd_scratch_bytes(B, Cn, Cs)
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    with _guard(dev):
+        _check(load().ww_se_bwd(ctx(dev), _p(x), _p(dy), _p(s), _p(pre1), _p(pre2), _p(w1), _p(w2), B, HW, Cn, Cs, _p(dx), _p(dw1),
+                                _p(db1), _p(dw2), _p(db2), _p(scratch), nbytes, _stream(dev)), "ww_se_bwd")
+    return dx, dw1, db1, dw2, db2
 
 
 def im2col3x3s2(x):

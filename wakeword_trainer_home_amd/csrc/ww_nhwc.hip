@@ -38,8 +38,16 @@ __global__ __launch_bounds__(1024) void k_colstats(const float *__restrict__ x, 
     const int c = threadIdx.x % C, r = threadIdx.x / C;
     const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
     double s = 0.0, q = 0.0;
-#pragma unroll 8
-    for (long row = r0 + r; row < r1; row += R) { const double v = x[row * C + c]; s += v; q += v * v; }
+    // a thread's rows in batches of eight (clamped, unconditional) loads: at these sizes a thread has 4-16 rows, so a guarded
+    // loop was one L2 round trip per row
+    for (long rb = r0 + r; rb < r1; rb += 8L * R) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[min(rb + (long)u * R, r1 - 1) * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (rb + (long)u * R < r1) { const double d = v[u]; s += d; q += d * d; }
+    }
     red[r * C + c] = s; red[(R + r) * C + c] = q;
     __syncthreads();
     if (r == 0) {
@@ -49,12 +57,24 @@ __global__ __launch_bounds__(1024) void k_colstats(const float *__restrict__ x, 
         part[(long)blockIdx.x * 2 * C + C + c] = (float)b;
     }
 }
-// fixed-order sum of the chunk partials of 64 columns by 16 row lanes: tot0/tot1 valid in the threads with p == 0
+// fixed-order sum of the chunk partials of 64 columns by 16 row lanes: tot0/tot1 valid in the threads with p == 0.  A lane's
+// <= 16 partial rows (chunks <= NCHUNK = 256) are loaded in ONE batch before the first add: as a load -> add loop the finish
+// kernels were a chain of 16 dependent L2 round trips (6-7 us between two 5 us kernels); the order of the adds is unchanged.
 __device__ __forceinline__ void chunk_sums(const float *__restrict__ part, int chunks, int C, int col, int p, int c,
                                            double (*sh)[16][64], double &tot0, double &tot1) {
     double s = 0.0, q = 0.0;
-    if (col < C)
-        for (int i = p; i < chunks; i += 16) { s += part[(long)i * 2 * C + col]; q += part[(long)i * 2 * C + C + col]; }
+    if (col < C) {
+        float sv[NCHUNK / 16], qv[NCHUNK / 16];
+#pragma unroll
+        for (int u = 0; u < NCHUNK / 16; ++u) {
+            const int i = min(p + 16 * u, chunks - 1);          // unconditional loads (a guarded load is a branch + wait each)
+            sv[u] = part[(long)i * 2 * C + col];
+            qv[u] = part[(long)i * 2 * C + C + col];
+        }
+#pragma unroll
+        for (int u = 0; u < NCHUNK / 16; ++u)
+            if (p + 16 * u < chunks) { s += sv[u]; q += qv[u]; }
+    }
     sh[0][p][c] = s; sh[1][p][c] = q;
     __syncthreads();
     tot0 = tot1 = 0.0;
@@ -69,6 +89,12 @@ __global__ __launch_bounds__(1024) void k_bn_finish(const float *__restrict__ pa
                                                     float *__restrict__ ss, float *__restrict__ mr) {
     __shared__ double sh[2][16][64];
     const int cl = threadIdx.x & 63, p = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    // the per-channel parameters are fetched BEFORE the partial sums (they used to be two more dependent round trips behind them)
+    float g_c = 0.f, b_c = 0.f, rm_c = 0.f, rv_c = 1.f;
+    if (p == 0 && c < C) {
+        g_c = bn.gamma[c]; b_c = bn.beta[c];
+        if (bn.running_mean) { rm_c = bn.running_mean[c]; rv_c = bn.running_var[c]; }
+    }
     double s = 0.0, q = 0.0;
     if (bn.training) chunk_sums(part, chunks, C, c, p, cl, sh, s, q);
     if (p != 0 || c >= C) return;
@@ -79,16 +105,16 @@ __global__ __launch_bounds__(1024) void k_bn_finish(const float *__restrict__ pa
         if (var < 0.0) var = 0.0;
         if (bn.running_mean) {
             const double m = bn.momentum, unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
-            bn.running_mean[c] = (float)((1.0 - m) * (double)bn.running_mean[c] + m * mean);
-            bn.running_var[c] = (float)((1.0 - m) * (double)bn.running_var[c] + m * unb);
+            bn.running_mean[c] = (float)((1.0 - m) * (double)rm_c + m * mean);
+            bn.running_var[c] = (float)((1.0 - m) * (double)rv_c + m * unb);
         }
     } else {
-        mean = bn.running_mean[c];
-        var = bn.running_var[c];
+        mean = rm_c;
+        var = rv_c;
     }
-    const double rstd = 1.0 / sqrt(var + (double)bn.eps), scale = (double)bn.gamma[c] * rstd;
+    const double rstd = 1.0 / sqrt(var + (double)bn.eps), scale = (double)g_c * rstd;
     ss[c] = (float)scale;
-    ss[C + c] = (float)((double)bn.beta[c] - mean * scale);
+    ss[C + c] = (float)((double)b_c - mean * scale);
     mr[c] = (float)mean;
     mr[C + c] = (float)rstd;
 }
@@ -146,12 +172,20 @@ __global__ __launch_bounds__(1024) void k_bnact_bwd_stats(const float *__restric
     const long r0 = (long)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
     const float sc = ss[c], sf = ss[C + c], mu = mr[c], rs = mr[C + c];
     double s1 = 0.0, s2 = 0.0;
-#pragma unroll 8
-    for (long row = r0 + r; row < r1; row += R) {
-        const float xv = x[row * C + c];
-        const float dz = da[row * C + c] * act_grad(act, fmaf(xv, sc, sf));
-        s1 += dz;
-        s2 += (double)dz * (double)((xv - mu) * rs);
+    for (long rb = r0 + r; rb < r1; rb += 8L * R) {              // batches of eight (clamped, unconditional) row loads
+        float xv[8], dv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long o = min(rb + (long)u * R, r1 - 1) * C + c;
+            xv[u] = x[o]; dv[u] = da[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (rb + (long)u * R < r1) {
+                const float dz = dv[u] * act_grad(act, fmaf(xv[u], sc, sf));
+                s1 += dz;
+                s2 += (double)dz * (double)((xv[u] - mu) * rs);
+            }
     }
     red[r * C + c] = s1; red[(R + r) * C + c] = s2;
     __syncthreads();
@@ -290,6 +324,202 @@ __global__ __launch_bounds__(256) void k_dwg_bwd_dx(const float *__restrict__ dy
         }
     }
 }
+// C % 4 == 0 forms of the two gathers, templated on the kernel size: every tap's float4 is loaded UNCONDITIONALLY from clamped
+// coordinates and an out-of-range tap is zeroed by a select afterwards.  The guarded form above (a `continue` per tap) compiles
+// to a branch and a wait around every load -- up to 25 dependent L2 round trips per output, 20-40 us for tensors of a few MB;
+// this way a thread has all k*k loads in flight at once.  Same products in the same (kh, kw) order: the same bits.
+template <int K>
+__global__ __launch_bounds__(256) void k_dwg_fwd4(const float *__restrict__ x, const float *__restrict__ w, DwG g,
+                                                  float *__restrict__ y) {
+    extern __shared__ __align__(16) float wl[];      // [tap][C]
+    constexpr int KK = K * K, PAD = K / 2;
+    const int c4n = g.C >> 2;
+    for (int i = threadIdx.x; i < g.C * KK; i += 256) wl[(i % KK) * g.C + i / KK] = w[i];
+    __syncthreads();
+    const uint32_t n = (uint32_t)g.B * g.Ho * g.Wo * c4n;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        uint32_t p = i / (uint32_t)c4n;
+        const int cq = (int)(i - p * c4n);
+        uint32_t q = p / (uint32_t)g.Wo;
+        const int wo = (int)(p - q * g.Wo);
+        const int b = (int)(q / (uint32_t)g.Ho);
+        const int ho = (int)(q - (uint32_t)b * g.Ho);
+        const float *xb = x + (size_t)b * g.H * g.W * g.C + 4 * cq;
+        float4 xv[KK];
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int hi = min(max(ho * g.s + kh - PAD, 0), g.H - 1);
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int wi = min(max(wo * g.s + kw - PAD, 0), g.W - 1);
+                xv[kh * K + kw] = *reinterpret_cast<const float4 *>(xb + (uint32_t)((hi * g.W + wi) * g.C));
+            }
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int hi = ho * g.s + kh - PAD;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int wi = wo * g.s + kw - PAD;
+                if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(wl + (kh * K + kw) * g.C + 4 * cq);
+                    const float4 v = xv[kh * K + kw];
+                    acc.x = fmaf(v.x, wv.x, acc.x); acc.y = fmaf(v.y, wv.y, acc.y);
+                    acc.z = fmaf(v.z, wv.z, acc.z); acc.w = fmaf(v.w, wv.w, acc.w);
+                }
+            }
+        }
+        *reinterpret_cast<float4 *>(y + (size_t)p * g.C + 4 * cq) = acc;
+    }
+}
+template <int K>
+__global__ __launch_bounds__(256) void k_dwg_bwd_dx4(const float *__restrict__ dy, const float *__restrict__ w, DwG g,
+                                                     float *__restrict__ dx) {
+    extern __shared__ __align__(16) float wl[];      // [tap][C]
+    constexpr int KK = K * K, PAD = K / 2;
+    const int c4n = g.C >> 2;
+    for (int i = threadIdx.x; i < g.C * KK; i += 256) wl[(i % KK) * g.C + i / KK] = w[i];
+    __syncthreads();
+    const uint32_t n = (uint32_t)g.B * g.H * g.W * c4n;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        uint32_t p = i / (uint32_t)c4n;
+        const int cq = (int)(i - p * c4n);
+        uint32_t q = p / (uint32_t)g.W;
+        const int wi = (int)(p - q * g.W);
+        const int b = (int)(q / (uint32_t)g.H);
+        const int hi = (int)(q - (uint32_t)b * g.H);
+        const float *db = dy + (size_t)b * g.Ho * g.Wo * g.C + 4 * cq;
+        float4 dv[KK];
+        uint32_t ok = 0;
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int th = hi + PAD - kh, ho = g.s == 2 ? th >> 1 : th;      // stride 1 or 2 (host check)
+            const bool okh = th >= 0 && (g.s == 1 || !(th & 1)) && ho < g.Ho;
+            const int hoc = min(max(ho, 0), g.Ho - 1);
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int tw = wi + PAD - kw, wo = g.s == 2 ? tw >> 1 : tw;
+                const bool okw = tw >= 0 && (g.s == 1 || !(tw & 1)) && wo < g.Wo;
+                const int woc = min(max(wo, 0), g.Wo - 1);
+                dv[kh * K + kw] = *reinterpret_cast<const float4 *>(db + (uint32_t)((hoc * g.Wo + woc) * g.C));
+                ok |= (uint32_t)(okh && okw) << (kh * K + kw);
+            }
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < KK; ++t)
+            if (ok & (1u << t)) {
+                const float4 wv = *reinterpret_cast<const float4 *>(wl + t * g.C + 4 * cq);
+                acc.x = fmaf(dv[t].x, wv.x, acc.x); acc.y = fmaf(dv[t].y, wv.y, acc.y);
+                acc.z = fmaf(dv[t].z, wv.z, acc.z); acc.w = fmaf(dv[t].w, wv.w, acc.w);
+            }
+        *reinterpret_cast<float4 *>(dx + (size_t)p * g.C + 4 * cq) = acc;
+    }
+}
+// ---- small feature maps (H*W <= 128 pixels: the 5x19, 3x10 and 2x5 stages of MobileNetV3 at 40 x 151 inputs, 9 of its 11 depthwise
+// layers).  There every output needs most of its image, so the gather kernels above re-fetch each input float4 up to k*k times
+// through L1 (a 5x5 layer on 2x5 maps moved 147 MB for a 5.9 MB tensor: 37 us).  Here a workgroup stages NIMG whole images x a
+// chunk of <= 64 channels in LDS once (coalesced float4 rows, all loads in flight) and gathers from LDS.
+struct DwL { int nimg, CC4, G_c; };        // images per workgroup, float4 channels per chunk, channel chunks
+// stage rows [0, npix) of images b0 .. b0+nimg-1, channel float4s [c0q, c0q+CC4) of a (B, npix, C) tensor into slab[img][pix][CC4]
+__device__ __forceinline__ void dwl_stage(const float *__restrict__ src, int B, int b0, int nimg, int npix, int C, int c0q, int CC4,
+                                          float4 *slab) {
+    const int C4 = C >> 2, per = npix * CC4, n = nimg * per;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + 256 * u, n - 1), img = i / per, rem = i - img * per, pix = rem / CC4, cq = rem - pix * CC4;
+            const int b = min(b0 + img, B - 1), c4 = min(c0q + cq, C4 - 1);
+            v[u] = *reinterpret_cast<const float4 *>(src + ((size_t)b * npix + pix) * C + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 256 * u < n) slab[i0 + 256 * u] = v[u];
+    }
+}
+// BWD = false: y = conv(x);  BWD = true: dx = conv^T(dy).  `in` has (Hi, Wi) pixels per image, `out` (Hq, Wq).
+template <int K, bool BWD>
+__global__ __launch_bounds__(256) void k_dwl_conv(const float *__restrict__ in, const float *__restrict__ w, DwG g, DwL l,
+                                                  float *__restrict__ out) {
+    extern __shared__ __align__(16) float4 dwl_lds[];          // wl4 [KK][CC4] | slab [nimg][Hi*Wi][CC4]
+    constexpr int KK = K * K, PAD = K / 2;
+    const int Hi = BWD ? g.Ho : g.H, Wi = BWD ? g.Wo : g.W, Hq = BWD ? g.H : g.Ho, Wq = BWD ? g.W : g.Wo;
+    const int gc = blockIdx.x % l.G_c, b0 = (blockIdx.x / l.G_c) * l.nimg, c0q = gc * l.CC4, C4 = g.C >> 2;
+    float4 *wl4 = dwl_lds, *slab = dwl_lds + KK * l.CC4;
+    for (int i = threadIdx.x; i < KK * l.CC4 * 4; i += 256) {          // w (C,1,k,k) -> wl4[tap][cq].{x,y,z,w}
+        const int e = i & 3, cq = (i >> 2) % l.CC4, t = (i >> 2) / l.CC4, c = 4 * (c0q + cq) + e;
+        reinterpret_cast<float *>(wl4)[i] = c < g.C ? w[(size_t)c * KK + t] : 0.f;
+    }
+    const int nimg = min(l.nimg, g.B - b0);
+    dwl_stage(in, g.B, b0, nimg, Hi * Wi, g.C, c0q, l.CC4, slab);
+    __syncthreads();
+    const int perq = Hq * Wq * l.CC4, n = nimg * perq;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int img = i / perq, rem = i - img * perq, pix = rem / l.CC4, cq = rem - pix * l.CC4;
+        const int ho = pix / Wq, wo = pix - ho * Wq;
+        if (c0q + cq >= C4) continue;
+        const float4 *sl = slab + (size_t)img * Hi * Wi * l.CC4 + cq;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            int hi;
+            bool okh;
+            if (BWD) { const int th = ho + PAD - kh; hi = g.s == 2 ? th >> 1 : th; okh = th >= 0 && (g.s == 1 || !(th & 1)) && hi < Hi; }
+            else { hi = ho * g.s + kh - PAD; okh = hi >= 0 && hi < Hi; }
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                int wi;
+                bool okw;
+                if (BWD) { const int tw = wo + PAD - kw; wi = g.s == 2 ? tw >> 1 : tw; okw = tw >= 0 && (g.s == 1 || !(tw & 1)) && wi < Wi; }
+                else { wi = wo * g.s + kw - PAD; okw = wi >= 0 && wi < Wi; }
+                if (okh && okw) {
+                    const float4 v = sl[(hi * Wi + wi) * l.CC4], wv = wl4[(kh * K + kw) * l.CC4 + cq];
+                    acc.x = fmaf(v.x, wv.x, acc.x); acc.y = fmaf(v.y, wv.y, acc.y);
+                    acc.z = fmaf(v.z, wv.z, acc.z); acc.w = fmaf(v.w, wv.w, acc.w);
+                }
+            }
+        }
+        *reinterpret_cast<float4 *>(out + ((size_t)(b0 + img) * Hq * Wq + pix) * g.C + 4 * (c0q + cq)) = acc;
+    }
+}
+// weight gradient: x and dy slabs of the workgroup's images in LDS, thread = (tap, channel float4) summing over (image, output
+// pixel) in fixed order; part[image group][C*k*k], summed over the groups by the column-sum launch that follows.
+template <int K>
+__global__ __launch_bounds__(256) void k_dwl_dw(const float *__restrict__ x, const float *__restrict__ dy, DwG g, DwL l,
+                                                float *__restrict__ part) {
+    extern __shared__ __align__(16) float4 dwl_lds[];          // xs [nimg][H*W][CC4] | ds [nimg][Ho*Wo][CC4]
+    constexpr int KK = K * K, PAD = K / 2;
+    const int gc = blockIdx.x % l.G_c, grp = blockIdx.x / l.G_c, b0 = grp * l.nimg, c0q = gc * l.CC4, C4 = g.C >> 2;
+    const int nimg = min(l.nimg, g.B - b0), HW = g.H * g.W, HoWo = g.Ho * g.Wo;
+    float4 *xs = dwl_lds, *ds = dwl_lds + (size_t)l.nimg * HW * l.CC4;
+    dwl_stage(x, g.B, b0, nimg, HW, g.C, c0q, l.CC4, xs);
+    dwl_stage(dy, g.B, b0, nimg, HoWo, g.C, c0q, l.CC4, ds);
+    __syncthreads();
+    for (int i = threadIdx.x; i < KK * l.CC4; i += 256) {
+        const int t = i / l.CC4, cq = i - t * l.CC4, kh = t / K, kw = t - kh * K;
+        if (c0q + cq >= C4) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int img = 0; img < nimg; ++img) {
+            const float4 *xi = xs + (size_t)img * HW * l.CC4 + cq, *di = ds + (size_t)img * HoWo * l.CC4 + cq;
+            for (int ho = 0; ho < g.Ho; ++ho) {
+                const int hi = ho * g.s + kh - PAD;
+                if (hi < 0 || hi >= g.H) continue;
+                for (int wo = 0; wo < g.Wo; ++wo) {
+                    const int wi = wo * g.s + kw - PAD;
+                    if (wi < 0 || wi >= g.W) continue;
+                    const float4 d = di[(ho * g.Wo + wo) * l.CC4], v = xi[(hi * g.W + wi) * l.CC4];
+                    acc.x = fmaf(d.x, v.x, acc.x); acc.y = fmaf(d.y, v.y, acc.y);
+                    acc.z = fmaf(d.z, v.z, acc.z); acc.w = fmaf(d.w, v.w, acc.w);
+                }
+            }
+        }
+        float *o = part + (size_t)grp * g.C * KK + (size_t)(4 * (c0q + cq)) * KK + t;
+        o[0] = acc.x; o[KK] = acc.y; o[2 * KK] = acc.z; o[3 * KK] = acc.w;
+    }
+}
+
 // dw[c][tap] partials over a chunk of output pixels (thread layout of k_colstats): part[chunk][C*k*k]
 __global__ __launch_bounds__(1024) void k_dwg_bwd_dw(const float *__restrict__ x, const float *__restrict__ dy, DwG g, int R,
                                                      long px_per_chunk, float *__restrict__ part) {
@@ -334,17 +564,21 @@ __global__ __launch_bounds__(1024) void k_dwg_bwd_dw(const float *__restrict__ x
 }
 
 // the same for C % 4 == 0: a thread owns FOUR channels (float4 loads) and rows r, r+R, ...: block = (C/4)*R <= 512 threads.
-// Up to NCHUNK_DW blocks (four resident per CU); 32-bit pixel arithmetic; the row lanes of a block are summed through LDS
-// T taps at a time (T * R * C floats <= 48 KB), each (tap, channel quad) by one thread in fixed order.
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_dwg_bwd_dw4(const float *__restrict__ x, const float *__restrict__ dy, DwG g, int R,
-                                                      uint32_t px_per_chunk, int T, float *__restrict__ part) {
+// Up to NCHUNK_DW blocks; 32-bit pixel arithmetic; the row lanes of a block are summed through LDS T taps at a time
+// (T * R * C floats <= 48 KB), each (tap, channel quad) by one thread in fixed order.  Templated on the kernel size; the k*k
+// input float4s of a pixel are loaded unconditionally from clamped coordinates (a guarded tap load is a branch + a wait: 25
+// dependent round trips per pixel in the first form) and out-of-range taps are skipped by the accumulation only.
+template <int K>
+__global__ __launch_bounds__(512) void k_dwg_bwd_dw4(const float *__restrict__ x, const float *__restrict__ dy, DwG g, int R,
+                                                     uint32_t px_per_chunk, int T, float *__restrict__ part) {
     extern __shared__ __align__(16) float redf[];           // [T][R][C]
-    const int C4 = g.C / 4, cq = threadIdx.x % C4, r = threadIdx.x / C4, pad = g.k / 2, kk = g.k * g.k;
+    constexpr int KK = K * K, PAD = K / 2;
+    const int C4 = g.C / 4, cq = threadIdx.x % C4, r = threadIdx.x / C4;
     const uint32_t P = (uint32_t)g.B * g.Ho * g.Wo;
     const uint32_t p0 = blockIdx.x * px_per_chunk, p1 = min(P, p0 + px_per_chunk);
-    float ax[25], ay[25], az[25], aw[25];       // plain arrays: an array of HIP float4 structs is not promoted to registers
+    float ax[KK], ay[KK], az[KK], aw[KK];       // plain arrays: an array of HIP float4 structs is not promoted to registers
 #pragma unroll
-    for (int t = 0; t < 25; ++t) { ax[t] = 0.f; ay[t] = 0.f; az[t] = 0.f; aw[t] = 0.f; }
+    for (int t = 0; t < KK; ++t) { ax[t] = 0.f; ay[t] = 0.f; az[t] = 0.f; aw[t] = 0.f; }
     for (uint32_t p = p0 + r; p < p1; p += R) {
         const uint32_t q = p / (uint32_t)g.Wo;
         const int wo = (int)(p - q * g.Wo);
@@ -353,43 +587,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float4 d = *reinterpret_cast<const float4 *>(dy + (size_t)p * g.C + 4 * cq);
         const float *xb = x + (size_t)b * g.H * g.W * g.C + 4 * cq;
 #pragma unroll
-        for (int kh = 0; kh < 5; ++kh) {
-            const int hi = ho * g.s + kh - pad;
-            if (kh >= g.k || hi < 0 || hi >= g.H) continue;
+        for (int kh = 0; kh < K; ++kh) {
+            const int hi = ho * g.s + kh - PAD, hic = min(max(hi, 0), g.H - 1);
+            float4 xv[K];
 #pragma unroll
-            for (int kw = 0; kw < 5; ++kw) {
-                const int wi = wo * g.s + kw - pad;
-                if (kw >= g.k || wi < 0 || wi >= g.W) continue;
-                const float4 xv = *reinterpret_cast<const float4 *>(xb + (uint32_t)((hi * g.W + wi) * g.C));
-                const int t = kh * 5 + kw;
-                ax[t] = fmaf(d.x, xv.x, ax[t]); ay[t] = fmaf(d.y, xv.y, ay[t]);
-                az[t] = fmaf(d.z, xv.z, az[t]); aw[t] = fmaf(d.w, xv.w, aw[t]);
+            for (int kw = 0; kw < K; ++kw) {
+                const int wic = min(max(wo * g.s + kw - PAD, 0), g.W - 1);
+                xv[kw] = *reinterpret_cast<const float4 *>(xb + (uint32_t)((hic * g.W + wic) * g.C));
+            }
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int wi = wo * g.s + kw - PAD;
+                if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
+                    const int t = kh * K + kw;
+                    ax[t] = fmaf(d.x, xv[kw].x, ax[t]); ay[t] = fmaf(d.y, xv[kw].y, ay[t]);
+                    az[t] = fmaf(d.z, xv[kw].z, az[t]); aw[t] = fmaf(d.w, xv[kw].w, aw[t]);
+                }
             }
         }
     }
     int slot = 0, base = 0;                     // taps base .. base + slot - 1 (in (kh, kw) order) sit in LDS
-    float *outp = part + (size_t)blockIdx.x * g.C * kk + (size_t)(4 * cq) * kk;
+    float *outp = part + (size_t)blockIdx.x * g.C * KK + (size_t)(4 * cq) * KK;
 #pragma unroll
-    for (int a5 = 0; a5 < 25; ++a5) {
-        const int kh = a5 / 5, kw = a5 % 5;     // compile-time: the accumulators are read by constant index
-        if (kh < g.k && kw < g.k) {             // uniform
-            *reinterpret_cast<float4 *>(redf + ((size_t)slot * R + r) * g.C + 4 * cq) = make_float4(ax[a5], ay[a5], az[a5], aw[a5]);
-            ++slot;
-            if (slot == T || (kh == g.k - 1 && kw == g.k - 1)) {
-                __syncthreads();
-                for (int sl = r; sl < slot; sl += R) {
-                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int i = 0; i < R; ++i) {
-                        const float4 u = *reinterpret_cast<const float4 *>(redf + ((size_t)sl * R + i) * g.C + 4 * cq);
-                        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-                    }
-                    float *o = outp + base + sl;
-                    o[0] = t.x; o[kk] = t.y; o[2 * kk] = t.z; o[3 * kk] = t.w;
+    for (int t5 = 0; t5 < KK; ++t5) {           // compile-time: the accumulators are read by constant index
+        *reinterpret_cast<float4 *>(redf + ((size_t)slot * R + r) * g.C + 4 * cq) = make_float4(ax[t5], ay[t5], az[t5], aw[t5]);
+        ++slot;
+        if (slot == T || t5 == KK - 1) {
+            __syncthreads();
+            for (int sl = r; sl < slot; sl += R) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = 0; i < R; ++i) {
+                    const float4 u = *reinterpret_cast<const float4 *>(redf + ((size_t)sl * R + i) * g.C + 4 * cq);
+                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
                 }
-                __syncthreads();
-                base += slot;
-                slot = 0;
+                float *o = outp + base + sl;
+                o[0] = t.x; o[KK] = t.y; o[2 * KK] = t.z; o[3 * KK] = t.w;
             }
+            __syncthreads();
+            base += slot;
+            slot = 0;
         }
     }
 }
@@ -524,7 +760,6 @@ inline bool vec4_ok(long n, int C, std::initializer_list<const void *> ptrs) {
 }
 inline int rows_r(int C) { return std::max(1, 1024 / C); }                       // row lanes R of a C*R-thread block
 inline int chunks_for(long M, int C) { return (int)std::max<long>(1, std::min<long>(NCHUNK, M / (4L * rows_r(C)))); }
-
 }  // namespace
 
 // scratch of one layer call: chunk partials (BatchNorm: 2C per chunk, depthwise weight gradient: up to 25C per chunk) + 2C sums
@@ -540,7 +775,8 @@ extern "C" int ww_bn_act_fwd(ww_ctx *ctx, const float *x, long M, int C, const w
     ww_prof_scope ps_(ctx, WW_K_NHWC, st);
     float *part = (float *)scratch;
     WW_REQUIRE(C <= 1024, WW_E_UNSUPPORTED, "ww_bn_act_fwd: C=%d > 1024", C);
-    const int chunks = chunks_for(M, C), R = rows_r(C);
+    const int R = rows_r(C);
+    const int chunks = chunks_for(M, C);
     if (bn->training) {
         hipLaunchKernelGGL(k_colstats, dim3(chunks), dim3(C * R), (size_t)2 * R * C * sizeof(double), st, x, M, C, R,
                            (M + chunks - 1) / chunks, part);
@@ -565,7 +801,8 @@ extern "C" int ww_bn_act_bwd(ww_ctx *ctx, const float *x, const float *da, long 
     ww_prof_scope ps_(ctx, WW_K_NHWC, st);
     float *part = (float *)scratch, *sums = part + (size_t)NCHUNK * 2 * C;
     WW_REQUIRE(C <= 1024, WW_E_UNSUPPORTED, "ww_bn_act_bwd: C=%d > 1024", C);
-    const int chunks = chunks_for(M, C), R = rows_r(C);
+    const int R = rows_r(C);
+    const int chunks = chunks_for(M, C);
     hipLaunchKernelGGL(k_bnact_bwd_stats, dim3(chunks), dim3(C * R), (size_t)2 * R * C * sizeof(double), st, x, da, ss, mr, M, C, R,
                        act, (M + chunks - 1) / chunks, part);
     WW_LAUNCH_CHECK();
@@ -580,6 +817,20 @@ extern "C" int ww_bn_act_bwd(ww_ctx *ctx, const float *x, const float *da, long 
     return WW_OK;
 }
 
+// LDS plan of the small-feature-map depthwise kernels: usable when C % 4 == 0 and an image has <= 128 input pixels; images per
+// workgroup so that the slabs stay under `budget` bytes and (for the weight gradient) the image groups fit the partial slab
+static bool dwl_plan(const DwG &g, size_t bytes_per_img_cc4, size_t budget, DwL *l) {
+    if ((g.C & 3) || g.H * g.W > 128) return false;
+    const int C4 = g.C / 4;
+    l->G_c = (C4 + 15) / 16;
+    l->CC4 = (C4 + l->G_c - 1) / l->G_c;
+    const size_t per_img = bytes_per_img_cc4 * l->CC4;
+    if (per_img > budget) return false;
+    int nimg = (int)std::min<size_t>(8, budget / per_img);
+    while (nimg > 1 && (long)((g.B + nimg - 1) / nimg) * l->G_c < 512) --nimg;      // keep the device covered
+    l->nimg = nimg;
+    return true;
+}
 static int make_dwg(const char *who, int B, int H, int W, int C, int k, int s, DwG *g) {
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, WW_E_INVALID, "%s: bad shape", who);
     WW_REQUIRE((k == 3 || k == 5) && (s == 1 || s == 2), WW_E_UNSUPPORTED, "%s: kernel %d stride %d not implemented", who, k, s);
@@ -598,7 +849,19 @@ extern "C" int ww_dwconv_nhwc_fwd(ww_ctx *ctx, const float *x, const float *w, i
     const size_t wbytes = (size_t)C * k * k * sizeof(float);
     WW_REQUIRE(wbytes <= 64 * 1024, WW_E_UNSUPPORTED, "ww_dwconv_nhwc_fwd: C*k*k = %d weights do not fit the LDS cache", C * k * k);
     WW_REQUIRE((long)B * H * W * C < (1L << 31), WW_E_UNSUPPORTED, "ww_dwconv_nhwc_fwd: tensor too large for 32-bit indices");
-    hipLaunchKernelGGL(k_dwg_fwd, dim3(egrid((long)B * g.Ho * g.Wo * ((C + 3) / 4))), dim3(256), wbytes, (hipStream_t)stream, x, w, g, y);
+    const dim3 grid(egrid((long)B * g.Ho * g.Wo * ((C + 3) / 4)));
+    DwL l;
+    if ((((uintptr_t)x | (uintptr_t)y) & 15) == 0 && dwl_plan(g, (size_t)H * W * 16, 40 * 1024, &l)) {
+        const dim3 lg((unsigned)((B + l.nimg - 1) / l.nimg) * l.G_c);
+        const size_t lds = ((size_t)k * k * l.CC4 + (size_t)l.nimg * H * W * l.CC4) * 16;
+        if (k == 3) hipLaunchKernelGGL((k_dwl_conv<3, false>), lg, dim3(256), lds, (hipStream_t)stream, x, w, g, l, y);
+        else hipLaunchKernelGGL((k_dwl_conv<5, false>), lg, dim3(256), lds, (hipStream_t)stream, x, w, g, l, y);
+    } else if ((C & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+        if (k == 3) hipLaunchKernelGGL(k_dwg_fwd4<3>, grid, dim3(256), wbytes, (hipStream_t)stream, x, w, g, y);
+        else hipLaunchKernelGGL(k_dwg_fwd4<5>, grid, dim3(256), wbytes, (hipStream_t)stream, x, w, g, y);
+    } else {
+        hipLaunchKernelGGL(k_dwg_fwd, grid, dim3(256), wbytes, (hipStream_t)stream, x, w, g, y);
+    }
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -614,20 +877,43 @@ extern "C" int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, c
         const size_t wbytes = (size_t)C * k * k * sizeof(float);
         WW_REQUIRE(wbytes <= 64 * 1024, WW_E_UNSUPPORTED, "ww_dwconv_nhwc_bwd: C*k*k = %d weights do not fit the LDS cache", C * k * k);
         WW_REQUIRE((long)B * H * W * C < (1L << 31), WW_E_UNSUPPORTED, "ww_dwconv_nhwc_bwd: tensor too large for 32-bit indices");
-        hipLaunchKernelGGL(k_dwg_bwd_dx, dim3(egrid((long)B * H * W * ((C + 3) / 4))), dim3(256), wbytes, st, dy, w, g, dx);
+        const dim3 grid(egrid((long)B * H * W * ((C + 3) / 4)));
+        DwL l;
+        if ((((uintptr_t)dy | (uintptr_t)dx) & 15) == 0 && dwl_plan(g, (size_t)g.Ho * g.Wo * 16, 40 * 1024, &l)) {
+            const dim3 lg((unsigned)((B + l.nimg - 1) / l.nimg) * l.G_c);
+            const size_t lds = ((size_t)k * k * l.CC4 + (size_t)l.nimg * g.Ho * g.Wo * l.CC4) * 16;
+            if (k == 3) hipLaunchKernelGGL((k_dwl_conv<3, true>), lg, dim3(256), lds, st, dy, w, g, l, dx);
+            else hipLaunchKernelGGL((k_dwl_conv<5, true>), lg, dim3(256), lds, st, dy, w, g, l, dx);
+        } else if ((C & 3) == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
+            if (k == 3) hipLaunchKernelGGL(k_dwg_bwd_dx4<3>, grid, dim3(256), wbytes, st, dy, w, g, dx);
+            else hipLaunchKernelGGL(k_dwg_bwd_dx4<5>, grid, dim3(256), wbytes, st, dy, w, g, dx);
+        } else {
+            hipLaunchKernelGGL(k_dwg_bwd_dx, grid, dim3(256), wbytes, st, dy, w, g, dx);
+        }
         WW_LAUNCH_CHECK();
     }
     WW_REQUIRE(C <= 1024, WW_E_UNSUPPORTED, "ww_dwconv_nhwc_bwd: C=%d > 1024", C);
     const long P = (long)B * g.Ho * g.Wo;
     float *part = (float *)scratch;
     int chunks;
-    if ((C & 3) == 0) {
+    DwL l;
+    if ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && dwl_plan(g, (size_t)(H * W + g.Ho * g.Wo) * 16, 56 * 1024, &l) &&
+        (B + l.nimg - 1) / l.nimg <= NCHUNK_DW) {
+        chunks = (B + l.nimg - 1) / l.nimg;
+        const size_t lds = (size_t)l.nimg * (H * W + g.Ho * g.Wo) * l.CC4 * 16;
+        if (k == 3) hipLaunchKernelGGL(k_dwl_dw<3>, dim3((unsigned)chunks * l.G_c), dim3(256), lds, st, x, dy, g, l, part);
+        else hipLaunchKernelGGL(k_dwl_dw<5>, dim3((unsigned)chunks * l.G_c), dim3(256), lds, st, x, dy, g, l, part);
+    } else if ((C & 3) == 0) {
         const int R4 = std::max(1, std::min(32, 512 / (C / 4)));      // <= 512 threads: 100 accumulator registers per thread
         WW_REQUIRE(P < (1L << 31) && (long)H * W * C < (1L << 31), WW_E_UNSUPPORTED, "ww_dwconv_nhwc_bwd: tensor too large for 32-bit pixel indices");
         chunks = (int)std::max<long>(1, std::min<long>(NCHUNK_DW, P / (4L * R4)));
         const int T = std::max(1, std::min(k * k, 12288 / (R4 * C)));   // taps per LDS round: <= 48 KB
-        hipLaunchKernelGGL(k_dwg_bwd_dw4, dim3(chunks), dim3((C / 4) * R4), (size_t)T * R4 * C * sizeof(float), st, x, dy, g, R4,
-                           (uint32_t)((P + chunks - 1) / chunks), T, part);
+        if (k == 3)
+            hipLaunchKernelGGL(k_dwg_bwd_dw4<3>, dim3(chunks), dim3((C / 4) * R4), (size_t)T * R4 * C * sizeof(float), st, x, dy, g, R4,
+                               (uint32_t)((P + chunks - 1) / chunks), T, part);
+        else
+            hipLaunchKernelGGL(k_dwg_bwd_dw4<5>, dim3(chunks), dim3((C / 4) * R4), (size_t)T * R4 * C * sizeof(float), st, x, dy, g, R4,
+                               (uint32_t)((P + chunks - 1) / chunks), T, part);
     } else {
         const int R = rows_r(C);
         chunks = chunks_for(P, C);

@@ -172,22 +172,36 @@ class _ConvBNActFn(torch.autograd.Function):
 
 
 class _SEFn(torch.autograd.Function):
-    """Squeeze-excitation as one node: pool -> FC+ReLU -> FC+Hardsigmoid -> scale; the two uses of x meet in ONE backward
-    kernel (dx = dy*gate + dpool/HW) instead of two gradient tensors and an add."""
+    """Squeeze-excitation as one node and THREE launches (``ww_se_fwd`` / ``ww_se_bwd``: a workgroup owns whole images, so the
+    pool, both FCs, the gate and the scaling are one kernel, and dx = dy*gate + dpool/HW another; fp32 FMA in every matrix
+    mode -- the FCs are B x C x C/4).  Shapes outside the kernels' limits compose the block from the layer library's pieces
+    (pool -> matrix-core FC+ReLU -> FC+Hardsigmoid -> scale)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, mode):
         B, H, W, Cn = x.shape
         x3 = x.reshape(B, H * W, Cn)
-        s = nat.pool_hw_fwd(x3)
-        h, pre1 = nat.linear_mfma_fwd(s, w1.reshape(w1.shape[0], -1), b1, act=nat.LIN_RELU, mode=mode, want_pre=True)
-        g, pre2 = nat.linear_mfma_fwd(h, w2.reshape(w2.shape[0], -1), b2, act=nat.LIN_HARDSIGMOID, mode=mode, want_pre=True)
-        ctx.save_for_backward(x3, s, h, pre1, pre2, g, w1, w2)
+        w1m, w2m = w1.reshape(w1.shape[0], -1), w2.reshape(w2.shape[0], -1)
         ctx.mode, ctx.xshape = mode, x.shape
+        ctx.fused = nat.se_supported(Cn, w1m.shape[0], x3, w1m, w2m)
+        if ctx.fused:
+            y, s, pre1, pre2 = nat.se_fwd(x3.contiguous(), w1m, b1, w2m, b2)
+            ctx.save_for_backward(x3, s, pre1, pre2, w1, w2)
+            return y.reshape(x.shape)
+        s = nat.pool_hw_fwd(x3)
+        h, pre1 = nat.linear_mfma_fwd(s, w1m, b1, act=nat.LIN_RELU, mode=mode, want_pre=True)
+        g, pre2 = nat.linear_mfma_fwd(h, w2m, b2, act=nat.LIN_HARDSIGMOID, mode=mode, want_pre=True)
+        ctx.save_for_backward(x3, s, h, pre1, pre2, g, w1, w2)
         return nat.scale_bc_fwd(x3, g).reshape(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.fused:
+            x3, s, pre1, pre2, w1, w2 = ctx.saved_tensors
+            dy3 = dy.contiguous().reshape(x3.shape)
+            dx, dw1, db1, dw2, db2 = nat.se_bwd(x3.contiguous(), dy3, s, pre1, pre2, w1.reshape(w1.shape[0], -1),
+                                                w2.reshape(w2.shape[0], -1))
+            return dx.reshape(ctx.xshape), dw1.reshape(w1.shape), db1, dw2.reshape(w2.shape), db2, None
         x3, s, h, pre1, pre2, g, w1, w2 = ctx.saved_tensors
         B, HW, Cn = x3.shape
         dy3 = dy.contiguous().reshape(B, HW, Cn)
