@@ -331,6 +331,18 @@ int ww_bn_act_fwd(ww_ctx *ctx, const float *x, long M, int C, const ww_bn_t *bn,
                   void *scratch, ww_stream_t stream);
 int ww_bn_act_bwd(ww_ctx *ctx, const float *x, const float *da, long M, int C, const float *ss, const float *mr, int act,
                   int training, float *dx, float *dgamma, float *dbeta, void *scratch, ww_stream_t stream);
+/* Conv2dNormActivation in TRAINING mode as the producer + one pass (torchvision's Conv2dNormActivation, the unit MobileNetV3 is
+ * built from -- src/models/architectures.py:91-102): the convolution's own kernel leaves the BatchNorm statistics partials (the
+ * GEMM epilogue's column sums per row tile / the LDS depthwise kernel's per image group), and the BatchNorm(+activation) apply
+ * pass finishes them itself: 2 launches instead of conv + statistics + finish + apply (very tall layers keep the finish launch).
+ * y = pre-BatchNorm output (kept for the backward), a = act(bn(y)); ss / mr as ww_bn_act_fwd.  scratch: ww_nhwc_scratch_bytes(C_out).
+ * ww_conv1x1_bn_act_fwd: x (M,K) rows = pixels (or 3x3 patches of the stem), w (N,K), matrix mode as ww_linear_mfma_fwd.
+ * ww_dwconv_bn_act_fwd: shapes the LDS kernel does not take (more than 128 input pixels per image, C % 4 != 0) and eval mode
+ * run ww_dwconv_nhwc_fwd + ww_bn_act_fwd inside.                                                                      */
+int ww_conv1x1_bn_act_fwd(ww_ctx *ctx, int mode, const float *x, const float *w, int M, int K, int N, const ww_bn_t *bn, int act,
+                          float *y, float *a, float *ss, float *mr, void *scratch, size_t scratch_bytes, ww_stream_t stream);
+int ww_dwconv_bn_act_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int H, int W, int C, int k, int stride,
+                         const ww_bn_t *bn, int act, float *y, float *a, float *ss, float *mr, void *scratch, ww_stream_t stream);
 /* depthwise Conv2d(C, C, k, stride, padding=k/2, groups=C, bias=False): x (B,H,W,C), w (C,1,k,k), k in {3,5}, stride in {1,2} */
 int ww_dwconv_nhwc_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int H, int W, int C, int k, int stride, float *y,
                        ww_stream_t stream);

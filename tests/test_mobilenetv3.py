@@ -86,6 +86,59 @@ def test_se_pieces_and_stem_patches():
     assert torch.equal(cols, ref)
 
 
+@pytest.mark.parametrize("M,K,N,act", [(7680, 40, 240, 1), (2560, 96, 576, 1), (1000, 16, 72, 2), (24320, 72, 24, 0), (300, 9, 16, 1),
+                                        (97280, 16, 16, 0)])
+def test_conv1x1_bn_act_statistics_in_the_gemm_epilogue(M, K, N, act):
+    """ww_conv1x1_bn_act_fwd (GEMM whose epilogue leaves the BatchNorm partials, apply pass that finishes them) against float64
+    torch and against the four-launch composition of the same layer; both the finishing apply pass (few row tiles) and the
+    finish-launch form (many) are covered by the row counts."""
+    from wakeword_trainer_home_amd import _native as nat
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g, dtype=torch.float64)
+    w = torch.randn(N, K, generator=g, dtype=torch.float64) * 0.3
+    gamma, beta = torch.rand(N, generator=g, dtype=torch.float64) + 0.5, torch.randn(N, generator=g, dtype=torch.float64) * 0.3
+    rm, rv = torch.randn(N, generator=g, dtype=torch.float64) * 0.1, torch.rand(N, generator=g, dtype=torch.float64) + 0.5
+    y_ref = x @ w.T
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    a_ref = ACTS[act](Fn.batch_norm(y_ref, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.01, eps=1e-3))
+    f = lambda t: t.float().to(DEV).contiguous()
+    xd, wd, gm, bt = f(x), f(w), f(gamma), f(beta)
+    rm1, rv1, rm2, rv2 = f(rm), f(rv), f(rm), f(rv)
+    y, a, ss, mr = nat.conv1x1_bn_act_fwd(xd, wd, nat.make_bn(gm, bt, rm1, rv1, momentum=0.01, eps=1e-3, training=True), act)
+    assert _rel(y.cpu().double(), y_ref) <= 2e-6 and _rel(a.cpu().double(), a_ref) <= 2e-5
+    assert _rel(rm1.cpu().double(), rm_ref) <= 1e-5 and _rel(rv1.cpu().double(), rv_ref) <= 1e-5
+    y0 = nat.linear_mfma_fwd(xd, wd, None)
+    a0, ss0, mr0 = nat.bn_act_fwd(y0, nat.make_bn(gm, bt, rm2, rv2, momentum=0.01, eps=1e-3, training=True), act, N)
+    assert torch.equal(y, y0)                                   # the same GEMM
+    assert _rel(ss.cpu(), ss0.cpu()) <= 2e-6 and _rel(mr.cpu(), mr0.cpu()) <= 2e-6 and _rel(a.cpu(), a0.cpu()) <= 5e-6
+    rm3, rv3 = f(rm), f(rv)                                     # (make_bn holds raw pointers: the tensors must outlive the call)
+    y2, a2, ss2, _ = nat.conv1x1_bn_act_fwd(xd, wd, nat.make_bn(gm, bt, rm3, rv3, momentum=0.01, eps=1e-3, training=True), act)
+    assert torch.equal(a, a2) and torch.equal(ss, ss2)          # fixed-order sums
+
+
+@pytest.mark.parametrize("B,H,W,C,k,s,act", [(9, 3, 10, 240, 5, 1, 1), (5, 5, 19, 96, 5, 2, 1), (6, 2, 5, 576, 5, 1, 1), (3, 5, 19, 88, 3, 1, 2),
+                                             (2, 10, 38, 72, 3, 2, 2), (2, 7, 9, 10, 3, 1, 2)])
+def test_dwconv_bn_act_statistics_from_the_conv_kernel(B, H, W, C, k, s, act):
+    """ww_dwconv_bn_act_fwd against float64 torch (depthwise conv -> train-mode BatchNorm -> activation); the last two shapes take
+    the composition inside (more than 128 input pixels / C % 4 != 0)."""
+    from wakeword_trainer_home_amd import _native as nat
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(C, 1, k, k, generator=g, dtype=torch.float64) * 0.3
+    gamma, beta = torch.rand(C, generator=g, dtype=torch.float64) + 0.5, torch.randn(C, generator=g, dtype=torch.float64) * 0.3
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    y_ref = Fn.conv2d(x, w, stride=s, padding=k // 2, groups=C)
+    a_ref = ACTS[act](Fn.batch_norm(y_ref, rm, rv, gamma, beta, training=True, momentum=0.01, eps=1e-3))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).float().contiguous().to(DEV)
+    f = lambda t: t.float().to(DEV).contiguous()
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    gm, bt = f(gamma), f(beta)
+    y, a, ss, mr = nat.dwconv_bn_act_fwd(nhwc(x), f(w), k, s, nat.make_bn(gm, bt, rmd, rvd, momentum=0.01, eps=1e-3, training=True), act)
+    assert _rel(y.cpu().double(), nhwc(y_ref).cpu().double()) <= 2e-6
+    assert _rel(a.cpu().double(), nhwc(a_ref).cpu().double()) <= 2e-5
+    assert _rel(rmd.cpu().double(), rm) <= 1e-5 and _rel(rvd.cpu().double(), rv) <= 1e-5
+
+
 @pytest.mark.parametrize("B,HW,C,Cs", [(5, 190, 16, 8), (3, 30, 96, 24), (6, 30, 240, 64), (2, 10, 576, 144), (7, 9, 40, 12),
                                        (130, 6, 24, 8), (41, 4, 32, 8), (129, 10, 576, 144), (34, 3, 1024, 256)])
 def test_se_block_one_launch_forward_two_backward(B, HW, C, Cs):

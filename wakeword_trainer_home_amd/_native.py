@@ -124,6 +124,8 @@ _SIGS = {
     "ww_nhwc_scratch_bytes": (_sz, [_i]),
     "ww_bn_act_fwd": (C.c_int, [_vp, _vp, C.c_long, _i, C.POINTER(BN), _i, _vp, _vp, _vp, _vp, _vp]),
     "ww_bn_act_bwd": (C.c_int, [_vp, _vp, _vp, C.c_long, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ww_conv1x1_bn_act_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, C.POINTER(BN), _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ww_dwconv_bn_act_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(BN), _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ww_dwconv_nhwc_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ww_dwconv_nhwc_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ww_pool_hw_fwd": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -519,6 +521,40 @@ def bn_act_bwd(x, da, ss, mr, act, training, Cn):
         _check(load().ww_bn_act_bwd(ctx(dev), _p(x), _p(da), M, Cn, _p(ss), _p(mr), act, int(training), _p(dx), _p(dgamma),
                                     _p(dbeta), _p(nhwc_scratch(Cn, dev)), _stream(dev)), "ww_bn_act_bwd")
     return dx, dgamma, dbeta
+
+
+def conv1x1_bn_act_fwd(x, w, bn: BN, act, mode=torch.float32):
+    """Training-mode conv (x (M,K) @ w (N,K)^T) + BatchNorm + activation with the statistics taken in the GEMM's epilogue.
+    -> (y pre-BN (M,N), a (M,N), ss (2N), mr (2N))."""
+    dev = _dev(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=dev)
+    a = torch.empty_like(y)
+    ss = torch.empty(2 * N, dtype=torch.float32, device=dev)
+    mr = torch.empty(2 * N, dtype=torch.float32, device=dev)
+    scratch = nhwc_scratch(N, dev)
+    if scratch.numel() < ((M + 63) // 64) * 2 * N:          # very tall and narrow: a scratch of its own size
+        scratch = torch.empty(((M + 63) // 64) * 2 * N, dtype=torch.float32, device=dev)
+    with _guard(dev):
+        _check(load().ww_conv1x1_bn_act_fwd(ctx(dev), act_code(mode), _p(x), _p(w), M, K, N, C.byref(bn), act, _p(y), _p(a), _p(ss),
+                                            _p(mr), _p(scratch), scratch.numel() * 4, _stream(dev)), "ww_conv1x1_bn_act_fwd")
+    return y, a, ss, mr
+
+
+def dwconv_bn_act_fwd(x, w, k, stride, bn: BN, act):
+    """Depthwise conv + BatchNorm + activation -> (y pre-BN, a, ss, mr); the LDS kernel takes the statistics where it applies."""
+    dev = _dev(x, w)
+    B, H, W, Cn = x.shape
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    y = torch.empty((B, Ho, Wo, Cn), dtype=torch.float32, device=dev)
+    a = torch.empty_like(y)
+    ss = torch.empty(2 * Cn, dtype=torch.float32, device=dev)
+    mr = torch.empty(2 * Cn, dtype=torch.float32, device=dev)
+    with _guard(dev):
+        _check(load().ww_dwconv_bn_act_fwd(ctx(dev), _p(x), _p(w), B, H, W, Cn, k, stride, C.byref(bn), act, _p(y), _p(a), _p(ss),
+                                           _p(mr), _p(nhwc_scratch(Cn, dev)), _stream(dev)), "ww_dwconv_bn_act_fwd")
+    return y, a, ss, mr
 
 
 def dwconv_nhwc_fwd(x, w, k, stride):

@@ -10,6 +10,7 @@
 // Dropout after the activation draws from the same Philox stream as the cnn_small classifier dropout (TAG_DROPOUT,
 // 4 features per draw, global sample index), so the oracle reproduces the mask exactly.
 #include "ww_internal.h"
+#include "ww_layers.h"
 #include "ww_act.h"
 #include <algorithm>
 
@@ -40,6 +41,7 @@ struct Epilogue {
     uint64_t sample_offset;
     const ww_step_ctl *ctl;
     int accumulate;             // C += result (second direction of a bidirectional layer adds into dX)
+    float *stat_part;           // nullable: per row tile [sum (N) | sum of squares (N)] of the stored outputs (BatchNorm partials)
 };
 
 __device__ __forceinline__ float lin_act(int act, float z) {
@@ -204,8 +206,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
         }
     }
     C += (long)blockIdx.z * split_stride;
+    float ssum[TN], qsum[TN];       // EPI && e.stat_part: this lane's column sums of what it stores
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
+    ssum[tn] = 0.f; qsum[tn] = 0.f;
     const long col = n0 + 32 * TN * nh + 32 * tn + r;
     if (col >= B.rows) continue;
     const float bias = (EPI && e.bias) ? e.bias[col] : 0.f;
@@ -224,6 +228,29 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
             }
             if (e.accumulate && gridDim.z == 1) v += C[row * ldc + col];
             C[row * ldc + col] = v;
+            if (EPI) { ssum[tn] += v; qsum[tn] = fmaf(v, v, qsum[tn]); }
+        }
+    }
+    // BatchNorm statistics of a 1x1 convolution ride on its epilogue: the tile's column sums (the two half-waves by a shuffle,
+    // the two row waves through LDS, fixed order) -> stat_part[row tile][2N]; the layer needs no pass over y for them
+    if (EPI && e.stat_part) {
+        __syncthreads();                               // every wave is done with the operand tiles
+        float *sred = reinterpret_cast<float *>(lds);  // [4 waves][TN][32][2]
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const float sv = ssum[tn] + __shfl_xor(ssum[tn], 32), qv = qsum[tn] + __shfl_xor(qsum[tn], 32);
+            if (h == 0) { sred[((wv * TN + tn) * 32 + r) * 2] = sv; sred[((wv * TN + tn) * 32 + r) * 2 + 1] = qv; }
+        }
+        __syncthreads();
+        if (tid < RB) {
+            const int nh_ = tid / (32 * TN), tn_ = (tid >> 5) % TN, r_ = tid & 31;
+            const long col = n0 + tid;
+            if (col < B.rows) {
+                const float *lo = sred + (((0 * 2 + nh_) * TN + tn_) * 32 + r_) * 2, *hi = sred + (((1 * 2 + nh_) * TN + tn_) * 32 + r_) * 2;
+                float *o = e.stat_part + (size_t)blockIdx.y * 2 * B.rows;
+                o[col] = lo[0] + hi[0];
+                o[B.rows + col] = lo[1] + hi[1];
+            }
         }
     }
 }
@@ -332,7 +359,7 @@ int make_epilogue(const ww_ctx *ctx, const ww_linear_epi *epi, const float *bias
 // splits > 1: partial products into `part` (splits x rows x cols), then summed in fixed order into C
 template <bool KCA, bool KCB, bool EPI>
 int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, float *C, long ldc, const Epilogue &e,
-                hipStream_t st, int splits = 1, float *part = nullptr) {
+                hipStream_t st, int splits = 1, float *part = nullptr, int *row_tile_out = nullptr) {
     auto aligned = [](const GemmOperand &o, bool kc) {
         const long ld = kc ? o.s_row : o.s_k;
         return (int)(((uintptr_t)o.p & 15) == 0 && (ld & 3) == 0);
@@ -348,6 +375,7 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
     // (the 128 x 128 form pays in bf16 mode only: in fp32 mode its 64 accumulator + 32 prefetch registers cost occupancy, 72 vs 82 TF)
     const int cfg = (mode != WW_ACT_F32 && A.rows >= 128 && B.rows >= 128 && tiles128 >= 256) ? 2 : (A.rows >= 8192 ? 1 : 0);
     const int RA = cfg ? 128 : 64, RBt = cfg == 2 ? 128 : 64;
+    if (row_tile_out) *row_tile_out = RA;
     dim3 grid((B.rows + RBt - 1) / RBt, (A.rows + RA - 1) / RA, nz);
     float *dst = nz > 1 ? part : C;
     const long sstride = (long)A.rows * ldc;
@@ -442,6 +470,32 @@ extern "C" int ww_linear_mfma_fwd(ww_ctx *ctx, int mode, const float *x, const f
     const GemmOperand A{x, K, 1, M}, B{w, K, 1, N};
     ww_prof_scope ps_(ctx, WW_K_LINEAR, (hipStream_t)stream);
     return launch_gemm<true, true, true>(mode, A, B, K, y, N, e, (hipStream_t)stream);
+}
+
+// Conv2dNormActivation with a 1x1 (or im2col'ed) convolution in training mode: y = x W^T on the matrix cores with the BatchNorm
+// statistics partials written by the GEMM's own epilogue, then the BatchNorm(+activation) apply pass that finishes them
+// (ww_bn_act_from_partials): 2 launches (3 for very tall layers) instead of GEMM + statistics + finish + apply.
+extern "C" int ww_conv1x1_bn_act_fwd(ww_ctx *ctx, int mode, const float *x, const float *w, int M, int K, int N, const ww_bn_t *bn,
+                                     int act, float *y, float *a, float *ss, float *mr, void *scratch, size_t scratch_bytes,
+                                     ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && w && bn && bn->gamma && bn->beta && y && a && ss && mr && scratch, WW_E_INVALID, "ww_conv1x1_bn_act_fwd: null argument");
+    int rc = check_dims("ww_conv1x1_bn_act_fwd", mode, M, K, N);
+    if (rc) return rc;
+    WW_REQUIRE(bn->training, WW_E_INVALID, "ww_conv1x1_bn_act_fwd: training-mode statistics only (eval: ww_linear_mfma_fwd + ww_bn_act_fwd)");
+    WW_REQUIRE(scratch_bytes >= (size_t)((M + 63) / 64) * 2 * N * sizeof(float), WW_E_WORKSPACE,
+               "ww_conv1x1_bn_act_fwd: scratch too small for the statistics partials");
+    hipStream_t st = (hipStream_t)stream;
+    Epilogue e = {};
+    e.act = WW_LIN_NONE;
+    e.stat_part = (float *)scratch;
+    const GemmOperand A{x, K, 1, M}, B{w, K, 1, N};
+    int row_tile = 64;
+    {
+        ww_prof_scope ps_(ctx, WW_K_LINEAR, st);
+        if ((rc = launch_gemm<true, true, true>(mode, A, B, K, y, N, e, st, 1, nullptr, &row_tile))) return rc;
+    }
+    ww_prof_scope ps_(ctx, WW_K_NHWC, st);
+    return ww_bn_act_from_partials(ctx, y, M, N, bn, act, a, ss, mr, (const float *)scratch, (M + row_tile - 1) / row_tile, st);
 }
 
 // K splits of the weight-gradient product dW (N x K) = dpre^T x: its contraction runs over the M rows (batch x pixels), which

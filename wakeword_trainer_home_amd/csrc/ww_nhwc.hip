@@ -8,6 +8,7 @@
 //   * squeeze-excitation is pool -> FC+ReLU -> FC+Hardsigmoid -> scale.
 // First version: correctness and the reference's layer semantics; fusion of these passes is the next step.
 #include "ww_internal.h"
+#include "ww_layers.h"
 #include <algorithm>
 
 namespace {
@@ -63,18 +64,19 @@ __global__ __launch_bounds__(1024) void k_colstats(const float *__restrict__ x, 
 __device__ __forceinline__ void chunk_sums(const float *__restrict__ part, int chunks, int C, int col, int p, int c,
                                            double (*sh)[16][64], double &tot0, double &tot1) {
     double s = 0.0, q = 0.0;
-    if (col < C) {
-        float sv[NCHUNK / 16], qv[NCHUNK / 16];
+    if (col < C)
+        for (int base = 0; base < chunks; base += NCHUNK) {      // one batch for the layer library's own <= 256 chunks
+            float sv[NCHUNK / 16], qv[NCHUNK / 16];
 #pragma unroll
-        for (int u = 0; u < NCHUNK / 16; ++u) {
-            const int i = min(p + 16 * u, chunks - 1);          // unconditional loads (a guarded load is a branch + wait each)
-            sv[u] = part[(long)i * 2 * C + col];
-            qv[u] = part[(long)i * 2 * C + C + col];
+            for (int u = 0; u < NCHUNK / 16; ++u) {
+                const int i = min(base + p + 16 * u, chunks - 1);    // unconditional loads (a guarded load is a branch + wait each)
+                sv[u] = part[(long)i * 2 * C + col];
+                qv[u] = part[(long)i * 2 * C + C + col];
+            }
+#pragma unroll
+            for (int u = 0; u < NCHUNK / 16; ++u)
+                if (base + p + 16 * u < chunks) { s += sv[u]; q += qv[u]; }
         }
-#pragma unroll
-        for (int u = 0; u < NCHUNK / 16; ++u)
-            if (p + 16 * u < chunks) { s += sv[u]; q += qv[u]; }
-    }
     sh[0][p][c] = s; sh[1][p][c] = q;
     __syncthreads();
     tot0 = tot1 = 0.0;
@@ -224,6 +226,98 @@ __global__ __launch_bounds__(256) void k_bnact_bwd_apply(const float *__restrict
         } else {
             dx[i] = sc * dz;
         }
+    }
+}
+
+// ---- BatchNorm apply pass that FINISHES the statistics itself, for layers whose PRODUCER (the 1x1-convolution GEMM's epilogue,
+// the LDS depthwise kernel) already left per-tile partial sums: conv -> this = 2 launches instead of conv, statistics, finish,
+// apply.  A workgroup owns (row chunk, group of CG4 <= 16 channel float4s) and sums the group's partial columns itself --
+// float4 loads in batches of eight, the same fixed order in every workgroup, so all of them hold bit-identical totals.  Used
+// when that re-read is <= 24 KB per workgroup (the caller picks CG4); with the layer library's own statistics pass (up to 256
+// chunks x 64 channels) it was slower than the three-launch form (profiles/r02_mnv3_experiments).
+struct BnTile { int CG4, G_c, R; long rows_per_block; };
+// totals of the group's 2*CG partial columns -> tot[2*CG] (LDS, double).  part rows are [2C] floats.  256 threads.
+__device__ __forceinline__ void bn_group_totals(const float *__restrict__ part, int chunks, int C, int c0, int CG4, double *tot,
+                                                double *redd /* [256][4] */) {
+    const int nq = 2 * CG4;                         // float4 columns of the group (both statistics)
+    const int LA = 256 / nq;                        // chunk lanes (>= 8)
+    const int k4 = threadIdx.x % nq, la = threadIdx.x / nq;
+    const int comp = k4 / CG4, cq = k4 - comp * CG4, col = comp * C + min(c0 + 4 * cq, C - 4);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (la < LA)
+        for (int q0 = la; q0 < chunks; q0 += 8 * LA) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(part + (size_t)min(q0 + u * LA, chunks - 1) * 2 * C + col);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (q0 + u * LA < chunks) { a0 += v[u].x; a1 += v[u].y; a2 += v[u].z; a3 += v[u].w; }
+        }
+    double *r = redd + (size_t)threadIdx.x * 4;
+    r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3;
+    __syncthreads();
+    if (threadIdx.x < nq) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        for (int q = 0; q < LA; ++q) {
+            const double *u = redd + (size_t)(q * nq + k4) * 4;
+            t0 += u[0]; t1 += u[1]; t2 += u[2]; t3 += u[3];
+        }
+        double *o = tot + comp * 4 * CG4 + 4 * cq;
+        o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+    }
+    __syncthreads();
+}
+// grid G_r * G_c, block 256: thread = (float4 of the group's channels, row lane)
+__global__ __launch_bounds__(256) void k_bn_act_apply_fin(const float *__restrict__ x, const float *__restrict__ part, int chunks,
+                                                          long M, int C, BnTile t, ww_bn_t bn, int act, float *__restrict__ y,
+                                                          float *__restrict__ ss, float *__restrict__ mr) {
+    __shared__ double redd[256 * 4];
+    __shared__ double tot[128];
+    __shared__ __align__(16) float scsh[128];
+    const int gc = blockIdx.x % t.G_c, c0 = gc * 4 * t.CG4, CG = 4 * t.CG4;
+    const long rc = blockIdx.x / t.G_c;
+    float g_c = 0.f, b_c = 0.f, rm_c = 0.f, rv_c = 1.f;          // fetched before the partial sums, not behind them
+    const bool fin = threadIdx.x < CG && c0 + threadIdx.x < C;
+    if (fin) {
+        const int c = c0 + threadIdx.x;
+        g_c = bn.gamma[c]; b_c = bn.beta[c];
+        if (rc == 0 && bn.running_mean) { rm_c = bn.running_mean[c]; rv_c = bn.running_var[c]; }
+    }
+    bn_group_totals(part, chunks, C, c0, t.CG4, tot, redd);
+    if (fin) {
+        const int c = c0 + threadIdx.x;
+        const double mean = tot[threadIdx.x] / (double)M;
+        double var = tot[CG + threadIdx.x] / (double)M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)bn.eps), scale = (double)g_c * rstd;
+        const float scf = (float)scale, shf = (float)((double)b_c - mean * scale);
+        scsh[threadIdx.x] = scf; scsh[CG + threadIdx.x] = shf;
+        if (rc == 0) {
+            ss[c] = scf; ss[C + c] = shf;
+            mr[c] = (float)mean; mr[C + c] = (float)rstd;
+            if (bn.running_mean) {
+                const double m = bn.momentum, unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+                bn.running_mean[c] = (float)((1.0 - m) * (double)rm_c + m * mean);
+                bn.running_var[c] = (float)((1.0 - m) * (double)rv_c + m * unb);
+            }
+        }
+    }
+    __syncthreads();
+    const int cq = threadIdx.x % t.CG4, rl = threadIdx.x / t.CG4;
+    if (rl >= t.R || c0 + 4 * cq >= C) return;
+    const float4 sc = *reinterpret_cast<const float4 *>(scsh + 4 * cq), sf = *reinterpret_cast<const float4 *>(scsh + CG + 4 * cq);
+    const long r0 = rc * t.rows_per_block, r1 = min(M, r0 + t.rows_per_block);
+    const size_t col = (size_t)c0 + 4 * cq;
+    for (long rb = r0 + rl; rb < r1; rb += 4L * t.R) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(x + (size_t)min(rb + (long)u * t.R, r1 - 1) * C + col);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (rb + (long)u * t.R < r1)
+                *reinterpret_cast<float4 *>(y + (size_t)(rb + (long)u * t.R) * C + col) =
+                    make_float4(act_fwd(act, fmaf(v[u].x, sc.x, sf.x)), act_fwd(act, fmaf(v[u].y, sc.y, sf.y)),
+                                act_fwd(act, fmaf(v[u].z, sc.z, sf.z)), act_fwd(act, fmaf(v[u].w, sc.w, sf.w)));
     }
 }
 
@@ -440,13 +534,16 @@ __device__ __forceinline__ void dwl_stage(const float *__restrict__ src, int B, 
     }
 }
 // BWD = false: y = conv(x);  BWD = true: dx = conv^T(dy).  `in` has (Hi, Wi) pixels per image, `out` (Hq, Wq).
-template <int K, bool BWD>
+// Thread = (channel float4 cq, lane): it walks the workgroup's (image, output pixel) pairs lane, lane + R, ...  STATS (forward):
+// the per-channel sum / sum of squares of the workgroup's outputs go to stat_part[image group][2C] (fixed-order LDS sum over
+// the lanes) -- the BatchNorm statistics partials of the layer, so no separate statistics pass reads y again.
+template <int K, bool BWD, bool STATS>
 __global__ __launch_bounds__(256) void k_dwl_conv(const float *__restrict__ in, const float *__restrict__ w, DwG g, DwL l,
-                                                  float *__restrict__ out) {
-    extern __shared__ __align__(16) float4 dwl_lds[];          // wl4 [KK][CC4] | slab [nimg][Hi*Wi][CC4]
+                                                  float *__restrict__ out, float *__restrict__ stat_part) {
+    extern __shared__ __align__(16) float4 dwl_lds[];          // wl4 [KK][CC4] | slab [nimg][Hi*Wi][CC4] | (STATS) red [2][256]
     constexpr int KK = K * K, PAD = K / 2;
     const int Hi = BWD ? g.Ho : g.H, Wi = BWD ? g.Wo : g.W, Hq = BWD ? g.H : g.Ho, Wq = BWD ? g.W : g.Wo;
-    const int gc = blockIdx.x % l.G_c, b0 = (blockIdx.x / l.G_c) * l.nimg, c0q = gc * l.CC4, C4 = g.C >> 2;
+    const int gc = blockIdx.x % l.G_c, grp = blockIdx.x / l.G_c, b0 = grp * l.nimg, c0q = gc * l.CC4, C4 = g.C >> 2;
     float4 *wl4 = dwl_lds, *slab = dwl_lds + KK * l.CC4;
     for (int i = threadIdx.x; i < KK * l.CC4 * 4; i += 256) {          // w (C,1,k,k) -> wl4[tap][cq].{x,y,z,w}
         const int e = i & 3, cq = (i >> 2) % l.CC4, t = (i >> 2) / l.CC4, c = 4 * (c0q + cq) + e;
@@ -455,33 +552,54 @@ __global__ __launch_bounds__(256) void k_dwl_conv(const float *__restrict__ in, 
     const int nimg = min(l.nimg, g.B - b0);
     dwl_stage(in, g.B, b0, nimg, Hi * Wi, g.C, c0q, l.CC4, slab);
     __syncthreads();
-    const int perq = Hq * Wq * l.CC4, n = nimg * perq;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int img = i / perq, rem = i - img * perq, pix = rem / l.CC4, cq = rem - pix * l.CC4;
-        const int ho = pix / Wq, wo = pix - ho * Wq;
-        if (c0q + cq >= C4) continue;
-        const float4 *sl = slab + (size_t)img * Hi * Wi * l.CC4 + cq;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int cq = threadIdx.x % l.CC4, lane = threadIdx.x / l.CC4, R = 256 / l.CC4, HqWq = Hq * Wq;
+    const bool live = lane < R && c0q + cq < C4;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), q4 = s4;
+    if (live)
+        for (int pp = lane; pp < nimg * HqWq; pp += R) {
+            const int img = pp / HqWq, pix = pp - img * HqWq, ho = pix / Wq, wo = pix - ho * Wq;
+            const float4 *sl = slab + (size_t)img * Hi * Wi * l.CC4 + cq;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int kh = 0; kh < K; ++kh) {
-            int hi;
-            bool okh;
-            if (BWD) { const int th = ho + PAD - kh; hi = g.s == 2 ? th >> 1 : th; okh = th >= 0 && (g.s == 1 || !(th & 1)) && hi < Hi; }
-            else { hi = ho * g.s + kh - PAD; okh = hi >= 0 && hi < Hi; }
+            for (int kh = 0; kh < K; ++kh) {
+                int hi;
+                bool okh;
+                if (BWD) { const int th = ho + PAD - kh; hi = g.s == 2 ? th >> 1 : th; okh = th >= 0 && (g.s == 1 || !(th & 1)) && hi < Hi; }
+                else { hi = ho * g.s + kh - PAD; okh = hi >= 0 && hi < Hi; }
 #pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                int wi;
-                bool okw;
-                if (BWD) { const int tw = wo + PAD - kw; wi = g.s == 2 ? tw >> 1 : tw; okw = tw >= 0 && (g.s == 1 || !(tw & 1)) && wi < Wi; }
-                else { wi = wo * g.s + kw - PAD; okw = wi >= 0 && wi < Wi; }
-                if (okh && okw) {
-                    const float4 v = sl[(hi * Wi + wi) * l.CC4], wv = wl4[(kh * K + kw) * l.CC4 + cq];
-                    acc.x = fmaf(v.x, wv.x, acc.x); acc.y = fmaf(v.y, wv.y, acc.y);
-                    acc.z = fmaf(v.z, wv.z, acc.z); acc.w = fmaf(v.w, wv.w, acc.w);
+                for (int kw = 0; kw < K; ++kw) {
+                    int wi;
+                    bool okw;
+                    if (BWD) { const int tw = wo + PAD - kw; wi = g.s == 2 ? tw >> 1 : tw; okw = tw >= 0 && (g.s == 1 || !(tw & 1)) && wi < Wi; }
+                    else { wi = wo * g.s + kw - PAD; okw = wi >= 0 && wi < Wi; }
+                    if (okh && okw) {
+                        const float4 v = sl[(hi * Wi + wi) * l.CC4], wv = wl4[(kh * K + kw) * l.CC4 + cq];
+                        acc.x = fmaf(v.x, wv.x, acc.x); acc.y = fmaf(v.y, wv.y, acc.y);
+                        acc.z = fmaf(v.z, wv.z, acc.z); acc.w = fmaf(v.w, wv.w, acc.w);
+                    }
                 }
             }
+            *reinterpret_cast<float4 *>(out + ((size_t)(b0 + img) * HqWq + pix) * g.C + 4 * (c0q + cq)) = acc;
+            if (STATS) {
+                s4.x += acc.x; s4.y += acc.y; s4.z += acc.z; s4.w += acc.w;
+                q4.x = fmaf(acc.x, acc.x, q4.x); q4.y = fmaf(acc.y, acc.y, q4.y);
+                q4.z = fmaf(acc.z, acc.z, q4.z); q4.w = fmaf(acc.w, acc.w, q4.w);
+            }
         }
-        *reinterpret_cast<float4 *>(out + ((size_t)(b0 + img) * Hq * Wq + pix) * g.C + 4 * (c0q + cq)) = acc;
+    if (STATS) {
+        float4 *red = slab + (size_t)l.nimg * Hi * Wi * l.CC4;      // [2][256]
+        red[threadIdx.x] = s4; red[256 + threadIdx.x] = q4;
+        __syncthreads();
+        if (lane == 0 && c0q + cq < C4) {
+            double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int q = 0; q < R; ++q) {
+                const float4 a = red[q * l.CC4 + cq], b = red[256 + q * l.CC4 + cq];
+                t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w; t[4] += b.x; t[5] += b.y; t[6] += b.z; t[7] += b.w;
+            }
+            float *o = stat_part + (size_t)grp * 2 * g.C + 4 * (c0q + cq);
+            *reinterpret_cast<float4 *>(o) = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+            *reinterpret_cast<float4 *>(o + g.C) = make_float4((float)t[4], (float)t[5], (float)t[6], (float)t[7]);
+        }
     }
 }
 // weight gradient: x and dy slabs of the workgroup's images in LDS, thread = (tap, channel float4) summing over (image, output
@@ -793,6 +911,45 @@ extern "C" int ww_bn_act_fwd(ww_ctx *ctx, const float *x, long M, int C, const w
     return WW_OK;
 }
 
+// (row chunk, channel group) tiling of k_bn_act_apply_fin: the widest group (16, 8 or 4 channel float4s) whose re-read of the
+// partials stays <= 24 KB per workgroup; CG4 == 0: too many partial rows, take the finish launch instead
+static BnTile bn_tile(long M, int C, int chunks) {
+    BnTile t = {0, 0, 0, 0};
+    const int C4 = C / 4;
+    for (int cg4 = 16; cg4 >= 4; cg4 >>= 1) {
+        const int G_c = (C4 + cg4 - 1) / cg4, CG4 = (C4 + G_c - 1) / G_c;
+        if ((size_t)chunks * 2 * 4 * CG4 * sizeof(float) > 24 * 1024) continue;
+        t.G_c = G_c; t.CG4 = CG4; t.R = 256 / CG4;
+        const long G_r = std::max<long>(1, std::min<long>(std::max(1, 1024 / G_c), M / (4L * t.R)));
+        t.rows_per_block = (M + G_r - 1) / G_r;
+        break;
+    }
+    return t;
+}
+// training-mode BatchNorm(+activation) of x (M, C) whose statistics partials -- `chunks` rows of [sum (C) | sum of squares (C)]
+// -- a producer has already written to `part`
+int ww_bn_act_from_partials(ww_ctx *ctx, const float *x, long M, int C, const ww_bn_t *bn, int act, float *y, float *ss, float *mr,
+                            const float *part, int chunks, hipStream_t st) {
+    WW_REQUIRE(C <= 1024 && chunks >= 1, WW_E_UNSUPPORTED, "ww_bn_act_from_partials: C=%d > 1024", C);
+    const bool v4 = vec4_ok(M * C, C, {x, y, part});
+    const BnTile t = v4 ? bn_tile(M, C, chunks) : BnTile{0, 0, 0, 0};
+    if (t.CG4) {
+        const int blocks = (int)((M + t.rows_per_block - 1) / t.rows_per_block) * t.G_c;
+        hipLaunchKernelGGL(k_bn_act_apply_fin, dim3(blocks), dim3(256), 0, st, x, part, chunks, M, C, t, *bn, act, y, ss, mr);
+        WW_LAUNCH_CHECK();
+        return WW_OK;
+    }
+    hipLaunchKernelGGL(k_bn_finish, dim3((C + 63) / 64), dim3(1024), 0, st, part, chunks, M, C, *bn, ss, mr);
+    WW_LAUNCH_CHECK();
+    if (v4)
+        hipLaunchKernelGGL(k_bn_act_apply4, dim3(egrid(M * C / 4)), dim3(256), 0, st, (const float4 *)x, ss, (uint32_t)(M * C / 4), C,
+                           act, (float4 *)y);
+    else
+        hipLaunchKernelGGL(k_bn_act_apply, dim3(egrid(M * C)), dim3(256), 0, st, x, ss, M * C, C, act, y);
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+
 extern "C" int ww_bn_act_bwd(ww_ctx *ctx, const float *x, const float *da, long M, int C, const float *ss, const float *mr, int act,
                              int training, float *dx, float *dgamma, float *dbeta, void *scratch, ww_stream_t stream) {
     WW_REQUIRE(ctx && x && da && ss && mr && dx && dgamma && dbeta && scratch, WW_E_INVALID, "ww_bn_act_bwd: null argument");
@@ -854,8 +1011,8 @@ extern "C" int ww_dwconv_nhwc_fwd(ww_ctx *ctx, const float *x, const float *w, i
     if ((((uintptr_t)x | (uintptr_t)y) & 15) == 0 && dwl_plan(g, (size_t)H * W * 16, 40 * 1024, &l)) {
         const dim3 lg((unsigned)((B + l.nimg - 1) / l.nimg) * l.G_c);
         const size_t lds = ((size_t)k * k * l.CC4 + (size_t)l.nimg * H * W * l.CC4) * 16;
-        if (k == 3) hipLaunchKernelGGL((k_dwl_conv<3, false>), lg, dim3(256), lds, (hipStream_t)stream, x, w, g, l, y);
-        else hipLaunchKernelGGL((k_dwl_conv<5, false>), lg, dim3(256), lds, (hipStream_t)stream, x, w, g, l, y);
+        if (k == 3) hipLaunchKernelGGL((k_dwl_conv<3, false, false>), lg, dim3(256), lds, (hipStream_t)stream, x, w, g, l, y, (float *)nullptr);
+        else hipLaunchKernelGGL((k_dwl_conv<5, false, false>), lg, dim3(256), lds, (hipStream_t)stream, x, w, g, l, y, (float *)nullptr);
     } else if ((C & 3) == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
         if (k == 3) hipLaunchKernelGGL(k_dwg_fwd4<3>, grid, dim3(256), wbytes, (hipStream_t)stream, x, w, g, y);
         else hipLaunchKernelGGL(k_dwg_fwd4<5>, grid, dim3(256), wbytes, (hipStream_t)stream, x, w, g, y);
@@ -864,6 +1021,31 @@ extern "C" int ww_dwconv_nhwc_fwd(ww_ctx *ctx, const float *x, const float *w, i
     }
     WW_LAUNCH_CHECK();
     return WW_OK;
+}
+extern "C" int ww_dwconv_bn_act_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int H, int W, int C, int k, int stride,
+                                    const ww_bn_t *bn, int act, float *y, float *a, float *ss, float *mr, void *scratch,
+                                    ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && w && bn && bn->gamma && bn->beta && y && a && ss && mr && scratch, WW_E_INVALID, "ww_dwconv_bn_act_fwd: null argument");
+    DwG g;
+    int rc = make_dwg("ww_dwconv_bn_act_fwd", B, H, W, C, k, stride, &g);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const long M = (long)B * g.Ho * g.Wo;
+    DwL l;
+    if (bn->training && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)scratch) & 15) == 0 && dwl_plan(g, (size_t)H * W * 16, 40 * 1024, &l)) {
+        // the LDS kernel leaves one row of statistics partials per image group: conv + (finishing) apply = 2 launches
+        ww_prof_scope ps_(ctx, WW_K_NHWC, st);
+        const int groups = (B + l.nimg - 1) / l.nimg;
+        const dim3 lg((unsigned)groups * l.G_c);
+        const size_t lds = ((size_t)k * k * l.CC4 + (size_t)l.nimg * H * W * l.CC4 + 512) * 16;
+        float *part = (float *)scratch;
+        if (k == 3) hipLaunchKernelGGL((k_dwl_conv<3, false, true>), lg, dim3(256), lds, st, x, w, g, l, y, part);
+        else hipLaunchKernelGGL((k_dwl_conv<5, false, true>), lg, dim3(256), lds, st, x, w, g, l, y, part);
+        WW_LAUNCH_CHECK();
+        return ww_bn_act_from_partials(ctx, y, M, C, bn, act, a, ss, mr, part, groups, st);
+    }
+    if ((rc = ww_dwconv_nhwc_fwd(ctx, x, w, B, H, W, C, k, stride, y, stream))) return rc;
+    return ww_bn_act_fwd(ctx, y, M, C, bn, act, a, ss, mr, scratch, stream);
 }
 extern "C" int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, const float *dy, int B, int H, int W, int C, int k,
                                   int stride, float *dx, float *dw, void *scratch, ww_stream_t stream) {
@@ -882,8 +1064,8 @@ extern "C" int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, c
         if ((((uintptr_t)dy | (uintptr_t)dx) & 15) == 0 && dwl_plan(g, (size_t)g.Ho * g.Wo * 16, 40 * 1024, &l)) {
             const dim3 lg((unsigned)((B + l.nimg - 1) / l.nimg) * l.G_c);
             const size_t lds = ((size_t)k * k * l.CC4 + (size_t)l.nimg * g.Ho * g.Wo * l.CC4) * 16;
-            if (k == 3) hipLaunchKernelGGL((k_dwl_conv<3, true>), lg, dim3(256), lds, st, dy, w, g, l, dx);
-            else hipLaunchKernelGGL((k_dwl_conv<5, true>), lg, dim3(256), lds, st, dy, w, g, l, dx);
+            if (k == 3) hipLaunchKernelGGL((k_dwl_conv<3, true, false>), lg, dim3(256), lds, st, dy, w, g, l, dx, (float *)nullptr);
+            else hipLaunchKernelGGL((k_dwl_conv<5, true, false>), lg, dim3(256), lds, st, dy, w, g, l, dx, (float *)nullptr);
         } else if ((C & 3) == 0 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
             if (k == 3) hipLaunchKernelGGL(k_dwg_bwd_dx4<3>, grid, dim3(256), wbytes, st, dy, w, g, dx);
             else hipLaunchKernelGGL(k_dwg_bwd_dx4<5>, grid, dim3(256), wbytes, st, dy, w, g, dx);

@@ -135,22 +135,31 @@ class _ConvBNActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, conv, bn, kind, act, mode):
+        bnp = nat.make_bn(gamma, beta, bn.running_mean, bn.running_var, momentum=bn.momentum, eps=bn.eps, training=bn.training)
         if kind == "stem":
             B, _, H, W = x.shape
             src = nat.im2col3x3s2(x.reshape(B, H, W).contiguous())
-            w2 = w.reshape(w.shape[0], 9)
-            y = nat.linear_mfma_fwd(src, w2, None, mode=mode).reshape(B, (H + 1) // 2, (W + 1) // 2, w.shape[0])
+            w2, oshape = w.reshape(w.shape[0], 9), (B, (H + 1) // 2, (W + 1) // 2, w.shape[0])
         elif kind == "dw":
             src = x.contiguous()
-            y = nat.dwconv_nhwc_fwd(src, w.contiguous(), conv.k, conv.stride)
         else:
             src = x.reshape(-1, x.shape[-1])
-            y = nat.linear_mfma_fwd(src, w.reshape(w.shape[0], -1), None, mode=mode).reshape(*x.shape[:-1], w.shape[0])
-        Cn = y.shape[-1]
-        bnp = nat.make_bn(gamma, beta, bn.running_mean, bn.running_var, momentum=bn.momentum, eps=bn.eps, training=bn.training)
-        a, ss, mr = nat.bn_act_fwd(y, bnp, act, Cn)
+            w2, oshape = w.reshape(w.shape[0], -1), (*x.shape[:-1], w.shape[0])
         if bn.training:
+            # training: the convolution's own kernel leaves the BatchNorm statistics partials and the apply pass finishes them
+            if kind == "dw":
+                y, a, ss, mr = nat.dwconv_bn_act_fwd(src, w.contiguous(), conv.k, conv.stride, bnp, act)
+            else:
+                y, a, ss, mr = nat.conv1x1_bn_act_fwd(src, w2, bnp, act, mode)
+                y, a = y.reshape(oshape), a.reshape(oshape)
             bn._pending_tracked += 1           # host-side count, folded into the buffer when the state is read
+        else:
+            if kind == "dw":
+                y = nat.dwconv_nhwc_fwd(src, w.contiguous(), conv.k, conv.stride)
+            else:
+                y = nat.linear_mfma_fwd(src, w2, None, mode=mode).reshape(oshape)
+            a, ss, mr = nat.bn_act_fwd(y, bnp, act, y.shape[-1])
+        Cn = y.shape[-1]
         ctx.save_for_backward(src, w, y, ss, mr)
         ctx.meta = (kind, act, mode, bn.training, conv.k, conv.stride, x.shape, Cn)
         return a
