@@ -228,10 +228,15 @@ __device__ __forceinline__ void ww_colgroup_sum(const float *__restrict__ partia
     {
         const int col = (q < 2 ? 8 * cg + 4 * q : 64 + 8 * cg + 4 * (q - 2));
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll 4
-        for (int r = part; r < rows; r += 256) {
-            const float4 v = *reinterpret_cast<const float4 *>(partials + (size_t)r * 128 + col);
-            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+        // a thread's (<= 4: rows <= 1024) slab rows in one batch of unconditional, clamped loads: as a guarded loop the rows
+        // beyond a multiple of four took the remainder loop -- one dependent L2 round trip each
+        for (int r0 = part; r0 < rows; r0 += 4 * 256) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(partials + (size_t)min(r0 + 256 * u, rows - 1) * 128 + col);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r0 + 256 * u < rows) { a0 += (double)v[u].x; a1 += (double)v[u].y; a2 += (double)v[u].z; a3 += (double)v[u].w; }
         }
         sh[part][4 * q] = a0; sh[part][4 * q + 1] = a1; sh[part][4 * q + 2] = a2; sh[part][4 * q + 3] = a3;
     }
@@ -261,6 +266,13 @@ __global__ __launch_bounds__(1024) void k_bn_fwd_finalize(const float *__restric
                                                           float *__restrict__ mr) {
     __shared__ double sh[256][16];
     __shared__ double tot[16];
+    // the channel's parameters are fetched BEFORE the slab sums (behind them they were two more dependent round trips)
+    float g_c = 0.f, b_c = 0.f, rm_c = 0.f, rv_c = 1.f;
+    if (threadIdx.x < 8) {
+        const int c = 8 * blockIdx.x + threadIdx.x;
+        g_c = bn.gamma[c]; b_c = bn.beta[c];
+        if (bn.running_mean) { rm_c = bn.running_mean[c]; rv_c = bn.running_var[c]; }
+    }
     ww_colgroup_sum(partials, rows, blockIdx.x, sh, tot);
     if (threadIdx.x < 8) {
         const int c = 8 * blockIdx.x + threadIdx.x;
@@ -268,16 +280,16 @@ __global__ __launch_bounds__(1024) void k_bn_fwd_finalize(const float *__restric
         double var = tot[8 + threadIdx.x] / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)bn.eps);
-        const double scale = (double)bn.gamma[c] * rstd;
+        const double scale = (double)g_c * rstd;
         ss[c] = (float)scale;
-        ss[64 + c] = (float)((double)bn.beta[c] - mean * scale);
+        ss[64 + c] = (float)((double)b_c - mean * scale);
         mr[c] = (float)mean;
         mr[64 + c] = (float)rstd;
         if (bn.running_mean) {
             const double m = bn.momentum;
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            bn.running_mean[c] = (float)((1.0 - m) * (double)bn.running_mean[c] + m * mean);
-            bn.running_var[c] = (float)((1.0 - m) * (double)bn.running_var[c] + m * unb);
+            bn.running_mean[c] = (float)((1.0 - m) * (double)rm_c + m * mean);
+            bn.running_var[c] = (float)((1.0 - m) * (double)rv_c + m * unb);
         }
     }
 }
@@ -302,11 +314,13 @@ __device__ __forceinline__ void bn_bwd_finalize_group(const float *__restrict__ 
                                                       const float *__restrict__ gamma, const float *__restrict__ mr,
                                                       float *__restrict__ coef, float *__restrict__ dgamma,
                                                       float *__restrict__ dbeta, double (*sh)[16], double *tot) {
+    float mean_c = 0.f, rstd_c = 0.f, g_c = 0.f;        // fetched before the slab sums, not behind them
+    if (threadIdx.x < 8) { const int c = 8 * cg + threadIdx.x; mean_c = mr[c]; rstd_c = mr[64 + c]; g_c = gamma[c]; }
     ww_colgroup_sum(partials, rows, cg, sh, tot);
     if (threadIdx.x < 8) {
         const int c = 8 * cg + threadIdx.x;
         const double s1 = tot[threadIdx.x], s2 = tot[8 + threadIdx.x];
-        const double mean = mr[c], rstd = mr[64 + c], g = gamma[c];
+        const double mean = mean_c, rstd = rstd_c, g = g_c;
         const double c1 = s1 / count, c2 = s2 / count;
         const double A = g * rstd;
         coef[c] = (float)A;
@@ -333,13 +347,15 @@ __device__ __forceinline__ void colsum_body(const float *__restrict__ partials, 
     const int c4 = threadIdx.x & 15, part = threadIdx.x >> 4;
     const int col = blk * 64 + 4 * c4;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    if (col < cols) {
-#pragma unroll 8
-        for (int r = part; r < rows; r += 64) {
-            const float4 v = *reinterpret_cast<const float4 *>(partials + (size_t)r * cols + col);
-            a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+    if (col < cols)
+        for (int r0 = part; r0 < rows; r0 += 8 * 64) {          // batches of eight unconditional, clamped row loads
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(partials + (size_t)min(r0 + 64 * u, rows - 1) * cols + col);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r0 + 64 * u < rows) { a0 += (double)v[u].x; a1 += (double)v[u].y; a2 += (double)v[u].z; a3 += (double)v[u].w; }
         }
-    }
     sh[part * 64 + 4 * c4] = a0; sh[part * 64 + 4 * c4 + 1] = a1;
     sh[part * 64 + 4 * c4 + 2] = a2; sh[part * 64 + 4 * c4 + 3] = a3;
     __syncthreads();

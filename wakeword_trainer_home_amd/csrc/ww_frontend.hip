@@ -154,19 +154,41 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                 fast = base >= 0 && base + a.span_len <= a.N && (((size_t)b * a.N + (size_t)base) & 3) == 0 &&
                        (reinterpret_cast<uintptr_t>(wave) & 15) == 0;
                 if (fast) {
+                    // a thread's float4s of the span in batches of four unconditional (clamped) loads: as a plain copy loop
+                    // every float4 was its own load -> wait -> LDS store round trip (3-4 dependent HBM latencies per item,
+                    // and at one workgroup per CU beside a training step nothing else hides them)
                     const float4 *src = reinterpret_cast<const float4 *>(x + base);
                     const int n4 = a.span_len >> 2;
-                    for (int i = tid; i < n4; i += 256) reinterpret_cast<float4 *>(span)[i] = src[i];
+                    for (int i0 = tid; i0 < n4; i0 += 4 * 256) {
+                        float4 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = src[min(i0 + 256 * u, n4 - 1)];
+                        // all four must be live here (else the register allocator, at this kernel's pressure, funnels them through
+                        // ONE register quad: load, wait, store, load ...); the stores are unconditional too (a clamped slot is
+                        // rewritten with its own value): behind a guard the compiler sinks each load next to its store again
+                        asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[0].w), "+v"(v[1].x), "+v"(v[1].y),
+                                     "+v"(v[1].z), "+v"(v[1].w), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w),
+                                     "+v"(v[3].x), "+v"(v[3].y), "+v"(v[3].z), "+v"(v[3].w));
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) reinterpret_cast<float4 *>(span)[min(i0 + 256 * u, n4 - 1)] = v[u];
+                    }
                     for (int i = 4 * n4 + tid; i < a.span_len; i += 256) span[i] = x[base + i];
                 }
             }
             if (!fast) {
-                for (int i = tid; i < a.span_len; i += 256) {
-                    long idx = base + i;
-                    if (idx < 0) idx = -idx;
-                    if (idx >= a.N) idx = 2L * (a.N - 1) - idx;
-                    idx = idx < 0 ? 0 : (idx >= a.N ? a.N - 1 : idx);  // only frames >= T can get here
-                    span[i] = load_sample(x, (size_t)idx);
+                for (int i0 = tid; i0 < a.span_len; i0 += 8 * 256) {      // same batching for the reflected / int16 / unaligned spans
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        long idx = base + min(i0 + 256 * u, a.span_len - 1);
+                        if (idx < 0) idx = -idx;
+                        if (idx >= a.N) idx = 2L * (a.N - 1) - idx;
+                        idx = idx < 0 ? 0 : (idx >= a.N ? a.N - 1 : idx);  // only frames >= T can get here
+                        v[u] = load_sample(x, (size_t)idx);
+                    }
+                    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) span[min(i0 + 256 * u, a.span_len - 1)] = v[u];
                 }
             }
         }
