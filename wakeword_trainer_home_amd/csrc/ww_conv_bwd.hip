@@ -37,44 +37,75 @@ __global__ __launch_bounds__(1024) void k_head_bwd(const float *__restrict__ dlo
                                                   float *__restrict__ coef, float *__restrict__ dgamma,
                                                   float *__restrict__ dbeta, const ww_step_ctl *__restrict__ ctl) {
     __shared__ double sh[6][1024];
+    __shared__ double sh2[6][16][8];
     ww_step_resolve(ctl, step_lo, step_hi, step_lo, step_hi);
     const int c = 8 * blockIdx.x + (threadIdx.x & 7), part = threadIdx.x >> 3;      // 128 batch parts
     const float w0 = fc_w[c], w1 = fc_w[64 + c];
+    float mean_c = 0.f, rstd_c = 0.f, g_c = 0.f;          // for the constants at the end: fetched up front, not behind the sums
+    if (threadIdx.x < 8) { mean_c = mr[c]; rstd_c = mr[64 + c]; g_c = gamma[c]; }
     const float inv_hw = 1.0f / (float)HW;
     double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int b = part; b < B; b += 128) {
-        const float dl0 = dlogits[(size_t)b * 2], dl1 = dlogits[(size_t)b * 2 + 1];
-        const float pv = pd[(size_t)b * 64 + c];
-        a0 += (double)dl0 * pv;
-        a1 += (double)dl1 * pv;
-        b0 += dl0;
-        b1 += dl1;
-        float dp = fmaf(dl0, w0, dl1 * w1);
-        if (use_dropout) {
-            uint32_t rr[4];
-            ww_philox(step_lo, step_hi, (uint32_t)(sample_offset + (uint64_t)b), (WW_TAG_DROPOUT << 24) | (uint32_t)(c >> 2),
-                      seed_lo, seed_hi, rr);
-            const int q = c & 3;   // selected with compares: a dynamically indexed local array would live in scratch
-            const uint32_t rv = q == 0 ? rr[0] : q == 1 ? rr[1] : q == 2 ? rr[2] : rr[3];
-            dp = ((uint64_t)rv >= drop_thresh) ? dp * drop_scale : 0.f;
+    // a part's clips (b = part, part + 128, ...) four at a time: their five loads each are issued as one batch (the guarded loop was
+    // one dependent round trip per clip)
+    for (int bb = part; bb < B; bb += 4 * 128) {
+        float dl0[4], dl1[4], pv[4], pc[4], ph[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t b = (size_t)min(bb + 128 * u, B - 1);
+            dl0[u] = dlogits[b * 2]; dl1[u] = dlogits[b * 2 + 1];
+            pv[u] = pd[b * 64 + c];
+            pc[u] = pool[b * 192 + 128 + c];  // count_{z>0}
+            ph[u] = pool[b * 192 + 64 + c];   // sum_{z>0} yhat
         }
-        dp *= inv_hw;  // d mean / d element
-        dpool[(size_t)b * 64 + c] = dp;
-        s1 += (double)dp * pool[(size_t)b * 192 + 128 + c];  // * count_{z>0}
-        s2 += (double)dp * pool[(size_t)b * 192 + 64 + c];   // * sum_{z>0} yhat
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = bb + 128 * u;
+            if (b < B) {
+                a0 += (double)dl0[u] * pv[u];
+                a1 += (double)dl1[u] * pv[u];
+                b0 += dl0[u];
+                b1 += dl1[u];
+                float dp = fmaf(dl0[u], w0, dl1[u] * w1);
+                if (use_dropout) {
+                    uint32_t rr[4];
+                    ww_philox(step_lo, step_hi, (uint32_t)(sample_offset + (uint64_t)b), (WW_TAG_DROPOUT << 24) | (uint32_t)(c >> 2),
+                              seed_lo, seed_hi, rr);
+                    const int q = c & 3;   // selected with compares: a dynamically indexed local array would live in scratch
+                    const uint32_t rv = q == 0 ? rr[0] : q == 1 ? rr[1] : q == 2 ? rr[2] : rr[3];
+                    dp = ((uint64_t)rv >= drop_thresh) ? dp * drop_scale : 0.f;
+                }
+                dp *= inv_hw;  // d mean / d element
+                dpool[(size_t)b * 64 + c] = dp;
+                s1 += (double)dp * pc[u];
+                s2 += (double)dp * ph[u];
+            }
+        }
     }
     sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1; sh[2][threadIdx.x] = b0;
     sh[3][threadIdx.x] = b1; sh[4][threadIdx.x] = s1; sh[5][threadIdx.x] = s2;
     __syncthreads();
+    // two-level fixed-order sum over the 128 parts: 6 quantities x 16 segments x 8 channels by 768 threads (8 parts each), then
+    // 16 segments by 48 threads -- eight threads walking 768 LDS values one after the other was half of this kernel's 16 us
+    if (threadIdx.x < 768) {
+        const int k = threadIdx.x >> 7, seg = (threadIdx.x >> 3) & 15, c8 = threadIdx.x & 7;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a += sh[k][8 * (8 * seg + q) + c8];
+        sh2[k][seg][c8] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 48) {
+        const int k = threadIdx.x >> 3, c8 = threadIdx.x & 7;
+        double a = 0.0;
+#pragma unroll
+        for (int seg = 0; seg < 16; ++seg) a += sh2[k][seg][c8];
+        sh[k][c8] = a;
+    }
+    __syncthreads();
     if (threadIdx.x < 8) {
         double t[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            double a = 0.0;
-#pragma unroll 4      // all loads in flight at once spilled; a kernel with scratch pays ~6 us on each side of its dispatch
-            for (int q = 0; q < 128; ++q) a += sh[k][8 * q + threadIdx.x];
-            t[k] = a;
-        }
+        for (int k = 0; k < 6; ++k) t[k] = sh[k][threadIdx.x];
         dfc_w[c] = (float)t[0];
         dfc_w[64 + c] = (float)t[1];
         if (c == 0) {
@@ -82,7 +113,7 @@ __global__ __launch_bounds__(1024) void k_head_bwd(const float *__restrict__ dlo
             dfc_b[1] = (float)t[3];
         }
         const double count = (double)B * HW;
-        const double mean = mr[c], rstd = mr[64 + c], g = gamma[c];
+        const double mean = mean_c, rstd = rstd_c, g = g_c;
         const double c1 = t[4] / count, c2 = t[5] / count, A = g * rstd;
         coef[c] = (float)A;
         coef[64 + c] = (float)(-A * rstd * c2);

@@ -479,35 +479,47 @@ __global__ __launch_bounds__(256) void k_pw_fwd_bf16(const H *__restrict__ yin, 
 
 // -------------------------------------------------------------------------------------- GAP
 // pool[b] = [sum relu(z) (64) | sum_{z>0} yhat (64) | count_{z>0} (64)]
-// one 1024-thread workgroup per clip (32 pixel slots): 32 waves/CU keep enough loads in flight for a pure read
+// one 1024-thread workgroup per clip: 64 pixel slots x 16 lanes of FOUR channels (8-byte loads of a 16-bit tensor), a lane's
+// pixels in batches of eight unconditional (clamped) loads -- with two channels per lane and four loads per loop trip the
+// kernel was a chain of twelve dependent round trips per thread (22 us for 100 MB)
 template <typename T>
 __global__ __launch_bounds__(1024) void k_gap_fwd(const T *__restrict__ y, const float *__restrict__ ss,
                                                   const float *__restrict__ mr, int HW, float *__restrict__ pool) {
-    __shared__ float sh[32 * 192];
-    const int tid = threadIdx.x, slot = tid >> 5, cl = tid & 31, b = blockIdx.x;
-    const float2 sc = *reinterpret_cast<const float2 *>(ss + 2 * cl);
-    const float2 sf = *reinterpret_cast<const float2 *>(ss + 64 + 2 * cl);
-    const float2 mu = *reinterpret_cast<const float2 *>(mr + 2 * cl);
-    const float2 rs = *reinterpret_cast<const float2 *>(mr + 64 + 2 * cl);
-    const T *yb = y + (size_t)b * HW * 64;
-    float a0 = 0.f, a1 = 0.f, h0 = 0.f, h1 = 0.f, c0 = 0.f, c1 = 0.f;
-#pragma unroll 4
-    for (int p = slot; p < HW; p += 32) {
-        const float2 v = Act<T>::cvt2(Act<T>::ldraw2_nt(yb + (size_t)p * 64 + 2 * cl));
-        const float z0 = fmaf(v.x, sc.x, sf.x), z1 = fmaf(v.y, sc.y, sf.y);
-        a0 += z0 < 0.f ? 0.f : z0;                       // NaN-propagating ReLU, as torch
-        a1 += z1 < 0.f ? 0.f : z1;
-        if (z0 > 0.f) { h0 += (v.x - mu.x) * rs.x; c0 += 1.f; }
-        if (z1 > 0.f) { h1 += (v.y - mu.y) * rs.y; c1 += 1.f; }
+    __shared__ __align__(16) float sh[64 * 192];
+    const int tid = threadIdx.x, slot = tid >> 4, cl = tid & 15, b = blockIdx.x;
+    const float4 sc = *reinterpret_cast<const float4 *>(ss + 4 * cl);
+    const float4 sf = *reinterpret_cast<const float4 *>(ss + 64 + 4 * cl);
+    const float4 mu = *reinterpret_cast<const float4 *>(mr + 4 * cl);
+    const float4 rs = *reinterpret_cast<const float4 *>(mr + 64 + 4 * cl);
+    const T *yb = y + (size_t)b * HW * 64 + 4 * cl;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), h = a, c = a;
+    auto one = [](float v, float scv, float sfv, float muv, float rsv, float &av, float &hv, float &cv) {
+        const float z = fmaf(v, scv, sfv);
+        av += z < 0.f ? 0.f : z;                         // NaN-propagating ReLU, as torch
+        if (z > 0.f) { hv += (v - muv) * rsv; cv += 1.f; }
+    };
+    for (int p0 = slot; p0 < HW; p0 += 8 * 64) {
+        typename Act<T>::raw4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = Act<T>::ldraw4_nt(yb + (size_t)min(p0 + 64 * u, HW - 1) * 64);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (p0 + 64 * u < HW) {
+                const float4 v = Act<T>::cvt4(r[u]);
+                one(v.x, sc.x, sf.x, mu.x, rs.x, a.x, h.x, c.x);
+                one(v.y, sc.y, sf.y, mu.y, rs.y, a.y, h.y, c.y);
+                one(v.z, sc.z, sf.z, mu.z, rs.z, a.z, h.z, c.z);
+                one(v.w, sc.w, sf.w, mu.w, rs.w, a.w, h.w, c.w);
+            }
     }
-    sh[slot * 192 + 2 * cl] = a0;        sh[slot * 192 + 2 * cl + 1] = a1;
-    sh[slot * 192 + 64 + 2 * cl] = h0;   sh[slot * 192 + 64 + 2 * cl + 1] = h1;
-    sh[slot * 192 + 128 + 2 * cl] = c0;  sh[slot * 192 + 128 + 2 * cl + 1] = c1;
+    *reinterpret_cast<float4 *>(sh + slot * 192 + 4 * cl) = a;
+    *reinterpret_cast<float4 *>(sh + slot * 192 + 64 + 4 * cl) = h;
+    *reinterpret_cast<float4 *>(sh + slot * 192 + 128 + 4 * cl) = c;
     __syncthreads();
     if (tid < 192) {
         float t = 0.f;
 #pragma unroll 8
-        for (int s = 0; s < 32; ++s) t += sh[s * 192 + tid];
+        for (int s = 0; s < 64; ++s) t += sh[s * 192 + tid];
         pool[(size_t)b * 192 + tid] = t;
     }
 }
