@@ -4,6 +4,7 @@ There is deliberately NO fallback: if the shared library is missing, or a tensor
 on an MI355X, these wrappers raise.  PyTorch is used for device memory and streams only.
 """
 import ctypes as C
+import math
 import os
 from pathlib import Path
 
@@ -443,9 +444,18 @@ def gemm16_nt(a, b, out_dtype=torch.float32):
     return out
 
 
+def _out(buf, shape, dev):
+    """`buf` (a caller's contiguous fp32 tensor of `shape`'s size -- e.g. a gradient-bucket slot) or a fresh tensor."""
+    if buf is None:
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+    if buf.dtype != torch.float32 or not buf.is_contiguous() or buf.numel() != math.prod(shape) or buf.device != dev:
+        raise ValueError("output buffer must be a contiguous float32 tensor of the result's size on the same device")
+    return buf
+
+
 def linear_mfma_bwd(x, w, pre, dy, act=LIN_NONE, dropout_p=0.0, seed=0, step=0, sample_offset=0, mode=torch.float32,
-                    need_dx=True, need_db=True):
-    """-> (dx | None, dw, db | None)."""
+                    need_dx=True, need_db=True, dw_out=None, db_out=None):
+    """-> (dx | None, dw, db | None).  dw_out / db_out: write the parameter gradients there (returned as given)."""
     dev = _dev(x, w, pre, dy)
     _lin_check(x, w, None)
     M, K = x.shape
@@ -453,8 +463,8 @@ def linear_mfma_bwd(x, w, pre, dy, act=LIN_NONE, dropout_p=0.0, seed=0, step=0, 
     if tuple(dy.shape) != (M, N) or dy.dtype != torch.float32:
         raise ValueError(f"linear backward: dy must be float32 {(M, N)}, got {tuple(dy.shape)}")
     dx = torch.empty((M, K), dtype=torch.float32, device=dev) if need_dx else None
-    dw = torch.empty((N, K), dtype=torch.float32, device=dev)
-    db = torch.empty(N, dtype=torch.float32, device=dev) if need_db else None
+    dw = _out(dw_out, (N, K), dev)
+    db = _out(db_out, (N,), dev) if need_db else None
     nbytes = load().ww_linear_mfma_bwd_scratch_bytes(M, K, N)
     scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     epi = LinearEpi(act, dropout_p, seed, step, sample_offset)
@@ -511,12 +521,12 @@ def bn_act_fwd(x, bn: BN, act, Cn):
     return y, ss, mr
 
 
-def bn_act_bwd(x, da, ss, mr, act, training, Cn):
+def bn_act_bwd(x, da, ss, mr, act, training, Cn, dgamma_out=None, dbeta_out=None):
     dev = _dev(x, da, ss, mr)
     M = x.numel() // Cn
     dx = torch.empty_like(x)
-    dgamma = torch.empty(Cn, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(Cn, dtype=torch.float32, device=dev)
+    dgamma = _out(dgamma_out, (Cn,), dev)
+    dbeta = _out(dbeta_out, (Cn,), dev)
     with _guard(dev):
         _check(load().ww_bn_act_bwd(ctx(dev), _p(x), _p(da), M, Cn, _p(ss), _p(mr), act, int(training), _p(dx), _p(dgamma),
                                     _p(dbeta), _p(nhwc_scratch(Cn, dev)), _stream(dev)), "ww_bn_act_bwd")
@@ -567,11 +577,11 @@ def dwconv_nhwc_fwd(x, w, k, stride):
     return y
 
 
-def dwconv_nhwc_bwd(x, w, dy, k, stride, need_dx=True):
+def dwconv_nhwc_bwd(x, w, dy, k, stride, need_dx=True, dw_out=None):
     dev = _dev(x, w, dy)
     B, H, W, Cn = x.shape
     dx = torch.empty_like(x) if need_dx else None
-    dw = torch.empty_like(w)
+    dw = _out(dw_out, tuple(w.shape), dev)
     with _guard(dev):
         _check(load().ww_dwconv_nhwc_bwd(ctx(dev), _p(x), _p(w), _p(dy), B, H, W, Cn, k, stride, _p(dx), _p(dw),
                                          _p(nhwc_scratch(Cn, dev)), _stream(dev)), "ww_dwconv_nhwc_bwd")
@@ -638,15 +648,15 @@ def se_fwd(x, w1, b1, w2, b2):
     return y, s, pre1, pre2
 
 
-def se_bwd(x, dy, s, pre1, pre2, w1, w2):
-    """-> (dx, dw1, db1, dw2, db2); two launches."""
+def se_bwd(x, dy, s, pre1, pre2, w1, w2, outs=(None, None, None, None)):
+    """-> (dx, dw1, db1, dw2, db2); two launches.  outs: optional buffers for (dw1, db1, dw2, db2)."""
     dev = _dev(x, dy, s, pre1, pre2, w1, w2)
     B, HW, Cn = x.shape
     Cs = w1.shape[0]
     dx = torch.empty_like(x)
-    dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
-    db1 = torch.empty(Cs, dtype=torch.float32, device=dev)
-    db2 = torch.empty(Cn, dtype=torch.float32, device=dev)
+    dw1, dw2 = _out(outs[0], (Cs, Cn), dev), _out(outs[2], (Cn, Cs), dev)
+    db1 = _out(outs[1], (Cs,), dev)
+    db2 = _out(outs[3], (Cn,), dev)
     nbytes = load().ww_se_bwd_scratch_bytes(B, Cn, Cs)
     scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     with _guard(dev):

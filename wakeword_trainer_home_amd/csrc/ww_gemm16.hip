@@ -12,6 +12,7 @@
 // (ds_read_b128, rows r .. r+31, one chunk) sees 16 different (row & 1, swizzled chunk) bank slots in every 16-lane group.
 // blockIdx -> tile is XCD-aware: the 8 column tiles that share an A row panel run on ONE XCD (its L2 fetches the panel once).
 #include "ww_internal.h"
+#include "ww_layers.h"
 #include "ww_act.h"
 
 namespace {
@@ -46,7 +47,8 @@ __device__ __forceinline__ typename H16<H>::x8 frag(const unsigned char *lds_til
 
 template <typename H, typename CT>
 __global__ __launch_bounds__(256, 2) void k_gemm16_nt(const H *__restrict__ A, const H *__restrict__ B, CT *__restrict__ C,
-                                                      long M, long N, long K, int tiles_m, int tiles_n) {
+                                                      long M, long N, long K, int tiles_m, int tiles_n,
+                                                      const float *__restrict__ bias /* per column, nullable */) {
     extern __shared__ __align__(1024) unsigned char lds[];     // [2 buffers][A tile | B tile]
     typedef typename H16<H>::x8 x8;
     typedef typename H16<H>::acc16 acc16;
@@ -105,44 +107,50 @@ __global__ __launch_bounds__(256, 2) void k_gemm16_nt(const H *__restrict__ A, c
         for (int j = 0; j < 2; ++j) {
             const long col = n0 + 64 * wn + 32 * j + r;
             CT *cp = C + (m0 + 64 * wm + 32 * i + 4 * h) * N + col;
+            const float bv = (bias && col < N) ? bias[col] : 0.f;
             if (full) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) cp[(long)((e & 3) + 8 * (e >> 2)) * N] = (CT)acc[i][j][e];
+                for (int e = 0; e < 16; ++e) cp[(long)((e & 3) + 8 * (e >> 2)) * N] = (CT)(acc[i][j][e] + bv);
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const long row = m0 + 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (row < M && col < N) C[row * N + col] = (CT)acc[i][j][e];
+                    if (row < M && col < N) C[row * N + col] = (CT)(acc[i][j][e] + bv);
                 }
             }
         }
 }
 
 template <typename H, typename CT>
-int launch(const void *A, const void *B, void *C, long M, long N, long K, hipStream_t st) {
+int launch(const void *A, const void *B, void *C, long M, long N, long K, const float *bias, hipStream_t st) {
     const int tiles_m = (int)((M + GB_M - 1) / GB_M), tiles_n = (int)((N + GB_N - 1) / GB_N);
     const size_t smem = 4 * TILE_BYTES;
     // every call: the attribute belongs to the (function, device) pair and a process may drive several devices
     WW_HIP(hipFuncSetAttribute((const void *)k_gemm16_nt<H, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL((k_gemm16_nt<H, CT>), dim3(tiles_m * tiles_n), dim3(256), smem, st, (const H *)A, (const H *)B, (CT *)C, M,
-                       N, K, tiles_m, tiles_n);
+                       N, K, tiles_m, tiles_n, bias);
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
 
 }  // namespace
 
-extern "C" int ww_gemm16_nt(ww_ctx *ctx, int dtype, const void *A, const void *B, void *C, int c_f32, long M, long N, long K,
-                            ww_stream_t stream) {
+// the entry point's body, with the optional per-column bias of the callers inside the library (GRU input projections)
+int ww_gemm16_nt_bias(ww_ctx *ctx, int dtype, const void *A, const void *B, void *C, int c_f32, long M, long N, long K,
+                      const float *bias, hipStream_t st) {
     WW_REQUIRE(ctx && A && B && C, WW_E_INVALID, "ww_gemm16_nt: null argument");
     WW_REQUIRE(dtype == WW_ACT_BF16 || dtype == WW_ACT_F16, WW_E_INVALID, "ww_gemm16_nt: dtype %d is not a 16-bit type", dtype);
     WW_REQUIRE(M >= 1 && N >= 1 && K >= 1, WW_E_INVALID, "ww_gemm16_nt: bad shape (%ld,%ld,%ld)", M, N, K);
     WW_REQUIRE(K % GB_K == 0, WW_E_UNSUPPORTED, "ww_gemm16_nt: K=%ld must be a multiple of %d", K, GB_K);
     WW_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, WW_E_INVALID, "ww_gemm16_nt: operands must be 16-byte aligned");
     WW_REQUIRE((M + GB_M - 1) / GB_M * ((N + GB_N - 1) / GB_N) < (1L << 31), WW_E_UNSUPPORTED, "ww_gemm16_nt: too many tiles");
-    hipStream_t st = (hipStream_t)stream;
     ww_prof_scope ps_(ctx, WW_K_LINEAR, st);
     if (dtype == WW_ACT_BF16)
-        return c_f32 ? launch<ww_bf16, float>(A, B, C, M, N, K, st) : launch<ww_bf16, ww_bf16>(A, B, C, M, N, K, st);
-    return c_f32 ? launch<ww_f16, float>(A, B, C, M, N, K, st) : launch<ww_f16, ww_f16>(A, B, C, M, N, K, st);
+        return c_f32 ? launch<ww_bf16, float>(A, B, C, M, N, K, bias, st) : launch<ww_bf16, ww_bf16>(A, B, C, M, N, K, bias, st);
+    return c_f32 ? launch<ww_f16, float>(A, B, C, M, N, K, bias, st) : launch<ww_f16, ww_f16>(A, B, C, M, N, K, bias, st);
+}
+
+extern "C" int ww_gemm16_nt(ww_ctx *ctx, int dtype, const void *A, const void *B, void *C, int c_f32, long M, long N, long K,
+                            ww_stream_t stream) {
+    return ww_gemm16_nt_bias(ctx, dtype, A, B, C, c_f32, M, N, K, nullptr, (hipStream_t)stream);
 }

@@ -15,6 +15,7 @@
 // projection, dX, dW_ih, dW_hh) AND for the per-step products of the recurrence (h and W_hh enter the MFMA as bf16; the hidden
 // state, the gates and every elementwise step stay fp32).  Hidden size 128 only.
 #include "ww_internal.h"
+#include "ww_layers.h"
 #include "ww_act.h"
 #include <algorithm>
 
@@ -360,6 +361,32 @@ __global__ __launch_bounds__(256) void k_dropout_bt(const float *__restrict__ x,
     }
 }
 
+// fp32 -> 16-bit copies of the input projection's two operands in ONE launch: x (M rows of I floats, row stride ldx) -> xh (M, I),
+// w (Nw*I contiguous) -> wh.  I % 4 == 0; a thread moves float4s in batches of four (unconditional, clamped loads).
+template <typename H>
+__global__ __launch_bounds__(256) void k_to16_pair(const float *__restrict__ x, long ldx, long M, int I, const float *__restrict__ w,
+                                                   long nw, H *__restrict__ xh, H *__restrict__ wh) {
+    typedef Act<H> A16;
+    const long I4 = I >> 2, nx4 = M * I4, n4 = nx4 + (nw >> 2);
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4L * gridDim.x * 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = min(i0 + (long)u * gridDim.x * 256, n4 - 1);
+            const float *src = i < nx4 ? x + (i / I4) * ldx + 4 * (i % I4) : w + 4 * (i - nx4);
+            v[u] = *reinterpret_cast<const float4 *>(src);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + (long)u * gridDim.x * 256;
+            if (i < n4) {
+                H *dst = i < nx4 ? xh + 4 * i : wh + 4 * (i - nx4);
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(A16::pack2(v[u].x, v[u].y), A16::pack2(v[u].z, v[u].w));
+            }
+        }
+    }
+}
+
 struct WsLayout { size_t gi, dgh, r, z, n, hn, hp, part, total; };
 constexpr int GRU_SPLITS = 32;
 WsLayout ws_layout(long B, long T, int I) {
@@ -423,7 +450,26 @@ extern "C" int ww_gru_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
     hipStream_t st = (hipStream_t)stream;
     ww_prof_scope ps_(ctx, WW_K_GRU, st);
     // Gi[(b,t)][3H] = x[(b,t)][:] W_ih^T + b_ih for all time steps at once
-    rc = ww_gemm(mode, x, ldx, 1, B * T, w_ih, I, 1, 3 * GH, I, (float *)(w + L.gi), 3 * GH, b_ih, 0, 1, nullptr, st);
+    // input projection of all time steps.  16-bit matrix modes with I a multiple of 64 (the CRNN's 64 conv channels, every
+    // second layer's 256): both operands are rounded ONCE into 16-bit copies (the dGh region of the workspace is idle in the
+    // forward pass) and the product runs on ww_gemm16_nt's 128 x 128 LDS-DMA tiles with b_ih added in its epilogue -- the same
+    // operand roundings as k_gemm's LDS fill, 3-5x faster than its 64 x 64 tiles on fp32 operands at these shapes.
+    const long Mrows = (long)B * T;
+    const size_t xh_bytes = ((size_t)Mrows * I * 2 + 255) & ~(size_t)255, wh_bytes = (size_t)3 * GH * I * 2;
+    if (mode != WW_ACT_F32 && I % 64 == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w_ih) & 15) == 0 &&
+        xh_bytes + wh_bytes <= (size_t)Mrows * 3 * GH * sizeof(float)) {
+        void *xh = w + L.dgh, *wh = w + L.dgh + xh_bytes;
+        const long n4 = Mrows * (I / 4) + 3L * GH * I / 4;
+        const int grid = (int)std::min<long>((n4 + 4 * 256 - 1) / (4 * 256), 4096);
+        if (mode == WW_ACT_BF16)
+            hipLaunchKernelGGL(k_to16_pair<ww_bf16>, dim3(grid), dim3(256), 0, st, x, ldx, Mrows, I, w_ih, 3L * GH * I, (ww_bf16 *)xh, (ww_bf16 *)wh);
+        else
+            hipLaunchKernelGGL(k_to16_pair<ww_f16>, dim3(grid), dim3(256), 0, st, x, ldx, Mrows, I, w_ih, 3L * GH * I, (ww_f16 *)xh, (ww_f16 *)wh);
+        WW_LAUNCH_CHECK();
+        rc = ww_gemm16_nt_bias(ctx, mode, xh, wh, w + L.gi, 1, Mrows, 3 * GH, I, b_ih, st);
+    } else {
+        rc = ww_gemm(mode, x, ldx, 1, B * T, w_ih, I, 1, 3 * GH, I, (float *)(w + L.gi), 3 * GH, b_ih, 0, 1, nullptr, st);
+    }
     if (rc) return rc;
     const size_t smem = (size_t)2 * 5 * GBT * HS_LD * sizeof(float);
     const int y_vec = (ldy % 4 == 0) && (((uintptr_t)y & 15) == 0);

@@ -8,6 +8,18 @@ data-parallel training all-reduces ONE tensor instead of one per parameter: at ~
 import torch
 
 
+def grad_slot(param):
+    """A fresh view of ``param``'s slot in its model's flat gradient bucket, for a backward kernel to write into and RETURN as the
+    gradient -- or None (no bucket, or the parameter already holds a gradient that this backward must be added to).  autograd
+    adopts a returned gradient tensor as ``param.grad`` without copying when nothing else references it and its layout is the
+    parameter's, so the gradient is born in the bucket and ``gather_grads`` has nothing to move (it was three multi-tensor copy
+    launches per step, 142 tensors)."""
+    fn = getattr(param, "_ww_grad_slot", None)
+    if fn is None or param.grad is not None:
+        return None
+    return fn()
+
+
 class FlatBuckets:
     """Mixin for an nn.Module (list it BEFORE nn.Module).  Parameters become views of one flat fp32 tensor in
     ``parameters()`` order, built lazily on first use and rebuilt after ``.to()`` / ``.cuda()`` (``_apply``)."""
@@ -46,6 +58,7 @@ class FlatBuckets:
         views, off = [], 0
         for t in plist:
             views.append(self._fb_grad[off:off + t.numel()].view_as(t))
+            t._ww_grad_slot = (lambda o=off, n=t.numel(), tt=t: self._fb_grad[o:o + n].view_as(tt))      # see grad_slot()
             off += t.numel()
         self._fb_views = views
 
@@ -84,5 +97,7 @@ class FlatBuckets:
         if missing:
             raise RuntimeError(f"gather_grads: {len(missing)} parameter(s) have no gradient (first index {missing[0]}); frozen or "
                                "unused parameters are not supported by the bucketed optimizer step")
-        torch._foreach_copy_(self._fb_views, [p.grad for p in self._fb_plist])
+        todo = [(v, p.grad) for v, p in zip(self._fb_views, self._fb_plist) if p.grad.data_ptr() != v.data_ptr()]
+        if todo:                                    # gradients the backward kernels wrote straight into their slots need no copy
+            torch._foreach_copy_([v for v, _ in todo], [g for _, g in todo])
         return self._fb_grad

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native as nat
+from .flat_buckets import grad_slot
 
 
 class _LinearFn(torch.autograd.Function):
@@ -27,7 +28,8 @@ class _LinearFn(torch.autograd.Function):
         mod = ctx.mod
         dx, dw, db = nat.linear_mfma_bwd(x, weight, pre, dy.contiguous(), act=mod._act, dropout_p=ctx.p, seed=mod.dropout_seed,
                                          step=ctx.step, sample_offset=mod.sample_offset, mode=mod.mode,
-                                         need_dx=ctx.needs_input_grad[0], need_db=ctx.has_bias)
+                                         need_dx=ctx.needs_input_grad[0], need_db=ctx.has_bias,
+                                         dw_out=grad_slot(mod.weight), db_out=grad_slot(mod.bias) if ctx.has_bias else None)
         return dx, dw, db, None, None
 
 

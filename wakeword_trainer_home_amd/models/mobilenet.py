@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native as nat
-from .flat_buckets import FlatBuckets
+from .flat_buckets import FlatBuckets, grad_slot
 from .heads import MobileNetV3Head
 
 SMALL_CONF = ((16, 3, 16, 16, True, "RE", 2), (16, 3, 72, 24, False, "RE", 2), (24, 3, 88, 24, False, "RE", 1),
@@ -161,6 +161,7 @@ class _ConvBNActFn(torch.autograd.Function):
             a, ss, mr = nat.bn_act_fwd(y, bnp, act, y.shape[-1])
         Cn = y.shape[-1]
         ctx.save_for_backward(src, w, y, ss, mr)
+        ctx.params = (w, gamma, beta)          # the Parameter objects themselves: their gradient-bucket slots (grad_slot)
         ctx.meta = (kind, act, mode, bn.training, conv.k, conv.stride, x.shape, Cn)
         return a
 
@@ -168,13 +169,17 @@ class _ConvBNActFn(torch.autograd.Function):
     def backward(ctx, da):
         src, w, y, ss, mr = ctx.saved_tensors
         kind, act, mode, training, k, stride, xshape, Cn = ctx.meta
-        dy, dgamma, dbeta = nat.bn_act_bwd(y, da.contiguous(), ss, mr, act, training, Cn)
+        wp, gamma, beta = ctx.params
+        # parameter gradients are written straight into their slots of the model's flat bucket where there is one (grad_slot)
+        dy, dgamma, dbeta = nat.bn_act_bwd(y, da.contiguous(), ss, mr, act, training, Cn, dgamma_out=grad_slot(gamma),
+                                           dbeta_out=grad_slot(beta))
         if kind == "dw":
-            dx, dw = nat.dwconv_nhwc_bwd(src, w.contiguous(), dy, k, stride, need_dx=ctx.needs_input_grad[0])
+            dx, dw = nat.dwconv_nhwc_bwd(src, w.contiguous(), dy, k, stride, need_dx=ctx.needs_input_grad[0], dw_out=grad_slot(wp))
         else:
             need_dx = kind == "pw" and ctx.needs_input_grad[0]
             w2 = w.reshape(w.shape[0], -1)
-            dx, dw, _ = nat.linear_mfma_bwd(src, w2, None, dy.reshape(-1, Cn), mode=mode, need_dx=need_dx, need_db=False)
+            dx, dw, _ = nat.linear_mfma_bwd(src, w2, None, dy.reshape(-1, Cn), mode=mode, need_dx=need_dx, need_db=False,
+                                            dw_out=grad_slot(wp))
             dx = dx.reshape(xshape) if dx is not None else None
             dw = dw.reshape(w.shape)
         return dx, dw, dgamma, dbeta, None, None, None, None, None
@@ -191,7 +196,7 @@ class _SEFn(torch.autograd.Function):
         B, H, W, Cn = x.shape
         x3 = x.reshape(B, H * W, Cn)
         w1m, w2m = w1.reshape(w1.shape[0], -1), w2.reshape(w2.shape[0], -1)
-        ctx.mode, ctx.xshape = mode, x.shape
+        ctx.mode, ctx.xshape, ctx.params = mode, x.shape, (w1, b1, w2, b2)
         ctx.fused = nat.se_supported(Cn, w1m.shape[0], x3, w1m, w2m)
         if ctx.fused:
             y, s, pre1, pre2 = nat.se_fwd(x3.contiguous(), w1m, b1, w2m, b2)
@@ -208,8 +213,10 @@ class _SEFn(torch.autograd.Function):
         if ctx.fused:
             x3, s, pre1, pre2, w1, w2 = ctx.saved_tensors
             dy3 = dy.contiguous().reshape(x3.shape)
+            w1p, b1, w2p, b2 = ctx.params
             dx, dw1, db1, dw2, db2 = nat.se_bwd(x3.contiguous(), dy3, s, pre1, pre2, w1.reshape(w1.shape[0], -1),
-                                                w2.reshape(w2.shape[0], -1))
+                                                w2.reshape(w2.shape[0], -1),
+                                                outs=(grad_slot(w1p), grad_slot(b1), grad_slot(w2p), grad_slot(b2)))
             return dx.reshape(ctx.xshape), dw1.reshape(w1.shape), db1, dw2.reshape(w2.shape), db2, None
         x3, s, h, pre1, pre2, g, w1, w2 = ctx.saved_tensors
         B, HW, Cn = x3.shape
