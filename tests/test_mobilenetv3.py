@@ -242,18 +242,26 @@ def test_trainer_step_uses_flat_buckets_and_fused_optimizer(tmp_path):
     x = torch.randn(4, 1, 40, 151, generator=torch.Generator().manual_seed(1)).to(DEV)
     y = torch.tensor([0, 1, 1, 0])
     model.train()
+    import copy
+    twin = copy.deepcopy(model)                       # the same step's UNCLIPPED gradients, from a copy that takes no optimizer step
+    tr.criterion(twin(x), y.to(DEV)).backward()
+    unclipped = torch.cat([p.grad.flatten() for p in twin.parameters()]).norm().item()
     tr._step_autograd_async(x, y, 0)
     done = tr._flush_pending()
     assert len(done) == 1 and np.isfinite(done[0][1])
-    grads = [p.grad.detach().clone() for p in model.parameters()]     # autograd's (unclipped) gradients of that step
+    assert abs(tr.last_grad_norm - unclipped) <= 1e-5 * unclipped
+    # the backward kernels wrote the gradients into the flat bucket (p.grad are views of it) and the fused step clipped them THERE,
+    # as clip_grad_norm_ leaves p.grad: what is read back is the clipped gradient, the reported norm is the one before clipping
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(model._fb_plist, model._fb_views))
+    grads = [p.grad.detach().clone() for p in model.parameters()]
+    clip = float(tr.gradient_clip)
+    total = torch.cat([g.flatten() for g in grads]).norm().item()
+    assert tr.last_grad_norm > clip and abs(total - clip) <= 1e-4 * clip
     ref = [torch.nn.Parameter(b.clone()) for b in before]
     for r, g in zip(ref, grads):
         r.grad = g.clone()
-    o = cfg.optimizer
     topt = torch.optim.AdamW(ref, lr=tr.optimizer.param_groups[0]["lr"], betas=tr.optimizer.param_groups[0]["betas"],
                              weight_decay=tr.optimizer.param_groups[0]["weight_decay"])
-    tn = torch.nn.utils.clip_grad_norm_(ref, float(tr.gradient_clip))
     topt.step()
-    assert abs(tr.last_grad_norm - tn.item()) <= 1e-4 * tn.item()
     for p, r in zip(model.parameters(), ref):
         assert (p.detach() - r.detach()).abs().max().item() <= 5e-6

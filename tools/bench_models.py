@@ -2,6 +2,7 @@
 forward, native loss, backward, clip, AdamW -- at batch 4096 (and 512), inputs resident in HBM.  Secondary measurement:
 bench.py's headline line stays BASELINE config 2."""
 import contextlib
+import gc
 import json
 import sys
 import tempfile
@@ -44,11 +45,14 @@ for arch, B, act in CONFIGS:
         step(i)
     torch.cuda.synchronize()
     n = 30 if B <= 1024 else 12
-    t0 = time.perf_counter()
+    gc.collect()
+    gc.disable()          # as timeit does: a generation-2 collection inside the loop is a one-off 50-80 ms host pause (seen: one 76 ms
+    t0 = time.perf_counter()      # step among thirty 2.9 ms ones made "crnn 512 fp16" read 5.3 ms instead of 2.94)
     for i in range(n):
         step(5 + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
+    gc.enable()
     nat.prof_enable(dev, classes)
     tr.use_hip_graph = False                   # the per-class event timing needs host-issued launches
     step(100)

@@ -456,7 +456,8 @@ extern "C" int ww_gru_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
     // operand roundings as k_gemm's LDS fill, 3-5x faster than its 64 x 64 tiles on fp32 operands at these shapes.
     const long Mrows = (long)B * T;
     const size_t xh_bytes = ((size_t)Mrows * I * 2 + 255) & ~(size_t)255, wh_bytes = (size_t)3 * GH * I * 2;
-    if (mode != WW_ACT_F32 && I % 64 == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w_ih) & 15) == 0 &&
+    static const int use_gemm16 = ww_env_int("WW_GRU_GEMM16", 1);      // A/B knob: 0 = the k_gemm path for every shape
+    if (use_gemm16 && mode != WW_ACT_F32 && I % 64 == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w_ih) & 15) == 0 &&
         xh_bytes + wh_bytes <= (size_t)Mrows * 3 * GH * sizeof(float)) {
         void *xh = w + L.dgh, *wh = w + L.dgh + xh_bytes;
         const long n4 = Mrows * (I / 4) + 3L * GH * I / 4;

@@ -5,6 +5,8 @@ autograd nodes (``MobileNetV3Wakeword``) get the same contract from this mixin -
 ``grads_in_bucket()`` -- so ``create_optimizer`` hands them the fused clip+optimizer kernel (``FlatFusedOptimizer``) and
 data-parallel training all-reduces ONE tensor instead of one per parameter: at ~140 parameter tensors
 ``clip_grad_norm_`` + the torch optimizer cost 1.5 ms of host time per step."""
+import weakref
+
 import torch
 
 
@@ -14,10 +16,15 @@ def grad_slot(param):
     adopts a returned gradient tensor as ``param.grad`` without copying when nothing else references it and its layout is the
     parameter's, so the gradient is born in the bucket and ``gather_grads`` has nothing to move (it was three multi-tensor copy
     launches per step, 142 tensors)."""
-    fn = getattr(param, "_ww_grad_slot", None)
-    if fn is None or param.grad is not None:
+    slot = getattr(param, "_ww_grad_slot", None)
+    if slot is None or param.grad is not None:
         return None
-    return fn()
+    ref, idx, off = slot
+    mod = ref()
+    # the slot must still be THIS parameter's (a copied attribute, a rebuilt or dropped bucket: no slot)
+    if mod is None or mod._fb_plist is None or idx >= len(mod._fb_plist) or mod._fb_plist[idx] is not param:
+        return None
+    return mod._fb_grad[off:off + param.numel()].view_as(param)
 
 
 class FlatBuckets:
@@ -58,7 +65,7 @@ class FlatBuckets:
         views, off = [], 0
         for t in plist:
             views.append(self._fb_grad[off:off + t.numel()].view_as(t))
-            t._ww_grad_slot = (lambda o=off, n=t.numel(), tt=t: self._fb_grad[o:o + n].view_as(tt))      # see grad_slot()
+            t._ww_grad_slot = (weakref.ref(self), len(views) - 1, off)      # see grad_slot()
             off += t.numel()
         self._fb_views = views
 
