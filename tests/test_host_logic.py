@@ -373,3 +373,51 @@ def test_bench_self_launch_spawns_ranks_before_touching_the_gpu():
     assert r.returncode != 0
     assert r.stdout.strip() == ""
     assert "needs an MI355X" in r.stderr
+
+
+def test_flat_bucket_gradient_slots_are_adopted_by_autograd_and_owner_checked():
+    """models/flat_buckets.py: a backward function that writes a parameter gradient into ``grad_slot(param)`` and returns that view
+    has it adopted as ``param.grad`` without a copy (``gather_grads`` then moves nothing); a deep copy of the model does not
+    inherit the original's slots; a second backward without zero_grad accumulates instead of overwriting."""
+    import copy
+    import torch.nn as nn
+    from wakeword_trainer_home_amd.models.flat_buckets import FlatBuckets, grad_slot
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x)
+            ctx.w = w
+            return x @ w.T
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            dw, out = g.T @ x, grad_slot(ctx.w)
+            if out is not None:
+                out.copy_(dw)
+                dw = out
+            return g @ ctx.w, dw
+
+    class M(FlatBuckets, nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = nn.Parameter(torch.randn(3, 4)), nn.Parameter(torch.randn(2, 3))
+
+        def forward(self, x):
+            return Fn.apply(Fn.apply(x, self.a), self.b)
+
+    torch.manual_seed(0)
+    m, x = M(), torch.randn(5, 4)
+    _ = m.flat_grad                                              # builds the bucket and the slots
+    m(x).sum().backward()
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(m._fb_plist, m._fb_views))
+    ref = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    assert torch.equal(m.gather_grads(), ref)
+    m(x).sum().backward()                                        # no zero_grad: the slot is taken, autograd accumulates
+    assert torch.allclose(m.flat_grad, 2 * ref)
+    twin = copy.deepcopy(m)
+    assert grad_slot(twin.a) is None                             # no bucket of its own yet, and never the original's
+    _ = twin.flat_grad
+    s = grad_slot(twin.a)
+    assert s.data_ptr() == twin._fb_views[0].data_ptr() != m._fb_views[0].data_ptr()
