@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 10
+#define WW_ABI_VERSION 11
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -340,6 +340,7 @@ int ww_bn_act_bwd(ww_ctx *ctx, const float *x, const float *da, long M, int C, c
  * ww_dwconv_bn_act_fwd: shapes the LDS kernel does not take (more than 128 input pixels per image, C % 4 != 0) and eval mode
  * run ww_dwconv_nhwc_fwd + ww_bn_act_fwd inside.                                                                      */
 int ww_conv1x1_bn_act_fwd(ww_ctx *ctx, int mode, const float *x, const float *w, int M, int K, int N, const ww_bn_t *bn, int act,
+                          const float *residual /* nullable (M,N): a = act(bn(y)) + residual, the block's skip connection */,
                           float *y, float *a, float *ss, float *mr, void *scratch, size_t scratch_bytes, ww_stream_t stream);
 int ww_dwconv_bn_act_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int H, int W, int C, int k, int stride,
                          const ww_bn_t *bn, int act, float *y, float *a, float *ss, float *mr, void *scratch, ww_stream_t stream);

@@ -114,6 +114,10 @@ def test_conv1x1_bn_act_statistics_in_the_gemm_epilogue(M, K, N, act):
     rm3, rv3 = f(rm), f(rv)                                     # (make_bn holds raw pointers: the tensors must outlive the call)
     y2, a2, ss2, _ = nat.conv1x1_bn_act_fwd(xd, wd, nat.make_bn(gm, bt, rm3, rv3, momentum=0.01, eps=1e-3, training=True), act)
     assert torch.equal(a, a2) and torch.equal(ss, ss2)          # fixed-order sums
+    res = torch.randn(M, N, generator=g).to(DEV)                # the inverted-residual skip connection, added in the same pass
+    rm4, rv4 = f(rm), f(rv)
+    _, a3, _, _ = nat.conv1x1_bn_act_fwd(xd, wd, nat.make_bn(gm, bt, rm4, rv4, momentum=0.01, eps=1e-3, training=True), act, residual=res)
+    assert torch.equal(a3, a + res)
 
 
 @pytest.mark.parametrize("B,H,W,C,k,s,act", [(9, 3, 10, 240, 5, 1, 1), (5, 5, 19, 96, 5, 2, 1), (6, 2, 5, 576, 5, 1, 1), (3, 5, 19, 88, 3, 1, 2),

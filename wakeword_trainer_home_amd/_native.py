@@ -14,7 +14,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 BWD_ALL, BWD_LATE, BWD_EARLY = 0, 1, 2
 ACT_F32, ACT_BF16, ACT_F16 = 0, 1, 2
 LOSS_CE, LOSS_FOCAL = 0, 1
@@ -125,7 +125,7 @@ _SIGS = {
     "ww_nhwc_scratch_bytes": (_sz, [_i]),
     "ww_bn_act_fwd": (C.c_int, [_vp, _vp, C.c_long, _i, C.POINTER(BN), _i, _vp, _vp, _vp, _vp, _vp]),
     "ww_bn_act_bwd": (C.c_int, [_vp, _vp, _vp, C.c_long, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "ww_conv1x1_bn_act_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, C.POINTER(BN), _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ww_conv1x1_bn_act_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, C.POINTER(BN), _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ww_dwconv_bn_act_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(BN), _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ww_dwconv_nhwc_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ww_dwconv_nhwc_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -533,10 +533,10 @@ def bn_act_bwd(x, da, ss, mr, act, training, Cn, dgamma_out=None, dbeta_out=None
     return dx, dgamma, dbeta
 
 
-def conv1x1_bn_act_fwd(x, w, bn: BN, act, mode=torch.float32):
+def conv1x1_bn_act_fwd(x, w, bn: BN, act, mode=torch.float32, residual=None):
     """Training-mode conv (x (M,K) @ w (N,K)^T) + BatchNorm + activation with the statistics taken in the GEMM's epilogue.
-    -> (y pre-BN (M,N), a (M,N), ss (2N), mr (2N))."""
-    dev = _dev(x, w)
+    residual (M,N), optional: added to the activated output in the same pass.  -> (y pre-BN (M,N), a (M,N), ss (2N), mr (2N))."""
+    dev = _dev(x, w, residual)
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty((M, N), dtype=torch.float32, device=dev)
@@ -547,8 +547,8 @@ def conv1x1_bn_act_fwd(x, w, bn: BN, act, mode=torch.float32):
     if scratch.numel() < ((M + 63) // 64) * 2 * N:          # very tall and narrow: a scratch of its own size
         scratch = torch.empty(((M + 63) // 64) * 2 * N, dtype=torch.float32, device=dev)
     with _guard(dev):
-        _check(load().ww_conv1x1_bn_act_fwd(ctx(dev), act_code(mode), _p(x), _p(w), M, K, N, C.byref(bn), act, _p(y), _p(a), _p(ss),
-                                            _p(mr), _p(scratch), scratch.numel() * 4, _stream(dev)), "ww_conv1x1_bn_act_fwd")
+        _check(load().ww_conv1x1_bn_act_fwd(ctx(dev), act_code(mode), _p(x), _p(w), M, K, N, C.byref(bn), act, _p(residual), _p(y), _p(a),
+                                            _p(ss), _p(mr), _p(scratch), scratch.numel() * 4, _stream(dev)), "ww_conv1x1_bn_act_fwd")
     return y, a, ss, mr
 
 

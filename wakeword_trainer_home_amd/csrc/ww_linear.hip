@@ -474,10 +474,11 @@ extern "C" int ww_linear_mfma_fwd(ww_ctx *ctx, int mode, const float *x, const f
 
 // Conv2dNormActivation with a 1x1 (or im2col'ed) convolution in training mode: y = x W^T on the matrix cores with the BatchNorm
 // statistics partials written by the GEMM's own epilogue, then the BatchNorm(+activation) apply pass that finishes them
-// (ww_bn_act_from_partials): 2 launches (3 for very tall layers) instead of GEMM + statistics + finish + apply.
+// (ww_bn_act_from_partials): 2 launches (3 for very tall layers) instead of GEMM + statistics + finish + apply.  residual
+// (nullable, (M,N)): the inverted-residual block's input, added to the activated output in the same pass (a = act(bn(y)) + residual).
 extern "C" int ww_conv1x1_bn_act_fwd(ww_ctx *ctx, int mode, const float *x, const float *w, int M, int K, int N, const ww_bn_t *bn,
-                                     int act, float *y, float *a, float *ss, float *mr, void *scratch, size_t scratch_bytes,
-                                     ww_stream_t stream) {
+                                     int act, const float *residual, float *y, float *a, float *ss, float *mr, void *scratch,
+                                     size_t scratch_bytes, ww_stream_t stream) {
     WW_REQUIRE(ctx && x && w && bn && bn->gamma && bn->beta && y && a && ss && mr && scratch, WW_E_INVALID, "ww_conv1x1_bn_act_fwd: null argument");
     int rc = check_dims("ww_conv1x1_bn_act_fwd", mode, M, K, N);
     if (rc) return rc;
@@ -495,7 +496,7 @@ extern "C" int ww_conv1x1_bn_act_fwd(ww_ctx *ctx, int mode, const float *x, cons
         if ((rc = launch_gemm<true, true, true>(mode, A, B, K, y, N, e, st, 1, nullptr, &row_tile))) return rc;
     }
     ww_prof_scope ps_(ctx, WW_K_NHWC, st);
-    return ww_bn_act_from_partials(ctx, y, M, N, bn, act, a, ss, mr, (const float *)scratch, (M + row_tile - 1) / row_tile, st);
+    return ww_bn_act_from_partials(ctx, y, M, N, bn, act, a, ss, mr, (const float *)scratch, (M + row_tile - 1) / row_tile, residual, st);
 }
 
 // K splits of the weight-gradient product dW (N x K) = dpre^T x: its contraction runs over the M rows (batch x pixels), which

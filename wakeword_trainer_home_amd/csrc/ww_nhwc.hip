@@ -270,7 +270,8 @@ __device__ __forceinline__ void bn_group_totals(const float *__restrict__ part, 
 // grid G_r * G_c, block 256: thread = (float4 of the group's channels, row lane)
 __global__ __launch_bounds__(256) void k_bn_act_apply_fin(const float *__restrict__ x, const float *__restrict__ part, int chunks,
                                                           long M, int C, BnTile t, ww_bn_t bn, int act, float *__restrict__ y,
-                                                          float *__restrict__ ss, float *__restrict__ mr) {
+                                                          float *__restrict__ ss, float *__restrict__ mr,
+                                                          const float *__restrict__ res /* nullable: y = act(bn(x)) + res */) {
     __shared__ double redd[256 * 4];
     __shared__ double tot[128];
     __shared__ __align__(16) float scsh[128];
@@ -309,15 +310,19 @@ __global__ __launch_bounds__(256) void k_bn_act_apply_fin(const float *__restric
     const long r0 = rc * t.rows_per_block, r1 = min(M, r0 + t.rows_per_block);
     const size_t col = (size_t)c0 + 4 * cq;
     for (long rb = r0 + rl; rb < r1; rb += 4L * t.R) {
-        float4 v[4];
+        float4 v[4], rv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(x + (size_t)min(rb + (long)u * t.R, r1 - 1) * C + col);
+        for (int u = 0; u < 4; ++u) {
+            const size_t o = (size_t)min(rb + (long)u * t.R, r1 - 1) * C + col;
+            v[u] = *reinterpret_cast<const float4 *>(x + o);
+            rv[u] = res ? *reinterpret_cast<const float4 *>(res + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (rb + (long)u * t.R < r1)
                 *reinterpret_cast<float4 *>(y + (size_t)(rb + (long)u * t.R) * C + col) =
-                    make_float4(act_fwd(act, fmaf(v[u].x, sc.x, sf.x)), act_fwd(act, fmaf(v[u].y, sc.y, sf.y)),
-                                act_fwd(act, fmaf(v[u].z, sc.z, sf.z)), act_fwd(act, fmaf(v[u].w, sc.w, sf.w)));
+                    make_float4(act_fwd(act, fmaf(v[u].x, sc.x, sf.x)) + rv[u].x, act_fwd(act, fmaf(v[u].y, sc.y, sf.y)) + rv[u].y,
+                                act_fwd(act, fmaf(v[u].z, sc.z, sf.z)) + rv[u].z, act_fwd(act, fmaf(v[u].w, sc.w, sf.w)) + rv[u].w);
     }
 }
 
@@ -912,13 +917,13 @@ extern "C" int ww_bn_act_fwd(ww_ctx *ctx, const float *x, long M, int C, const w
 }
 
 // (row chunk, channel group) tiling of k_bn_act_apply_fin: the widest group (16, 8 or 4 channel float4s) whose re-read of the
-// partials stays <= 24 KB per workgroup; CG4 == 0: too many partial rows, take the finish launch instead
+// partials stays <= 32 KB per workgroup; CG4 == 0: too many partial rows, take the finish launch instead
 static BnTile bn_tile(long M, int C, int chunks) {
     BnTile t = {0, 0, 0, 0};
     const int C4 = C / 4;
     for (int cg4 = 16; cg4 >= 4; cg4 >>= 1) {
         const int G_c = (C4 + cg4 - 1) / cg4, CG4 = (C4 + G_c - 1) / G_c;
-        if ((size_t)chunks * 2 * 4 * CG4 * sizeof(float) > 24 * 1024) continue;
+        if ((size_t)chunks * 2 * 4 * CG4 * sizeof(float) > 32 * 1024) continue;
         t.G_c = G_c; t.CG4 = CG4; t.R = 256 / CG4;
         const long G_r = std::max<long>(1, std::min<long>(std::max(1, 1024 / G_c), M / (4L * t.R)));
         t.rows_per_block = (M + G_r - 1) / G_r;
@@ -929,13 +934,13 @@ static BnTile bn_tile(long M, int C, int chunks) {
 // training-mode BatchNorm(+activation) of x (M, C) whose statistics partials -- `chunks` rows of [sum (C) | sum of squares (C)]
 // -- a producer has already written to `part`
 int ww_bn_act_from_partials(ww_ctx *ctx, const float *x, long M, int C, const ww_bn_t *bn, int act, float *y, float *ss, float *mr,
-                            const float *part, int chunks, hipStream_t st) {
+                            const float *part, int chunks, const float *res, hipStream_t st) {
     WW_REQUIRE(C <= 1024 && chunks >= 1, WW_E_UNSUPPORTED, "ww_bn_act_from_partials: C=%d > 1024", C);
-    const bool v4 = vec4_ok(M * C, C, {x, y, part});
+    const bool v4 = vec4_ok(M * C, C, {x, y, part, res});
     const BnTile t = v4 ? bn_tile(M, C, chunks) : BnTile{0, 0, 0, 0};
     if (t.CG4) {
         const int blocks = (int)((M + t.rows_per_block - 1) / t.rows_per_block) * t.G_c;
-        hipLaunchKernelGGL(k_bn_act_apply_fin, dim3(blocks), dim3(256), 0, st, x, part, chunks, M, C, t, *bn, act, y, ss, mr);
+        hipLaunchKernelGGL(k_bn_act_apply_fin, dim3(blocks), dim3(256), 0, st, x, part, chunks, M, C, t, *bn, act, y, ss, mr, res);
         WW_LAUNCH_CHECK();
         return WW_OK;
     }
@@ -947,6 +952,7 @@ int ww_bn_act_from_partials(ww_ctx *ctx, const float *x, long M, int C, const ww
     else
         hipLaunchKernelGGL(k_bn_act_apply, dim3(egrid(M * C)), dim3(256), 0, st, x, ss, M * C, C, act, y);
     WW_LAUNCH_CHECK();
+    if (res) return ww_add_f32(ctx, y, res, (size_t)(M * C), y, (ww_stream_t)st);      // tall layers: the add stays its own pass (in place)
     return WW_OK;
 }
 
@@ -1042,7 +1048,7 @@ extern "C" int ww_dwconv_bn_act_fwd(ww_ctx *ctx, const float *x, const float *w,
         if (k == 3) hipLaunchKernelGGL((k_dwl_conv<3, false, true>), lg, dim3(256), lds, st, x, w, g, l, y, part);
         else hipLaunchKernelGGL((k_dwl_conv<5, false, true>), lg, dim3(256), lds, st, x, w, g, l, y, part);
         WW_LAUNCH_CHECK();
-        return ww_bn_act_from_partials(ctx, y, M, C, bn, act, a, ss, mr, part, groups, st);
+        return ww_bn_act_from_partials(ctx, y, M, C, bn, act, a, ss, mr, part, groups, nullptr, st);
     }
     if ((rc = ww_dwconv_nhwc_fwd(ctx, x, w, B, H, W, C, k, stride, y, stream))) return rc;
     return ww_bn_act_fwd(ctx, y, M, C, bn, act, a, ss, mr, scratch, stream);

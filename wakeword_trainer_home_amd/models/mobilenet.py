@@ -134,7 +134,7 @@ class _ConvBNActFn(torch.autograd.Function):
     three-node form, which is what bounds the step at the per-GPU batch of data-parallel training.  kind: stem | dw | pw."""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, conv, bn, kind, act, mode):
+    def forward(ctx, x, w, gamma, beta, conv, bn, kind, act, mode, residual=None):
         bnp = nat.make_bn(gamma, beta, bn.running_mean, bn.running_var, momentum=bn.momentum, eps=bn.eps, training=bn.training)
         if kind == "stem":
             B, _, H, W = x.shape
@@ -150,8 +150,11 @@ class _ConvBNActFn(torch.autograd.Function):
             if kind == "dw":
                 y, a, ss, mr = nat.dwconv_bn_act_fwd(src, w.contiguous(), conv.k, conv.stride, bnp, act)
             else:
-                y, a, ss, mr = nat.conv1x1_bn_act_fwd(src, w2, bnp, act, mode)
+                # (an inverted-residual block's skip connection is added in the same apply pass)
+                res2 = residual.reshape(-1, w2.shape[0]).contiguous() if residual is not None else None
+                y, a, ss, mr = nat.conv1x1_bn_act_fwd(src, w2, bnp, act, mode, residual=res2)
                 y, a = y.reshape(oshape), a.reshape(oshape)
+                residual = None
             bn._pending_tracked += 1           # host-side count, folded into the buffer when the state is read
         else:
             if kind == "dw":
@@ -159,6 +162,8 @@ class _ConvBNActFn(torch.autograd.Function):
             else:
                 y = nat.linear_mfma_fwd(src, w2, None, mode=mode).reshape(oshape)
             a, ss, mr = nat.bn_act_fwd(y, bnp, act, y.shape[-1])
+        if residual is not None:               # eval mode / depthwise: the add is its own pass
+            a = nat.add_f32(a, residual.contiguous())
         Cn = y.shape[-1]
         ctx.save_for_backward(src, w, y, ss, mr)
         ctx.params = (w, gamma, beta)          # the Parameter objects themselves: their gradient-bucket slots (grad_slot)
@@ -182,7 +187,7 @@ class _ConvBNActFn(torch.autograd.Function):
                                             dw_out=grad_slot(wp))
             dx = dx.reshape(xshape) if dx is not None else None
             dw = dw.reshape(w.shape)
-        return dx, dw, dgamma, dbeta, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, (da if ctx.needs_input_grad[9] else None)
 
 
 class _SEFn(torch.autograd.Function):
@@ -228,16 +233,6 @@ class _SEFn(torch.autograd.Function):
         return dx, dw1.reshape(w1.shape), db1, dw2.reshape(w2.shape), db2, None
 
 
-class _AddFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, a, b):
-        return nat.add_f32(a.contiguous(), b.contiguous())
-
-    @staticmethod
-    def backward(ctx, g):
-        return g, g
-
-
 # ------------------------------------------------------------------------------------------ modules (torchvision's tree)
 class _Conv(nn.Module):
     """Parameter holder shaped like nn.Conv2d(bias=False): ``weight`` (Cout, Cin/groups, k, k)."""
@@ -275,10 +270,10 @@ class ConvBNAct(nn.Sequential):
         super().__init__(_Conv(cin, cout, k, stride, groups), _BN(cout))
         self.act, self.mode, self.stem, self.depthwise = _ACT[act], mode, stem, groups > 1
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         conv, bn = self[0], self[1]
         kind = "stem" if self.stem else ("dw" if self.depthwise else "pw")
-        return _ConvBNActFn.apply(x, conv.weight, bn.weight, bn.bias, conv, bn, kind, self.act, self.mode)
+        return _ConvBNActFn.apply(x, conv.weight, bn.weight, bn.bias, conv, bn, kind, self.act, self.mode, residual)
 
 
 class _FC(nn.Module):
@@ -314,8 +309,12 @@ class InvertedResidual(nn.Module):
         self.use_res_connect = stride == 1 and cin == cout
 
     def forward(self, x):
-        y = self.block(x)
-        return _AddFn.apply(x, y) if self.use_res_connect else y
+        if not self.use_res_connect:
+            return self.block(x)
+        h = x
+        for layer in list(self.block)[:-1]:
+            h = layer(h)
+        return self.block[-1](h, residual=x)       # the projection layer's BatchNorm pass adds the skip connection
 
 
 class _MobileNet(nn.Module):
