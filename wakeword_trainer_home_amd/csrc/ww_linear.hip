@@ -127,7 +127,7 @@ __device__ __forceinline__ typename H16<H>::x8 tr_frag(const H *tile, int ld, in
 // Block tile (64*TM) x 64: 4 wavefronts as 2 x 2, each TM 32x32 MFMA tiles stacked along the rows (TM = 2 for tall
 // problems: twice the MFMA work per staged B byte).  grid: x = column tiles, y = row tiles, z = K splits (partial
 // products go to C + z*split_stride)
-template <int MODE, bool KCA, bool KCB, bool EPI, int TM, int TN>
+template <int MODE, bool KCA, bool KCB, bool EPI, int TM, int TN, int KS = 0>
 __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int K, int k_per_split, float *__restrict__ C,
                                               long ldc, long split_stride, int vecA, int vecB, Epilogue e) {
     constexpr bool BF16 = MODE != 0;
@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
     constexpr int RA = 64 * TM, RB = 64 * TN;
     // K per LDS stage: the bf16 MFMA eats 16 k per instruction, so a 32-deep stage is two MFMAs between barrier pairs --
     // 128 gives eight (64 for the 128 x 128 tile, whose prefetch registers double); the fp32 MFMA eats 2 k: 32 is sixteen
-    constexpr int KT = BF16 ? (TM * TN == 4 ? 64 : GKH) : GK;
+    // KS = 32: the shallow-K form for contractions of <= 32 (a 128-deep stage of a K = 9 / 16 / 24 product -- the MobileNetV3 stem and
+    // its first expansions -- is 75-93 % zero padding that is still fetched, staged and multiplied: 90 us for the stem's 39 MB)
+    constexpr int KT = KS ? KS : (BF16 ? (TM * TN == 4 ? 64 : GKH) : GK);
     constexpr int LDH_KC = KT + 8, LDF_KC = KT + 4;
     constexpr int A_BYTES = BF16 ? (KCA ? RA * LDH_KC : KT * (RA + 8)) * 2 : (KCA ? RA * LDF_KC : KT * (RA + 4)) * 4;
     constexpr int B_BYTES = BF16 ? (KCB ? RB * LDH_KC : KT * (RB + 8)) * 2 : (KCB ? RB * LDF_KC : KT * (RB + 4)) * 4;
@@ -381,14 +383,20 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
     const long sstride = (long)A.rows * ldc;
 #define WW_GEMM_LAUNCH(BF, TM_, TN_) \
     hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, TN_>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e)
+#define WW_GEMM_LAUNCH_K32(BF, TM_) \
+    hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, 1, 32>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e)
+    const bool shallow = K <= 32 && nz == 1 && cfg != 2;       // 16-bit modes: one 32-deep stage instead of a 128-deep one
     if (mode == WW_ACT_BF16) {
-        if (cfg == 2) WW_GEMM_LAUNCH(1, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(1, 2, 1); else WW_GEMM_LAUNCH(1, 1, 1);
+        if (shallow) { if (cfg == 1) WW_GEMM_LAUNCH_K32(1, 2); else WW_GEMM_LAUNCH_K32(1, 1); }
+        else if (cfg == 2) WW_GEMM_LAUNCH(1, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(1, 2, 1); else WW_GEMM_LAUNCH(1, 1, 1);
     } else if (mode == WW_ACT_F16) {
-        if (cfg == 2) WW_GEMM_LAUNCH(2, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(2, 2, 1); else WW_GEMM_LAUNCH(2, 1, 1);
+        if (shallow) { if (cfg == 1) WW_GEMM_LAUNCH_K32(2, 2); else WW_GEMM_LAUNCH_K32(2, 1); }
+        else if (cfg == 2) WW_GEMM_LAUNCH(2, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(2, 2, 1); else WW_GEMM_LAUNCH(2, 1, 1);
     } else {
         if (cfg == 2) WW_GEMM_LAUNCH(0, 2, 2); else if (cfg == 1) WW_GEMM_LAUNCH(0, 2, 1); else WW_GEMM_LAUNCH(0, 1, 1);
     }
 #undef WW_GEMM_LAUNCH
+#undef WW_GEMM_LAUNCH_K32
     WW_LAUNCH_CHECK();
     if (nz > 1) {
         const long n = sstride;
