@@ -367,6 +367,14 @@ int ww_se_fwd(ww_ctx *ctx, const float *x, int B, int HW, int C, int Cs, const f
 int ww_se_bwd(ww_ctx *ctx, const float *x, const float *dy, const float *s, const float *pre1, const float *pre2, const float *w1,
               const float *w2, int B, int HW, int C, int Cs, float *dx, float *dw1, float *db1, float *dw2, float *db2,
               void *scratch, size_t scratch_bytes, ww_stream_t stream);
+/* The one-channel stem of MobileNetV3Wakeword (src/models/architectures.py:94-101 replaces torchvision's first conv by
+ * Conv2d(1, 16, 3, stride 2, padding 1, bias=False)) as a direct convolution: x (B,H,W), w (C,1,3,3), C % 4 == 0, C <= 64.
+ * Forward in training mode = convolution (which leaves the BatchNorm statistics partials) + the finishing apply pass, as
+ * ww_conv1x1_bn_act_fwd; ww_stem3x3s2_bwd_dw is its weight gradient (the input needs none).  scratch: ww_nhwc_scratch_bytes(C). */
+int ww_stem3x3s2_bn_act_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int H, int W, int C, const ww_bn_t *bn, int act,
+                            float *y, float *a, float *ss, float *mr, void *scratch, ww_stream_t stream);
+int ww_stem3x3s2_bwd_dw(ww_ctx *ctx, const float *x, const float *dy, int B, int H, int W, int C, float *dw, void *scratch,
+                        ww_stream_t stream);
 /* 3x3 stride-2 pad-1 patches of a one-channel image (B,H,W) -> (B*ceil(H/2)*ceil(W/2), 9): the stem conv becomes a GEMM */
 int ww_im2col3x3s2(ww_ctx *ctx, const float *x, int B, int H, int W, float *cols, ww_stream_t stream);
 int ww_add_f32(ww_ctx *ctx, const float *a, const float *b, size_t n, float *y, ww_stream_t stream);

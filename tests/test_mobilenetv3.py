@@ -143,6 +143,33 @@ def test_dwconv_bn_act_statistics_from_the_conv_kernel(B, H, W, C, k, s, act):
     assert _rel(rmd.cpu().double(), rm) <= 1e-5 and _rel(rvd.cpu().double(), rv) <= 1e-5
 
 
+@pytest.mark.parametrize("B,H,W,C,act", [(3, 40, 151, 16, 1), (2, 7, 9, 8, 2), (130, 12, 11, 32, 1)])
+def test_stem_direct_convolution_with_batchnorm(B, H, W, C, act):
+    """ww_stem3x3s2_bn_act_fwd / ww_stem3x3s2_bwd_dw (Conv2d(1, C, 3, 2, 1) as a direct convolution whose kernel leaves the
+    BatchNorm partials) against float64 torch: outputs, normalised activations, running statistics, weight gradient."""
+    from wakeword_trainer_home_amd import _native as nat
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(B, 1, H, W, generator=g, dtype=torch.float64)
+    w = (torch.randn(C, 1, 3, 3, generator=g, dtype=torch.float64) * 0.4).requires_grad_(True)
+    gamma, beta = torch.rand(C, generator=g, dtype=torch.float64) + 0.5, torch.randn(C, generator=g, dtype=torch.float64) * 0.3
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    y_ref = Fn.conv2d(x, w, stride=2, padding=1)
+    a_ref = ACTS[act](Fn.batch_norm(y_ref, rm, rv, gamma, beta, training=True, momentum=0.01, eps=1e-3))
+    dy = torch.randn_like(y_ref)
+    (y_ref * dy).sum().backward()
+    f = lambda t: t.detach().float().to(DEV).contiguous()
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).float().contiguous().to(DEV)
+    gm, bt, rmd, rvd = f(gamma), f(beta), torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    xd = f(x[:, 0])
+    y, a, ss, mr = nat.stem3x3s2_bn_act_fwd(xd, f(w), nat.make_bn(gm, bt, rmd, rvd, momentum=0.01, eps=1e-3, training=True), act)
+    assert _rel(y.cpu().double(), nhwc(y_ref).cpu().double()) <= 2e-6
+    assert _rel(a.cpu().double(), nhwc(a_ref).cpu().double()) <= 2e-5
+    assert _rel(rmd.cpu().double(), rm) <= 1e-5 and _rel(rvd.cpu().double(), rv) <= 1e-5
+    dw = nat.stem3x3s2_bwd_dw(xd, nhwc(dy), w.shape)
+    assert _rel(dw.cpu().double(), w.grad) <= 2e-5
+    assert torch.equal(dw, nat.stem3x3s2_bwd_dw(xd, nhwc(dy), w.shape))      # fixed-order sums
+
+
 @pytest.mark.parametrize("B,HW,C,Cs", [(5, 190, 16, 8), (3, 30, 96, 24), (6, 30, 240, 64), (2, 10, 576, 144), (7, 9, 40, 12),
                                        (130, 6, 24, 8), (41, 4, 32, 8), (129, 10, 576, 144), (34, 3, 1024, 256)])
 def test_se_block_one_launch_forward_two_backward(B, HW, C, Cs):

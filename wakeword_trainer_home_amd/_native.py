@@ -136,6 +136,8 @@ _SIGS = {
     "ww_se_bwd_scratch_bytes": (_sz, [_i, _i, _i]),
     "ww_se_fwd": (C.c_int, [_vp, _vp, _i, _i, _i, _i] + [_vp] * 9),
     "ww_se_bwd": (C.c_int, [_vp] * 8 + [_i, _i, _i, _i] + [_vp] * 6 + [_sz, _vp]),
+    "ww_stem3x3s2_bn_act_fwd": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(BN), _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ww_stem3x3s2_bwd_dw": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ww_im2col3x3s2": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ww_add_f32": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "ww_gru_workspace_bytes": (_sz, [_i, _i, _i, _i]),
@@ -663,6 +665,37 @@ def se_bwd(x, dy, s, pre1, pre2, w1, w2, outs=(None, None, None, None)):
         _check(load().ww_se_bwd(ctx(dev), _p(x), _p(dy), _p(s), _p(pre1), _p(pre2), _p(w1), _p(w2), B, HW, Cn, Cs, _p(dx), _p(dw1),
                                 _p(db1), _p(dw2), _p(db2), _p(scratch), nbytes, _stream(dev)), "ww_se_bwd")
     return dx, dw1, db1, dw2, db2
+
+
+def stem_supported(Cn):
+    return Cn % 4 == 0 and 4 <= Cn <= 64
+
+
+def stem3x3s2_bn_act_fwd(x, w, bn: BN, act):
+    """x (B,H,W) one-channel images, w (C,1,3,3): direct 3x3 stride-2 convolution + training-mode BatchNorm + activation.
+    -> (y pre-BN (B,Ho,Wo,C), a, ss, mr)."""
+    dev = _dev(x, w)
+    B, H, W = x.shape
+    Cn = w.shape[0]
+    y = torch.empty((B, (H + 1) // 2, (W + 1) // 2, Cn), dtype=torch.float32, device=dev)
+    a = torch.empty_like(y)
+    ss = torch.empty(2 * Cn, dtype=torch.float32, device=dev)
+    mr = torch.empty(2 * Cn, dtype=torch.float32, device=dev)
+    with _guard(dev):
+        _check(load().ww_stem3x3s2_bn_act_fwd(ctx(dev), _p(x), _p(w), B, H, W, Cn, C.byref(bn), act, _p(y), _p(a), _p(ss), _p(mr),
+                                              _p(nhwc_scratch(Cn, dev)), _stream(dev)), "ww_stem3x3s2_bn_act_fwd")
+    return y, a, ss, mr
+
+
+def stem3x3s2_bwd_dw(x, dy, w_shape, dw_out=None):
+    dev = _dev(x, dy)
+    B, H, W = x.shape
+    Cn = dy.shape[-1]
+    dw = _out(dw_out, tuple(w_shape), dev)
+    with _guard(dev):
+        _check(load().ww_stem3x3s2_bwd_dw(ctx(dev), _p(x), _p(dy), B, H, W, Cn, _p(dw), _p(nhwc_scratch(Cn, dev)), _stream(dev)),
+               "ww_stem3x3s2_bwd_dw")
+    return dw
 
 
 def im2col3x3s2(x):

@@ -855,6 +855,125 @@ __global__ __launch_bounds__(256) void k_scale_pool_bwd(const float *__restrict_
         dx[i] = v;
     }
 }
+// ---- the one-channel 3x3 stride-2 stem (Conv2d(1, C, 3, 2, 1), the first layer of MobileNetV3Wakeword) as a direct convolution.
+// As patches + GEMM (ww_im2col3x3s2 + k_gemm) it was an 11 us gather, a K = 9 matrix product that the 64-wide tiles ran in 39-90 us,
+// and a 14 MB patch tensor kept for the backward; a thread here owns (output pixel, 4 channels), reads its nine input samples
+// (unconditional, clamped; zeroed by a select outside the image) and keeps its 36 weights in registers.  Persistent grid: a
+// thread's channel quad is fixed, so its BatchNorm partial sums / weight-gradient partials accumulate in registers and leave
+// through one fixed-order LDS sum per workgroup.
+struct StemG { int B, H, W, C, Ho, Wo; };
+__device__ __forceinline__ void stem_patch(const float *__restrict__ xb, const StemG &g, int ho, int wo, float (&p)[9]) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hi = 2 * ho + kh - 1, hic = min(max(hi, 0), g.H - 1);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wi = 2 * wo + kw - 1, wic = min(max(wi, 0), g.W - 1);
+            const float v = xb[hic * g.W + wic];
+            p[kh * 3 + kw] = (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? v : 0.f;
+        }
+    }
+}
+// grid = gridDim.x workgroups of 256 = 64 pixel lanes x (C/4 <= 4) ... generally threads = (pixel lane, channel quad): C4 = C/4 quads,
+// 256/C4 pixel lanes.  y (B,Ho,Wo,C); stat_part[block][2C] (nullable).
+__global__ __launch_bounds__(256) void k_stem3x3s2_fwd(const float *__restrict__ x, const float *__restrict__ w, StemG g,
+                                                       float *__restrict__ y, float *__restrict__ stat_part) {
+    __shared__ __align__(16) float4 red[2][256];
+    const int C4 = g.C >> 2, cq = threadIdx.x % C4, lane = threadIdx.x / C4, L = 256 / C4;
+    float wr[4][9];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[e][t] = w[(size_t)(4 * cq + e) * 9 + t];
+    const long P = (long)g.B * g.Ho * g.Wo, HoWo = (long)g.Ho * g.Wo;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), q4 = s4;
+    if (lane < L)
+        for (long p0 = (long)blockIdx.x * L + lane; p0 < P; p0 += 4L * gridDim.x * L) {      // four pixels per trip: 36 loads in flight
+            float pt[4][9];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long p = min(p0 + (long)u * gridDim.x * L, P - 1), b = p / HoWo;
+                const int r = (int)(p - b * HoWo), ho = r / g.Wo, wo = r - ho * g.Wo;
+                stem_patch(x + (size_t)b * g.H * g.W, g, ho, wo, pt[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long p = p0 + (long)u * gridDim.x * L;
+                if (p < P) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) a = fmaf(pt[u][t], wr[e][t], a);
+                        o[e] = a;
+                    }
+                    *reinterpret_cast<float4 *>(y + (size_t)p * g.C + 4 * cq) = make_float4(o[0], o[1], o[2], o[3]);
+                    s4.x += o[0]; s4.y += o[1]; s4.z += o[2]; s4.w += o[3];
+                    q4.x = fmaf(o[0], o[0], q4.x); q4.y = fmaf(o[1], o[1], q4.y); q4.z = fmaf(o[2], o[2], q4.z); q4.w = fmaf(o[3], o[3], q4.w);
+                }
+            }
+        }
+    if (!stat_part) return;
+    red[0][threadIdx.x] = s4; red[1][threadIdx.x] = q4;
+    __syncthreads();
+    if (lane == 0) {
+        double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < L; ++q) {
+            const float4 a = red[0][q * C4 + cq], b = red[1][q * C4 + cq];
+            t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w; t[4] += b.x; t[5] += b.y; t[6] += b.z; t[7] += b.w;
+        }
+        float *o = stat_part + (size_t)blockIdx.x * 2 * g.C + 4 * cq;
+        *reinterpret_cast<float4 *>(o) = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+        *reinterpret_cast<float4 *>(o + g.C) = make_float4((float)t[4], (float)t[5], (float)t[6], (float)t[7]);
+    }
+}
+// dW[c][t] = sum_p dy[p][c] * patch[p][t]: part[block][C*9] (summed over the blocks by the column-sum launch that follows)
+__global__ __launch_bounds__(256) void k_stem3x3s2_dw(const float *__restrict__ x, const float *__restrict__ dy, StemG g,
+                                                      float *__restrict__ part) {
+    __shared__ float red[256][37];
+    const int C4 = g.C >> 2, cq = threadIdx.x % C4, lane = threadIdx.x / C4, L = 256 / C4;
+    const long P = (long)g.B * g.Ho * g.Wo, HoWo = (long)g.Ho * g.Wo;
+    float acc[4][9];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[e][t] = 0.f;
+    if (lane < L)
+        for (long p0 = (long)blockIdx.x * L + lane; p0 < P; p0 += 4L * gridDim.x * L) {      // four pixels per trip
+            float pt[4][9];
+            float4 d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long p = min(p0 + (long)u * gridDim.x * L, P - 1), b = p / HoWo;
+                const int r = (int)(p - b * HoWo), ho = r / g.Wo, wo = r - ho * g.Wo;
+                d[u] = *reinterpret_cast<const float4 *>(dy + (size_t)p * g.C + 4 * cq);
+                stem_patch(x + (size_t)b * g.H * g.W, g, ho, wo, pt[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (p0 + (long)u * gridDim.x * L < P) {
+                    const float dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) acc[e][t] = fmaf(dv[e], pt[u][t], acc[e][t]);
+                }
+        }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[threadIdx.x][e * 9 + t] = acc[e][t];
+    __syncthreads();
+    // C*9 outputs, each the fixed-order sum over the L pixel lanes of its channel quad
+    for (int o = threadIdx.x; o < g.C * 9; o += 256) {
+        const int c = o / 9, t = o - c * 9, q4 = c >> 2, e = c & 3;
+        float sum = 0.f;
+        for (int q = 0; q < L; ++q) sum += red[q * C4 + q4][e * 9 + t];
+        part[(size_t)blockIdx.x * g.C * 9 + o] = sum;
+    }
+}
+
 // 3x3 stride-2 pad-1 patches of a single-channel image: cols (B*Ho*Wo, 9)
 __global__ __launch_bounds__(256) void k_im2col3x3s2(const float *__restrict__ x, int B, int H, int W, int Ho, int Wo,
                                                      float *__restrict__ cols) {
@@ -1147,6 +1266,47 @@ extern "C" int ww_scale_pool_bwd(ww_ctx *ctx, const float *dy, const float *gate
         hipLaunchKernelGGL(k_scale_pool_bwd, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, dy, gate, dpool, B, HW, C, dx);
     WW_LAUNCH_CHECK();
     return WW_OK;
+}
+static int make_stem(const char *who, int B, int H, int W, int C, StemG *g) {
+    WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "%s: bad shape", who);
+    WW_REQUIRE(C >= 4 && (C & 3) == 0 && C <= 64, WW_E_UNSUPPORTED, "%s: C=%d (needs a multiple of 4, at most 64)", who, C);
+    g->B = B; g->H = H; g->W = W; g->C = C; g->Ho = (H + 1) / 2; g->Wo = (W + 1) / 2;
+    return WW_OK;
+}
+constexpr int STEM_BLOCKS = 512;        // persistent grid = rows of BatchNorm / weight-gradient partials
+// Conv2d(1, C, 3, stride 2, padding 1, bias=False) on (B,H,W) one-channel images + training-mode BatchNorm + activation: the direct
+// convolution leaves the statistics partials, ww_bn_act_from_partials finishes and applies them.  scratch: ww_nhwc_scratch_bytes(C).
+extern "C" int ww_stem3x3s2_bn_act_fwd(ww_ctx *ctx, const float *x, const float *w, int B, int H, int W, int C, const ww_bn_t *bn,
+                                       int act, float *y, float *a, float *ss, float *mr, void *scratch, ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && w && bn && bn->gamma && bn->beta && y && a && ss && mr && scratch, WW_E_INVALID, "ww_stem3x3s2_bn_act_fwd: null argument");
+    StemG g;
+    int rc = make_stem("ww_stem3x3s2_bn_act_fwd", B, H, W, C, &g);
+    if (rc) return rc;
+    WW_REQUIRE(bn->training, WW_E_INVALID, "ww_stem3x3s2_bn_act_fwd: training-mode statistics only");
+    WW_REQUIRE((((uintptr_t)y | (uintptr_t)scratch) & 15) == 0, WW_E_INVALID, "ww_stem3x3s2_bn_act_fwd: y / scratch must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    ww_prof_scope ps_(ctx, WW_K_NHWC, st);
+    const long P = (long)B * g.Ho * g.Wo;
+    const int L = 256 / (C / 4), blocks = (int)std::max<long>(1, std::min<long>(STEM_BLOCKS, (P + L - 1) / L));
+    hipLaunchKernelGGL(k_stem3x3s2_fwd, dim3(blocks), dim3(256), 0, st, x, w, g, y, (float *)scratch);
+    WW_LAUNCH_CHECK();
+    return ww_bn_act_from_partials(ctx, y, P, C, bn, act, a, ss, mr, (const float *)scratch, blocks, nullptr, st);
+}
+// weight gradient of the same convolution: dw (C,1,3,3) = sum over pixels of dy (B,Ho,Wo,C) x input patches
+extern "C" int ww_stem3x3s2_bwd_dw(ww_ctx *ctx, const float *x, const float *dy, int B, int H, int W, int C, float *dw, void *scratch,
+                                   ww_stream_t stream) {
+    WW_REQUIRE(ctx && x && dy && dw && scratch, WW_E_INVALID, "ww_stem3x3s2_bwd_dw: null argument");
+    StemG g;
+    int rc = make_stem("ww_stem3x3s2_bwd_dw", B, H, W, C, &g);
+    if (rc) return rc;
+    WW_REQUIRE(((uintptr_t)dy & 15) == 0, WW_E_INVALID, "ww_stem3x3s2_bwd_dw: dy must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    ww_prof_scope ps_(ctx, WW_K_NHWC, st);
+    const long P = (long)B * g.Ho * g.Wo;
+    const int L = 256 / (C / 4), blocks = (int)std::max<long>(1, std::min<long>(STEM_BLOCKS, (P + L - 1) / L));
+    hipLaunchKernelGGL(k_stem3x3s2_dw, dim3(blocks), dim3(256), 0, st, x, dy, g, (float *)scratch);
+    WW_LAUNCH_CHECK();
+    return ww_colsum_rows_small((const float *)scratch, blocks, C * 9, dw, st);
 }
 extern "C" int ww_im2col3x3s2(ww_ctx *ctx, const float *x, int B, int H, int W, float *cols, ww_stream_t stream) {
     WW_REQUIRE(ctx && x && cols && B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "ww_im2col3x3s2: bad argument");

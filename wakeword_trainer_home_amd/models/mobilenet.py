@@ -136,7 +136,13 @@ class _ConvBNActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, gamma, beta, conv, bn, kind, act, mode, residual=None):
         bnp = nat.make_bn(gamma, beta, bn.running_mean, bn.running_var, momentum=bn.momentum, eps=bn.eps, training=bn.training)
-        if kind == "stem":
+        direct_stem = kind == "stem" and bn.training and nat.stem_supported(w.shape[0])
+        if direct_stem:
+            # the one-channel stem as a direct convolution (no patch tensor; its kernel leaves the BatchNorm statistics)
+            B, _, H, W = x.shape
+            src = x.reshape(B, H, W).contiguous()
+            kind = "stem_direct"
+        elif kind == "stem":
             B, _, H, W = x.shape
             src = nat.im2col3x3s2(x.reshape(B, H, W).contiguous())
             w2, oshape = w.reshape(w.shape[0], 9), (B, (H + 1) // 2, (W + 1) // 2, w.shape[0])
@@ -149,6 +155,8 @@ class _ConvBNActFn(torch.autograd.Function):
             # training: the convolution's own kernel leaves the BatchNorm statistics partials and the apply pass finishes them
             if kind == "dw":
                 y, a, ss, mr = nat.dwconv_bn_act_fwd(src, w.contiguous(), conv.k, conv.stride, bnp, act)
+            elif kind == "stem_direct":
+                y, a, ss, mr = nat.stem3x3s2_bn_act_fwd(src, w.contiguous(), bnp, act)
             else:
                 # (an inverted-residual block's skip connection is added in the same apply pass)
                 res2 = residual.reshape(-1, w2.shape[0]).contiguous() if residual is not None else None
@@ -180,6 +188,8 @@ class _ConvBNActFn(torch.autograd.Function):
                                            dbeta_out=grad_slot(beta))
         if kind == "dw":
             dx, dw = nat.dwconv_nhwc_bwd(src, w.contiguous(), dy, k, stride, need_dx=ctx.needs_input_grad[0], dw_out=grad_slot(wp))
+        elif kind == "stem_direct":
+            dx, dw = None, nat.stem3x3s2_bwd_dw(src, dy, w.shape, dw_out=grad_slot(wp))
         else:
             need_dx = kind == "pw" and ctx.needs_input_grad[0]
             w2 = w.reshape(w.shape[0], -1)
