@@ -885,20 +885,20 @@ __global__ __launch_bounds__(256) void k_stem3x3s2_fwd(const float *__restrict__
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int t = 0; t < 9; ++t) wr[e][t] = w[(size_t)(4 * cq + e) * 9 + t];
-    const long P = (long)g.B * g.Ho * g.Wo, HoWo = (long)g.Ho * g.Wo;
+    const uint32_t P = (uint32_t)g.B * g.Ho * g.Wo, HoWo = (uint32_t)g.Ho * g.Wo, stride = gridDim.x * L;   // P < 2^31 (host check)
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), q4 = s4;
     if (lane < L)
-        for (long p0 = (long)blockIdx.x * L + lane; p0 < P; p0 += 4L * gridDim.x * L) {      // four pixels per trip: 36 loads in flight
+        for (uint32_t p0 = blockIdx.x * L + lane; p0 < P; p0 += 4u * stride) {      // four pixels per trip: 36 loads in flight
             float pt[4][9];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const long p = min(p0 + (long)u * gridDim.x * L, P - 1), b = p / HoWo;
+                const uint32_t p = min(p0 + u * stride, P - 1), b = p / HoWo;
                 const int r = (int)(p - b * HoWo), ho = r / g.Wo, wo = r - ho * g.Wo;
                 stem_patch(x + (size_t)b * g.H * g.W, g, ho, wo, pt[u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const long p = p0 + (long)u * gridDim.x * L;
+                const uint32_t p = p0 + u * stride;
                 if (p < P) {
                     float o[4];
 #pragma unroll
@@ -933,26 +933,26 @@ __global__ __launch_bounds__(256) void k_stem3x3s2_dw(const float *__restrict__ 
                                                       float *__restrict__ part) {
     __shared__ float red[256][37];
     const int C4 = g.C >> 2, cq = threadIdx.x % C4, lane = threadIdx.x / C4, L = 256 / C4;
-    const long P = (long)g.B * g.Ho * g.Wo, HoWo = (long)g.Ho * g.Wo;
+    const uint32_t P = (uint32_t)g.B * g.Ho * g.Wo, HoWo = (uint32_t)g.Ho * g.Wo, stride = gridDim.x * L;   // P < 2^31 (host check)
     float acc[4][9];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[e][t] = 0.f;
     if (lane < L)
-        for (long p0 = (long)blockIdx.x * L + lane; p0 < P; p0 += 4L * gridDim.x * L) {      // four pixels per trip
+        for (uint32_t p0 = blockIdx.x * L + lane; p0 < P; p0 += 4u * stride) {      // four pixels per trip
             float pt[4][9];
             float4 d[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const long p = min(p0 + (long)u * gridDim.x * L, P - 1), b = p / HoWo;
+                const uint32_t p = min(p0 + u * stride, P - 1), b = p / HoWo;
                 const int r = (int)(p - b * HoWo), ho = r / g.Wo, wo = r - ho * g.Wo;
                 d[u] = *reinterpret_cast<const float4 *>(dy + (size_t)p * g.C + 4 * cq);
                 stem_patch(x + (size_t)b * g.H * g.W, g, ho, wo, pt[u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (p0 + (long)u * gridDim.x * L < P) {
+                if (p0 + u * stride < P) {
                     const float dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -1271,6 +1271,7 @@ static int make_stem(const char *who, int B, int H, int W, int C, StemG *g) {
     WW_REQUIRE(B >= 1 && H >= 1 && W >= 1, WW_E_INVALID, "%s: bad shape", who);
     WW_REQUIRE(C >= 4 && (C & 3) == 0 && C <= 64, WW_E_UNSUPPORTED, "%s: C=%d (needs a multiple of 4, at most 64)", who, C);
     g->B = B; g->H = H; g->W = W; g->C = C; g->Ho = (H + 1) / 2; g->Wo = (W + 1) / 2;
+    WW_REQUIRE((long)B * g->Ho * g->Wo * C < (1L << 31), WW_E_UNSUPPORTED, "%s: tensor too large for 32-bit indices", who);
     return WW_OK;
 }
 constexpr int STEM_BLOCKS = 512;        // persistent grid = rows of BatchNorm / weight-gradient partials

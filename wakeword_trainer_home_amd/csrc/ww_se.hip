@@ -47,6 +47,7 @@ __device__ __forceinline__ void se_rowdot(const float *__restrict__ W, const flo
     const int grp = tid / GS, gl = tid % GS, ngrp = SE_T / GS;
     for (int j0 = 0; j0 < N; j0 += ngrp) {                        // uniform trip count: whole waves reach the shuffles
         const int j = j0 + grp, jc = min(j, N - 1);
+        const float bj = bias[jc];                                // with the weights, not behind the butterfly (a round trip of its own)
         float4 wv[SE_Q];                                          // unconditional (clamped) loads: a guarded load compiles to a
 #pragma unroll                                                    // branch and a wait each, i.e. one L2 round trip per float4
         for (int q = 0; q < SE_Q; ++q)
@@ -65,9 +66,8 @@ __device__ __forceinline__ void se_rowdot(const float *__restrict__ W, const flo
 #pragma unroll
             for (int i = 0; i < IMG; ++i) acc[i] += __shfl_xor(acc[i], m);
         if (gl == 0 && j < N) {
-            const float b = bias[j];
 #pragma unroll
-            for (int i = 0; i < IMG; ++i) out[i * N + j] = acc[i] + b;
+            for (int i = 0; i < IMG; ++i) out[i * N + j] = acc[i] + bj;
         }
     }
 }
@@ -247,11 +247,20 @@ __global__ __launch_bounds__(SE_T) void k_se_bwd(const float *__restrict__ x, co
     float *hv = gv + IMG * C;
     const int tid = threadIdx.x, b0 = blockIdx.x * IMG, nimg = min(IMG, B - b0);
     const float *xb = x + (size_t)b0 * HW * C, *dyb = dy + (size_t)b0 * HW * C;
+    // the saved pre-activations this thread will need are fetched BEFORE the pooled sums (IMG * C <= 4096, IMG * Cs <= 1024):
+    // behind them each was one more dependent round trip of the workgroup's chain
+    float z2[4], z1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) z2[u] = pre2[(size_t)b0 * C + min(tid + u * SE_T, nimg * C - 1)];
+    if (tid < nimg * Cs) z1 = pre1[(size_t)b0 * Cs + tid];
     se_hwsum<IMG>(xb, dyb, nimg, HW, C, 1.0, dgv, redd, tid);
-    for (int p = tid; p < IMG * C; p += SE_T) {                 // dpre2 = dgate * hardsigmoid'(pre2); the gate itself for dx
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                               // dpre2 = dgate * hardsigmoid'(pre2); the gate itself for dx
+        const int p = tid + u * SE_T;
+        if (p >= IMG * C) break;
         float d = 0.f, g = 0.f;
         if (p < nimg * C) {
-            const float z = pre2[(size_t)b0 * C + p];
+            const float z = z2[u];
             d = dgv[p] * hsig_grad(z);
             g = hsig(z);
             dpre2_out[(size_t)b0 * C + p] = d;
@@ -261,13 +270,13 @@ __global__ __launch_bounds__(SE_T) void k_se_bwd(const float *__restrict__ x, co
     }
     __syncthreads();
     se_wcolsum<IMG>(w2, C, Cs, dgv, hv, red, tid);              // dh[j] = sum_c W2[c][j] dpre2[c]
-    for (int p = tid; p < IMG * Cs; p += SE_T) {                // dpre1 = dh * relu'(pre1)
+    if (tid < IMG * Cs) {                                       // dpre1 = dh * relu'(pre1)   (IMG * Cs <= 1024 = one per thread)
         float d = 0.f;
-        if (p < nimg * Cs) {
-            d = pre1[(size_t)b0 * Cs + p] > 0.f ? hv[p] : 0.f;
-            dpre1_out[(size_t)b0 * Cs + p] = d;
+        if (tid < nimg * Cs) {
+            d = z1 > 0.f ? hv[tid] : 0.f;
+            dpre1_out[(size_t)b0 * Cs + tid] = d;
         }
-        hv[p] = d;
+        hv[tid] = d;
     }
     __syncthreads();
     se_wcolsum<IMG>(w1, Cs, C, hv, dsv, red, tid);              // dpool[c] = sum_j W1[j][c] dpre1[j]
