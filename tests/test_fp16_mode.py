@@ -128,6 +128,7 @@ def test_fp16_graph_replay_is_bit_exact(tmp_path):
         cfg = get_preset("cnn_small_logmel40")
         cfg.training.epochs, cfg.training.batch_size, cfg.optimizer.warmup_epochs = 2, 16, 0
         cfg.optimizer.mixed_precision, cfg.optimizer.amp_dtype, cfg.training.hip_graph = True, "fp16", graph
+        cfg.training.hip_graph_auto = False
         torch.manual_seed(2)
         model = create_model("cnn_small", dropout=0.3, dropout_seed=1)
         t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=tmp_path / str(graph), device=DEV)

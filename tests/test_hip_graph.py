@@ -21,7 +21,7 @@ def _cfg(graph, epochs=2, sched="cosine"):
     cfg.optimizer.scheduler, cfg.optimizer.warmup_epochs = sched, 0
     cfg.optimizer.mixed_precision = True              # bf16 storage: the benched mode
     cfg.model.dropout = 0.3
-    cfg.training.hip_graph = graph
+    cfg.training.hip_graph, cfg.training.hip_graph_auto = graph, False      # the eager leg must stay eager for every model
     cfg.training.checkpoint_frequency = "best_only"
     return cfg
 
@@ -129,3 +129,37 @@ def test_autograd_models_replay_bit_for_bit(tmp_path, arch):
     assert runs[1][0]._graph is not None and runs[0][0]._graph is None
     assert len(runs[1][1]) == 10
     _assert_same(runs[0], runs[1])
+
+
+def test_graph_replay_is_the_default_for_models_that_prefer_it(tmp_path):
+    """``training.hip_graph_auto`` (default on): a model that declares ``prefers_hip_graph`` (mobilenetv3: ~340 short launches per
+    step, host-bound when issued eagerly) trains through the replayed graph with a default config -- and bit-identically to the
+    eager steps it replaces; cnn_small (no preference) stays eager; the switch turns it off."""
+    from tests.golden_util import make_inputs
+    from wakeword_trainer_home_amd.config import get_preset
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    x, y = make_inputs(4, 8 * 5)
+    batches = [(x[8 * i:8 * i + 8], y[8 * i:8 * i + 8]) for i in range(5)]
+    out = {}
+    for name, auto in (("auto", True), ("off", False)):
+        cfg = get_preset("cnn_small_logmel40")
+        cfg.training.epochs, cfg.training.batch_size, cfg.optimizer.warmup_epochs = 1, 8, 0
+        cfg.training.checkpoint_frequency = "best_only"
+        cfg.training.hip_graph_auto = auto
+        assert cfg.training.hip_graph is False
+        torch.manual_seed(5)
+        model = create_model("mobilenetv3", dropout=0.2, dropout_seed=2)
+        t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=tmp_path / name, device=DEV)
+        assert t.use_hip_graph is auto
+        rec = []
+        t.add_callback(type("R", (), {"on_batch_end": lambda self, i, l, a: rec.append(l)})())
+        t.train()
+        assert (t._graph is not None) is auto
+        out[name] = (rec, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    assert out["auto"][0] == out["off"][0]                       # loss trace, float equality
+    for k, v in out["auto"][1].items():
+        assert torch.equal(v, out["off"][1][k]), k
+    cfg = get_preset("cnn_small_logmel40")
+    t = Trainer(create_model("cnn_small"), batches, batches[:1], cfg, checkpoint_dir=tmp_path / "c", device=DEV)
+    assert t.use_hip_graph is False

@@ -27,7 +27,7 @@ if argv:                                      # e.g.  bench_models.py crnn 4096 
 for arch, B, act in CONFIGS:
     cfg = get_preset("cnn_small_logmel40")
     cfg.training.batch_size = B
-    cfg.training.hip_graph = GRAPH
+    cfg.training.hip_graph, cfg.training.hip_graph_auto = GRAPH, False       # the eager line is eager for every model
     torch.manual_seed(0)
     kw = {"act_dtype": act} if arch == "crnn" else {"mode": act}
     model = create_model(arch, dropout=0.3, **kw)

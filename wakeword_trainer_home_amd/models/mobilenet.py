@@ -340,6 +340,7 @@ class _MobileNet(nn.Module):
 
 class MobileNetV3Wakeword(FlatBuckets, nn.Module):
     hip_backed = True
+    prefers_hip_graph = True      # ~340 short launches per step: host-bound when issued eagerly (Trainer: training.hip_graph_auto)
 
     def __init__(self, num_classes: int = 2, pretrained: bool = False, dropout: float = 0.3, input_channels: int = 1,
                  mode="fp32", dropout_seed: int = 0):

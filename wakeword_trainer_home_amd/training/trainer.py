@@ -168,7 +168,11 @@ class Trainer:
         # CU (measured: 1.36 ms per step at full residency, 1.32 at one per CU); 0 = fill the device
         self.input_stage_workgroups = None
         # HIP graph replay of the native step (BASELINE config 5 "hipGraph-captured step"; see _graph_capture)
-        self.use_hip_graph = bool(getattr(config.training, "hip_graph", False))
+        # on when asked for, or unasked for a model that prefers it (replayed steps are bit-identical to eager ones, tests/test_hip_graph.py)
+        # (the unasked form only where the in-graph gradient all-reduce can be captured: no process group, or RCCL -- gloo cannot)
+        capturable = self._dist is None or str(self._dist.get_backend()).lower() == "nccl"
+        self.use_hip_graph = bool(getattr(config.training, "hip_graph", False)) or (
+            bool(getattr(config.training, "hip_graph_auto", True)) and bool(getattr(model, "prefers_hip_graph", False)) and capturable)
         self._graph = None                 # dict: captured graph + its static buffers + host mirror of the control block
         self._graph_seen = None            # feature shape of the last eager step (a shape is captured when it repeats)
         self._eager_native_steps = 0
