@@ -533,9 +533,12 @@ __device__ __forceinline__ void dwl_stage(const float *__restrict__ src, int B, 
             const int b = min(b0 + img, B - 1), c4 = min(c0q + cq, C4 - 1);
             v[u] = *reinterpret_cast<const float4 *>(src + ((size_t)b * npix + pix) * C + 4 * c4);
         }
+        // all four live at once, and the stores unconditional too (a clamped slot is rewritten with its own value): behind a guard
+        // the compiler sinks every load next to its store -- load, wait, store, load ... (seen in the ISA: four round trips per batch)
+        asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[0].w), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[1].z), "+v"(v[1].w),
+                     "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[3].z), "+v"(v[3].w));
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (i0 + 256 * u < n) slab[i0 + 256 * u] = v[u];
+        for (int u = 0; u < 4; ++u) slab[min(i0 + 256 * u, n - 1)] = v[u];
     }
 }
 // BWD = false: y = conv(x);  BWD = true: dx = conv^T(dy).  `in` has (Hi, Wi) pixels per image, `out` (Hq, Wq).
@@ -550,9 +553,20 @@ __global__ __launch_bounds__(256) void k_dwl_conv(const float *__restrict__ in, 
     const int Hi = BWD ? g.Ho : g.H, Wi = BWD ? g.Wo : g.W, Hq = BWD ? g.H : g.Ho, Wq = BWD ? g.W : g.Wo;
     const int gc = blockIdx.x % l.G_c, grp = blockIdx.x / l.G_c, b0 = grp * l.nimg, c0q = gc * l.CC4, C4 = g.C >> 2;
     float4 *wl4 = dwl_lds, *slab = dwl_lds + KK * l.CC4;
-    for (int i = threadIdx.x; i < KK * l.CC4 * 4; i += 256) {          // w (C,1,k,k) -> wl4[tap][cq].{x,y,z,w}
-        const int e = i & 3, cq = (i >> 2) % l.CC4, t = (i >> 2) / l.CC4, c = 4 * (c0q + cq) + e;
-        reinterpret_cast<float *>(wl4)[i] = c < g.C ? w[(size_t)c * KK + t] : 0.f;
+    {   // w (C,1,k,k) -> wl4[tap][cq].{x,y,z,w}: a thread's <= 7 weights (k = 5, 64 channels) as ONE batch of clamped loads
+        const int nw = KK * l.CC4 * 4;
+        float wv[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int i = min((int)threadIdx.x + 256 * u, nw - 1), e = i & 3, cq = (i >> 2) % l.CC4, t = (i >> 2) / l.CC4;
+            wv[u] = w[(size_t)min(4 * (c0q + cq) + e, g.C - 1) * KK + t];
+        }
+        asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]));
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int i = min((int)threadIdx.x + 256 * u, nw - 1), e = i & 3, cq = (i >> 2) % l.CC4;
+            reinterpret_cast<float *>(wl4)[i] = 4 * (c0q + cq) + e < g.C ? wv[u] : 0.f;
+        }
     }
     const int nimg = min(l.nimg, g.B - b0);
     dwl_stage(in, g.B, b0, nimg, Hi * Wi, g.C, c0q, l.CC4, slab);
