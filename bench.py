@@ -166,6 +166,12 @@ def main():
     ap.add_argument("--dp-overlap", action="store_true", help="two gradient buckets (Trainer.dp_overlap)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as a captured HIP graph (Trainer.enable_hip_graph; not the headline line)")
+    ap.add_argument("--passes", type=int, default=3,
+                    help="the timed region (--steps steps) is run this many times; the MEDIAN is reported (SURVEY §8d)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend; gloo exists for tests/ only (the spawner path on a one-GPU box)")
+    ap.add_argument("--share-device0", action="store_true",
+                    help="tests/ only: every rank uses cuda:0 (a one-GPU box rehearsing the N-rank command path)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -196,6 +202,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    if args.share_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     use_dist = world > 1 or args.force_dist
@@ -205,7 +213,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         with _fd1_to_stderr():
-            dist.init_process_group("nccl", device_id=torch.device(dev))
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(dev))
+            else:
+                dist.init_process_group("gloo")
             warm = torch.zeros(1, device=dev)
             dist.all_reduce(warm)                      # communicator (and its banner) are created here
             torch.cuda.synchronize()
@@ -249,11 +260,12 @@ def main():
         wave, y = pool[i % len(pool)]
         staged[i] = trainer._prepare_native(wave, y, i)
 
-    def step(i):
+    def step(i, lookahead=True):
         if i not in staged:
             prepare(i)
         prep = staged.pop(i)
-        prepare(i + 1)                                    # one batch of lookahead, as Trainer.train_epoch does
+        if lookahead:
+            prepare(i + 1)                                # one batch of lookahead, as Trainer.train_epoch does
         for done in trainer._step_native(None, None, i, prepared=prep):   # results arrive one step late
             trainer.state.global_step += 1
             last_done[0] = done
@@ -263,10 +275,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up; the first steps also tell which kernel class dominates
+    def run_steps(first, n):
+        """n whole steps: n input stages (the first one cannot overlap anything, the rest run one batch ahead on the side
+        stream) and n model steps; nothing is launched for a batch that is not consumed."""
+        for j in range(n):
+            step(first + j, lookahead=j < n - 1)
+        for done in trainer._flush_pending():
+            last_done[0] = done
+
+    # warm-up with HIP events on every kernel class; the first steps also tell which class dominates
     nat.prof_enable(dev, None)
-    for i in range(args.warmup):
-        step(i)
+    run_steps(0, args.warmup)
     fence()
     warm = nat.prof_collect(dev)
     # the roofline kernel is the largest class on the step's critical path (the main stream).  The input stage (log-mel,
@@ -282,16 +301,14 @@ def main():
         trainer._features(pool[i % len(pool)][0], training=True, step=i)
     fence()
     alone = nat.prof_collect(dev).get("logmel_specaug", (0.0, 0))
-    nat.prof_enable(dev, [dominant, "logmel_specaug"])
-    extra = 0
+    nat.prof_enable(dev, [])
+    nxt = args.warmup
     if args.graph:
         # the step as ONE replayed HIP graph (Trainer._graph_capture): captured after the next eager step, then two replays
         # to settle.  Graph nodes cannot carry HIP events, so the per-kernel figures below come from the eager warm-up.
-        nat.prof_enable(dev, [])
         trainer.use_hip_graph = True
-        for i in range(4):
-            step(args.warmup + i)
-        extra = 4
+        run_steps(nxt, 4)
+        nxt += 4
         assert trainer._graph is not None, "the HIP graph was not captured"
 
     # the cyclic garbage collector stays out of the timed region, as in timeit: one generation-2 pass over this process's heap
@@ -300,28 +317,42 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + extra + i)
-    for done in trainer._flush_pending():
-        last_done[0] = done
-    fence()
+    # SURVEY §8d protocol: the region of EXACTLY --steps steps is timed --passes times (barrier + synchronize on both
+    # sides of each), no HIP events inside; the median pass is the reported one.
+    pass_dt = []
+    for _ in range(max(1, args.passes)):
+        fence()
+        t0 = time.perf_counter()
+        run_steps(nxt, args.steps)
+        fence()
+        pass_dt.append(time.perf_counter() - t0)
+        nxt += args.steps
+    # per-kernel HIP events: one more pass of the same region with events around the dominant class and the input stage
+    # (on the streams they are launched on), so the event records cost the timed passes nothing
+    ev_dt = None
+    if not args.graph:
+        nat.prof_enable(dev, [dominant, "logmel_specaug"])
+        fence()
+        t0 = time.perf_counter()
+        run_steps(nxt, args.steps)
+        fence()
+        ev_dt = time.perf_counter() - t0
+        nxt += args.steps
     last = None if last_done[0] is None else (last_done[0][1], last_done[0][2])
-    dt = time.perf_counter() - t0
     gc.enable()
     prof = nat.prof_collect(dev) if not args.graph else {k: v for k, v in warm.items()}
     nat.prof_enable(dev, [])
     devices = [torch.cuda.get_device_name(local_rank) + f" (cuda:{local_rank})"]
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor(pass_dt, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)             # per pass: the slowest rank's time
+        pass_dt = [float(v) for v in t.tolist()]
         gathered = [None] * dist.get_world_size()
         dist.all_gather_object(gathered, devices[0])
         devices = gathered
 
     if rank == 0:
+        dt = sorted(pass_dt)[len(pass_dt) // 2]               # median pass
         total = args.batch * world * args.steps
         value = total / dt
         ms, launches = prof.get(dominant, (0.0, 0))
@@ -342,6 +373,8 @@ def main():
         out = {
             "metric": "training samples/sec (16kHz x 1.5s clips)", "value": round(value, 1), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "passes_ms_per_step": [round(v / args.steps * 1e3, 4) for v in pass_dt], "timing": "median of the passes; each "
+            "pass = barrier + synchronize, exactly --steps steps (input stages included), barrier + synchronize",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE config 2: cnn_small + log-mel(40) + SpecAugment, fwd/bwd + clip + AdamW, "
                                    "16 kHz x 1.5 s clips resident in HBM" + (f" + on-GPU RIR({args.rir_len} taps)/noise-mix augmentation "
@@ -360,7 +393,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "launch_us": round(per_launch_s * 1e6, 2), "launches_timed": launches,
                          "timed_in": "eager warm-up steps (nodes of the replayed graph cannot carry HIP events)" if args.graph
-                         else "the timed region",
+                         else f"one more pass of the same {args.steps}-step region right after the timed passes, events on "
+                              f"this class + the input stage only ({ev_dt / args.steps * 1e3:.4f} ms/step with them)",
                          "algorithmic_bytes_per_launch": algo,
                          "step_frac_of_hbm_roofline": round(value / world * step_algo_bytes(esz) / (HBM_PEAK_GBS * 1e9), 4),
                          # the input stage: NOT on the critical path (side stream, one batch ahead), far from both of its

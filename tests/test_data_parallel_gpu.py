@@ -226,3 +226,30 @@ def test_bench_one_rank_rccl_plumbing():
     out = json.loads(lines[0])
     assert out["config"]["ranks_seen"] == 1 and out["config"]["collective"].startswith("nccl")
     assert out["value"] > 0 and np.isfinite(out["config"]["last_loss"])
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_through_its_own_spawner():
+    """``python bench.py --gpus 2`` with no launcher around it: bench.py starts its own ranks (torch.distributed.run, before
+    anything in the parent touches HIP) and relays rank 0's line -- the command path of the SCALE record.  On this one-GPU
+    box both ranks use cuda:0 and the process group is gloo (test-only switches; the driver's runs are nccl, one GPU each)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "64",
+                        "--passes", "2", "--backend", "gloo", "--share-device0"], capture_output=True, text=True, env=env,
+                       timeout=840)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                                   # exactly ONE stdout line: rank 0's record
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2 and len(out["config"]["devices"]) == 2
+    assert out["config"]["global_batch"] == 128 and out["config"]["parallelism"] == "dp2"
+    assert out["steps"] == 4 and out["warmup"] == 2 and len(out["passes_ms_per_step"]) == 2
+    assert out["config"]["collective"].startswith("gloo")
+    assert out["value"] > 0 and np.isfinite(out["config"]["last_loss"])
+    assert "cpu_baseline" not in out                                   # reported at N=1 only
