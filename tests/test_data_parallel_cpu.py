@@ -144,3 +144,78 @@ def test_two_rank_skip_is_a_global_decision(tmp_path):
             continue
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
         assert torch.isfinite(r0["sd"][k]).all(), k
+
+
+def _bucketed_model():
+    from wakeword_trainer_home_amd.models.flat_buckets import FlatBuckets
+
+    class Tiny(FlatBuckets, torch.nn.Module):
+        """A bucketed model whose layers do NOT write their gradients into the bucket (like the recurrent layers of crnn / gru):
+        autograd allocates every .grad outside ``flat_grad``."""
+
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(16 * 24, 8), torch.nn.Linear(8, 2)
+
+        def forward(self, x):
+            return self.b(torch.tanh(self.a(x.flatten(1))))
+    return Tiny()
+
+
+def _worker_bucketed(rank, world, port, out_dir):
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import wakeword_trainer_home_amd.training.trainer as T
+    from wakeword_trainer_home_amd.config import WakewordConfig
+    from oracle.train_step import TorchLoss
+    T.enforce_cuda = lambda: None
+    cfg = WakewordConfig()
+    cfg.training.epochs, cfg.optimizer.warmup_epochs, cfg.training.batch_size = 1, 0, 8
+    cfg.optimizer.optimizer = "sgd"                      # lr-proportional updates: un-averaged gradients show at once
+    torch.manual_seed(100)
+    model = _bucketed_model()
+    x, y = _data()
+    xs, ys = x[rank * 16:(rank + 1) * 16], y[rank * 16:(rank + 1) * 16]
+    batches = [(xs[i:i + 8], ys[i:i + 8]) for i in (0, 8)]
+    t = T.Trainer(model, batches, batches[:1], cfg, checkpoint_dir=Path(out_dir) / f"ckpt{rank}", device="cpu",
+                  criterion=TorchLoss("cross_entropy", eps=0.05))
+    assert hasattr(model, "flat_grad_ext") and not t.native and not t._fused_optimizer
+    t.train_epoch(0)
+    torch.save({"sd": model.state_dict()}, Path(out_dir) / f"rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_model_with_custom_criterion_averages_gradients(tmp_path):
+    """A model with flat buckets whose gradients are born OUTSIDE the bucket, on the reference-style step (custom criterion, torch
+    optimizer): the all-reduce runs on the bucket, and the averaged values must be what clip_gradients and torch.optim read
+    through ``p.grad`` -- otherwise every rank applies its local gradient and the replicas drift apart without an error."""
+    port = _free_port()
+    mp.start_processes(_worker_bucketed, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k              # lock-step replicas
+    from oracle.train_step import TorchLoss
+    torch.manual_seed(100)
+    reps = [_bucketed_model(), _bucketed_model()]
+    reps[1].load_state_dict(reps[0].state_dict())
+    opts = [torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4, nesterov=True) for m in reps]
+    crit = TorchLoss("cross_entropy", eps=0.05)
+    x, y = _data()
+    for step in range(2):
+        for r, m in enumerate(reps):
+            opts[r].zero_grad(set_to_none=True)
+            sl = slice(r * 16 + step * 8, r * 16 + step * 8 + 8)
+            crit(m(x[sl]), y[sl]).backward()
+        for p0, p1 in zip(reps[0].parameters(), reps[1].parameters()):
+            avg = (p0.grad + p1.grad) / 2
+            p0.grad, p1.grad = avg.clone(), avg.clone()
+        for r, m in enumerate(reps):
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+            opts[r].step()
+    for k, v in reps[0].state_dict().items():
+        np.testing.assert_allclose(r0["sd"][k].numpy(), v.numpy(), atol=1e-6, err_msg=k)

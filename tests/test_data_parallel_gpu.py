@@ -119,13 +119,14 @@ def test_native_two_rank_step_equals_sharded_emulation(tmp_path):
         np.testing.assert_allclose(r0["sd"][k].numpy(), v.numpy(), atol=2.5e-3, err_msg=k)
 
 
-def _worker_generic(rank, world, port, out_dir, arch):
+def _worker_generic(rank, world, port, out_dir, arch, overlap="auto"):
     sys.path.insert(0, str(REPO))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from wakeword_trainer_home_amd.models import create_model
     from wakeword_trainer_home_amd.training import Trainer
     cfg = _cfg()
+    cfg.training.dp_overlap = overlap
     torch.manual_seed(70 + rank)                      # different initial weights per rank: the Trainer broadcasts rank 0's
     model = create_model(arch, dropout=0.3, dropout_seed=5)
     wave, y = _data()
@@ -135,9 +136,73 @@ def _worker_generic(rank, world, port, out_dir, arch):
     losses = []
     t.add_callback(type("R", (), {"on_batch_end": lambda self, i, l, a: losses.append(l)})())
     t.train_epoch(0)
-    torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "loss": losses}, Path(out_dir) / f"r{rank}.pt")
+    torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "loss": losses, "collective": t.last_collective},
+               Path(out_dir) / f"r{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_overlapped_bucket_allreduce_equals_the_in_stream_form(tmp_path):
+    """MobileNetV3's 6 MB gradient bucket, 2 ranks: the tail of the bucket (late layers) all-reduced from a
+    post-accumulate-grad hook while the early layers' backward is still running + the head in-stream afterwards, against ONE
+    in-stream all-reduce after the backward.  Same sums in the same order per element: losses and parameters are bit-identical,
+    on both ranks.  "auto" picks the overlapped form for this bucket (>= Trainer.DP_OVERLAP_MIN_BYTES) on eager steps."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    out = {}
+    for name, ov in (("split", True), ("one", False), ("auto", "auto")):
+        d = tmp_path / name
+        d.mkdir()
+        mp.start_processes(_worker_generic, args=(2, _free_port(), str(d), "mobilenetv3", ov), nprocs=2, join=True,
+                           start_method="spawn")
+        out[name] = [torch.load(d / f"r{r}.pt", weights_only=False) for r in range(2)]
+    assert out["split"][0]["collective"] == "overlapped" and out["one"][0]["collective"] == "in-stream"
+    assert out["auto"][0]["collective"] == "overlapped"
+    for r in range(2):
+        assert out["split"][r]["loss"] == out["one"][r]["loss"] == out["auto"][r]["loss"]
+    for k, v in out["one"][0]["sd"].items():
+        if "running" in k or "num_batches" in k:
+            continue
+        assert torch.equal(v, out["split"][0]["sd"][k]) and torch.equal(v, out["split"][1]["sd"][k]), k
+        assert torch.equal(v, out["auto"][0]["sd"][k]), k
+
+
+def _worker_custom_criterion(rank, world, port, out_dir):
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.train_step import TorchLoss
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    cfg = _cfg()
+    torch.manual_seed(70)
+    model = create_model("crnn", dropout=0.0)
+    wave, y = _data()
+    batches = [(wave[16 * s + 8 * rank:16 * s + 8 * rank + 8], y[16 * s + 8 * rank:16 * s + 8 * rank + 8]) for s in range(2)]
+    t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=Path(out_dir) / f"ck{rank}", device="cuda:0",
+                criterion=TorchLoss("cross_entropy", eps=0.05))
+    assert not t.native and not t._async_autograd                      # a foreign criterion: the reference-style step
+    t.train_epoch(0)
+    torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}}, Path(out_dir) / f"r{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_crnn_with_a_custom_criterion_stays_in_lock_step(tmp_path):
+    """crnn is bucketed, but its recurrent layers' gradients are born outside the bucket.  On the reference-style step (user
+    criterion -> clip_gradients + the optimizer read ``p.grad``) the averaged bucket values must be what they read: replicas
+    fed DIFFERENT shards end with identical parameters (round 2 left the local gradients in place: silent divergence)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    mp.start_processes(_worker_custom_criterion, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0 = torch.load(tmp_path / "r0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "r1.pt", weights_only=False)
+    for k in r0["sd"]:
+        if "running" in k or "num_batches" in k:
+            continue
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
 
 
 @pytest.mark.timeout(300)

@@ -163,3 +163,110 @@ def test_graph_replay_is_the_default_for_models_that_prefer_it(tmp_path):
     cfg = get_preset("cnn_small_logmel40")
     t = Trainer(create_model("cnn_small"), batches, batches[:1], cfg, checkpoint_dir=tmp_path / "c", device=DEV)
     assert t.use_hip_graph is False
+
+
+def test_unasked_capture_that_fails_leaves_an_eager_run(tmp_path, caplog):
+    """``hip_graph_auto`` captures a graph nobody asked for; whatever goes wrong in that capture must not end a run that the
+    eager step completes (the reference re-raises only errors of the step itself, trainer.py:214-226).  A model whose forward
+    raises only while the stream is capturing trains to the SAME losses and parameters as with the switch off, the failure is
+    logged once and graph mode is off afterwards.  The same failure under an explicit ``hip_graph=True`` is the caller's to see."""
+    import logging
+    from tests.golden_util import make_inputs
+    from wakeword_trainer_home_amd.config import get_preset
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    x, y = make_inputs(4, 8 * 5)
+    batches = [(x[8 * i:8 * i + 8], y[8 * i:8 * i + 8]) for i in range(5)]
+
+    def build(name, auto, asked=False, poisoned=True):
+        cfg = get_preset("cnn_small_logmel40")
+        cfg.training.epochs, cfg.training.batch_size, cfg.optimizer.warmup_epochs = 1, 8, 0
+        cfg.training.checkpoint_frequency = "best_only"
+        cfg.training.hip_graph_auto, cfg.training.hip_graph = auto, asked
+        torch.manual_seed(5)
+        model = create_model("mobilenetv3", dropout=0.2, dropout_seed=2)
+        if poisoned:
+            inner = model.forward
+
+            def forward(inp):
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("this model cannot be captured")
+                return inner(inp)
+            model.forward = forward
+        t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=tmp_path / name, device=DEV)
+        rec = []
+        t.add_callback(type("R", (), {"on_batch_end": lambda self, i, l, a: rec.append(l)})())
+        return t, model, rec
+
+    t, model, rec = build("auto", True)
+    assert t.use_hip_graph
+    with caplog.at_level(logging.WARNING):
+        t.train()
+    assert len(rec) == 5 and t.use_hip_graph is False and t._graph is None and not t._graphs
+    assert sum("HIP graph capture failed" in r.message for r in caplog.records) == 1
+    t0, model0, rec0 = build("off", False, poisoned=False)
+    t0.train()
+    assert rec == rec0                                            # float equality: the failed capture changed nothing
+    for (k, v), w in zip(model.state_dict().items(), model0.state_dict().values()):
+        assert torch.equal(v, w), k
+    t1, _, _ = build("asked", False, asked=True)
+    with pytest.raises(RuntimeError, match="cannot be captured"):
+        t1.train_epoch(0)
+
+
+def test_full_and_ragged_batch_keep_one_graph_each(tmp_path):
+    """An epoch of full batches plus a ragged last one, several epochs: each shape is captured ONCE (the second time it is seen)
+    and both graphs stay -- the ragged batch does not evict the full batch's graph every epoch.  Still bit-identical to eager."""
+    from tests.golden_util import make_inputs
+    from wakeword_trainer_home_amd.training import Trainer
+    x, y = make_inputs(9, 16 * 3 + 5)
+    cuts = [0, 16, 32, 48, 53]                               # the last batch has 5 samples
+    batches = [(x[a:b], y[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    captures = []
+    orig = Trainer._graph_capture
+
+    def counting(self, feats):
+        captures.append(tuple(feats.shape))
+        return orig(self, feats)
+    eager = _run(tmp_path, False, batches, batches[:1], epochs=4)
+    Trainer._graph_capture = counting
+    try:
+        graph = _run(tmp_path, True, batches, batches[:1], epochs=4)
+    finally:
+        Trainer._graph_capture = orig
+    assert captures == [(16, 1, 40, 151), (5, 1, 40, 151)], captures
+    assert len(graph[0]._graphs) == 2
+    _assert_same(eager, graph)
+
+
+def test_changed_clip_norm_and_weight_decay_reach_the_replays(tmp_path):
+    """``max_norm`` and the optimizer's hyper-parameters are baked into a captured launch by value.  Changing
+    ``trainer.gradient_clip`` / ``param_groups[0]['weight_decay']`` between epochs must act on the following steps as it does on
+    eager ones: the stale graph is dropped and the step re-captured (bit equality with the eager run that honours the change)."""
+    from tests.golden_util import make_inputs
+    from wakeword_trainer_home_amd.models import create_model
+    from wakeword_trainer_home_amd.training import Trainer
+    x, y = make_inputs(2, 16 * 4)
+    batches = [(x[16 * i:16 * i + 16], y[16 * i:16 * i + 16]) for i in range(4)]
+    runs = []
+    for graph in (False, True):
+        cfg = _cfg(graph, epochs=3)
+        torch.manual_seed(7)
+        model = create_model("cnn_small", dropout=cfg.model.dropout, dropout_seed=3)
+        t = Trainer(model, batches, batches[:1], cfg, checkpoint_dir=tmp_path / ("g" if graph else "e"), device=DEV)
+        rec = []
+
+        class Cb:
+            def on_batch_end(self, i, l, a):
+                rec.append((i, l, a))
+
+            def on_epoch_start(self, epoch):
+                if epoch == 1:
+                    t.gradient_clip = 0.05
+                    t.optimizer.param_groups[0]["weight_decay"] = 0.1
+        t.add_callback(Cb())
+        res = t.train()
+        runs.append((t, rec, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                     copy.deepcopy(t.optimizer.state_dict()), res))
+    assert runs[1][0]._graph is not None and runs[1][0]._graph["key"][2] == 0.05
+    _assert_same(runs[0], runs[1])

@@ -421,3 +421,23 @@ def test_flat_bucket_gradient_slots_are_adopted_by_autograd_and_owner_checked():
     _ = twin.flat_grad
     s = grad_slot(twin.a)
     assert s.data_ptr() == twin._fb_views[0].data_ptr() != m._fb_views[0].data_ptr()
+
+
+def test_pending_batch_counts_do_not_survive_a_load_and_modules_pickle():
+    """BatchNorm's num_batches_tracked is counted on the host between state reads (no kernel per layer per step).  Loading a
+    state dict makes the loaded value the truth -- a count pending from earlier steps must not be added to it -- and the hooks
+    are plain functions, so whole-module pickling works."""
+    import pickle
+    from wakeword_trainer_home_amd.models.mobilenet import _BN
+    bn = _BN(4)
+    bn._pending_tracked = 3
+    assert int(bn.state_dict()["num_batches_tracked"]) == 3 and bn._pending_tracked == 0
+    bn._pending_tracked = 5                                   # steps after the save ...
+    sd = {k: v.clone() for k, v in bn.state_dict().items()}   # (flushes: 8)
+    sd["num_batches_tracked"] = torch.tensor(10)
+    bn._pending_tracked = 2                                   # ... and more steps, then a load in the same process
+    bn.load_state_dict(sd)
+    assert bn._pending_tracked == 0 and int(bn.state_dict()["num_batches_tracked"]) == 10
+    clone = pickle.loads(pickle.dumps(bn))
+    clone._pending_tracked = 1
+    assert int(clone.state_dict()["num_batches_tracked"]) == 11

@@ -50,7 +50,8 @@ class TrainingConfig(_Section):
     save_best_only: bool = True
     data_parallel: bool = True                # all-reduce gradients when torch.distributed is initialised
     deferred_metrics: bool = True             # HIP model: read a step's stats while the next step runs
-    dp_overlap: bool = False                  # data parallel: reduce the late layers' gradients under the early layers' backward
+    dp_overlap: Any = "auto"                  # data parallel: reduce the late layers' gradients under the early layers' backward
+                                              # (True / False / "auto" = buckets >= 4 MB of bucketed autograd models, eager steps)
     hip_graph: bool = False                   # HIP model: capture the training step once per batch shape, replay it
     hip_graph_auto: bool = True               # ... and do so unasked for models that declare prefers_hip_graph (mobilenetv3: its
                                               # ~340 short launches per step are host-bound when issued eagerly, 5.2 vs 2.8 ms)

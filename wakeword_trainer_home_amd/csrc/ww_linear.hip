@@ -56,11 +56,28 @@ __device__ __forceinline__ float lin_act_grad(int act, float z) {      // torch'
     if (act == WW_LIN_HARDSIGMOID) return (z > -3.f && z < 3.f) ? (1.f / 6.f) : 0.f;
     return 1.f;
 }
-__device__ __forceinline__ bool drop_keep(const Epilogue &e, long row, int col) {
-    uint32_t rr[4], slo, shi;
-    ww_step_resolve(e.ctl, e.step_lo, e.step_hi, slo, shi);
-    ww_philox(slo, shi, (uint32_t)(e.sample_offset + (uint64_t)row), (WW_TAG_DROPOUT << 24) | (uint32_t)(col >> 2),
-              e.seed_lo, e.seed_hi, rr);
+// The launch-constant Philox inputs of a dropout epilogue (resolved step, seed).  k_gemm keeps them in VECTOR registers on purpose
+// (dropout_ctx_vgpr): as wave-uniform values the compiler hoists the whole 10-round key schedule into ~20 SGPRs, which on top of the
+// GEMM's live kernel arguments overflowed the scalar file (20-60 spilled SGPRs and a scratch segment in the r02 build).
+struct DropCtx { uint32_t slo, shi, klo, khi; };
+__device__ __forceinline__ DropCtx dropout_ctx(const Epilogue &e) {
+    DropCtx d;
+    ww_step_resolve(e.ctl, e.step_lo, e.step_hi, d.slo, d.shi);
+    d.klo = e.seed_lo; d.khi = e.seed_hi;
+    return d;
+}
+__device__ __forceinline__ DropCtx dropout_ctx_vgpr(const Epilogue &e) {
+    const DropCtx u = dropout_ctx(e);
+    DropCtx d;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(d.slo) : "s"(u.slo));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(d.shi) : "s"(u.shi));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(d.klo) : "s"(u.klo));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(d.khi) : "s"(u.khi));
+    return d;
+}
+__device__ __forceinline__ bool drop_keep(const Epilogue &e, const DropCtx &d, long row, int col) {
+    uint32_t rr[4];
+    ww_philox(d.slo, d.shi, (uint32_t)(e.sample_offset + (uint64_t)row), (WW_TAG_DROPOUT << 24) | (uint32_t)(col >> 2), d.klo, d.khi, rr);
     const int q = col & 3;
     const uint32_t rv = q == 0 ? rr[0] : q == 1 ? rr[1] : q == 2 ? rr[2] : rr[3];
     return (uint64_t)rv >= e.drop_thresh;
@@ -127,7 +144,11 @@ __device__ __forceinline__ typename H16<H>::x8 tr_frag(const H *tile, int ld, in
 // Block tile (64*TM) x 64: 4 wavefronts as 2 x 2, each TM 32x32 MFMA tiles stacked along the rows (TM = 2 for tall
 // problems: twice the MFMA work per staged B byte).  grid: x = column tiles, y = row tiles, z = K splits (partial
 // products go to C + z*split_stride)
-template <int MODE, bool KCA, bool KCB, bool EPI, int TM, int TN, int KS = 0>
+// EPI: 0 = plain store; 1 = the dense head's epilogue (bias, pre-activation copy, activation, Philox dropout, accumulate, BatchNorm
+// partials); 2 = the light one (bias, accumulate, BatchNorm partials) -- what the 1x1 convolutions and the recurrent layers' input
+// projections use.  The full epilogue costs ~60 SGPRs of live kernel arguments; compiled into the 18 conv launches of a MobileNetV3
+// step it made the kernel spill SGPRs and carry a scratch segment (r02: 36 B, i.e. scratch set-up at every dispatch).
+template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS = 0>
 __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int K, int k_per_split, float *__restrict__ C,
                                               long ldc, long split_stride, int vecA, int vecB, Epilogue e) {
     constexpr bool BF16 = MODE != 0;
@@ -208,6 +229,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
         }
     }
     C += (long)blockIdx.z * split_stride;
+    DropCtx dctx = {};
+    if (EPI == 1 && e.use_dropout) dctx = dropout_ctx_vgpr(e);
     float ssum[TN], qsum[TN];       // EPI && e.stat_part: this lane's column sums of what it stores
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -222,20 +245,20 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
             const long row = m0 + 32 * TM * rh + 32 * tm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
             if (row >= A.rows) continue;
             float v = acc[tm][tn][reg];
-            if (EPI) {
-                v += bias;
+            if (EPI) v += bias;
+            if (EPI == 1) {
                 if (e.pre) e.pre[row * ldc + col] = v;
                 v = lin_act(e.act, v);
-                if (e.use_dropout) v = drop_keep(e, row, (int)col) ? v * e.drop_scale : 0.f;
+                if (e.use_dropout) v = drop_keep(e, dctx, row, (int)col) ? v * e.drop_scale : 0.f;
             }
-            if (e.accumulate && gridDim.z == 1) v += C[row * ldc + col];
+            if (EPI && e.accumulate && gridDim.z == 1) v += C[row * ldc + col];
             C[row * ldc + col] = v;
-            if (EPI) { ssum[tn] += v; qsum[tn] = fmaf(v, v, qsum[tn]); }
+            if (EPI == 2) { ssum[tn] += v; qsum[tn] = fmaf(v, v, qsum[tn]); }
         }
     }
     // BatchNorm statistics of a 1x1 convolution ride on its epilogue: the tile's column sums (the two half-waves by a shuffle,
     // the two row waves through LDS, fixed order) -> stat_part[row tile][2N]; the layer needs no pass over y for them
-    if (EPI && e.stat_part) {
+    if (EPI == 2 && e.stat_part) {
         __syncthreads();                               // every wave is done with the operand tiles
         float *sred = reinterpret_cast<float *>(lds);  // [4 waves][TN][32][2]
 #pragma unroll
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(256) void k_linear_dpre(const float *__restrict__ d
         const long row = i / N;
         const int col = (int)(i - row * N);
         float g = dy[i];
-        if (e.use_dropout) g = drop_keep(e, row, col) ? g * e.drop_scale : 0.f;
+        if (e.use_dropout) g = drop_keep(e, dropout_ctx(e), row, col) ? g * e.drop_scale : 0.f;
         if (e.act != WW_LIN_NONE) g *= lin_act_grad(e.act, pre[i]);
         dpre[i] = g;
     }
@@ -359,7 +382,7 @@ int make_epilogue(const ww_ctx *ctx, const ww_linear_epi *epi, const float *bias
 }
 
 // splits > 1: partial products into `part` (splits x rows x cols), then summed in fixed order into C
-template <bool KCA, bool KCB, bool EPI>
+template <bool KCA, bool KCB, int EPI>
 int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, float *C, long ldc, const Epilogue &e,
                 hipStream_t st, int splits = 1, float *part = nullptr, int *row_tile_out = nullptr) {
     auto aligned = [](const GemmOperand &o, bool kc) {
@@ -423,10 +446,10 @@ int ww_gemm(int mode, const float *A, long a_srow, long a_sk, int a_rows, const 
     e.accumulate = accumulate;
     const GemmOperand a{A, a_srow, a_sk, a_rows}, b{B, b_srow, b_sk, b_rows};
     const bool kca = a_sk == 1, kcb = b_sk == 1;
-    if (kca && kcb) return launch_gemm<true, true, true>(mode, a, b, K, C, ldc, e, st, splits, part);
-    if (kca && !kcb) return launch_gemm<true, false, true>(mode, a, b, K, C, ldc, e, st, splits, part);
-    if (!kca && kcb) return launch_gemm<false, true, true>(mode, a, b, K, C, ldc, e, st, splits, part);
-    return launch_gemm<false, false, true>(mode, a, b, K, C, ldc, e, st, splits, part);
+    if (kca && kcb) return launch_gemm<true, true, 2>(mode, a, b, K, C, ldc, e, st, splits, part);
+    if (kca && !kcb) return launch_gemm<true, false, 2>(mode, a, b, K, C, ldc, e, st, splits, part);
+    if (!kca && kcb) return launch_gemm<false, true, 2>(mode, a, b, K, C, ldc, e, st, splits, part);
+    return launch_gemm<false, false, 2>(mode, a, b, K, C, ldc, e, st, splits, part);
 }
 // a: rows x (2*cols) row-major; out0 = column sums of the left half, out1 of the right half (one launch)
 __global__ __launch_bounds__(1024) void k_colsum_pair(const float *__restrict__ a, int rows, int cols, float *__restrict__ out0,
@@ -477,7 +500,8 @@ extern "C" int ww_linear_mfma_fwd(ww_ctx *ctx, int mode, const float *x, const f
     if ((rc = make_epilogue(ctx, epi, bias, pre, &e))) return rc;
     const GemmOperand A{x, K, 1, M}, B{w, K, 1, N};
     ww_prof_scope ps_(ctx, WW_K_LINEAR, (hipStream_t)stream);
-    return launch_gemm<true, true, true>(mode, A, B, K, y, N, e, (hipStream_t)stream);
+    if (e.pre || e.act != WW_LIN_NONE || e.use_dropout) return launch_gemm<true, true, 1>(mode, A, B, K, y, N, e, (hipStream_t)stream);
+    return launch_gemm<true, true, 2>(mode, A, B, K, y, N, e, (hipStream_t)stream);
 }
 
 // Conv2dNormActivation with a 1x1 (or im2col'ed) convolution in training mode: y = x W^T on the matrix cores with the BatchNorm
@@ -501,7 +525,7 @@ extern "C" int ww_conv1x1_bn_act_fwd(ww_ctx *ctx, int mode, const float *x, cons
     int row_tile = 64;
     {
         ww_prof_scope ps_(ctx, WW_K_LINEAR, st);
-        if ((rc = launch_gemm<true, true, true>(mode, A, B, K, y, N, e, st, 1, nullptr, &row_tile))) return rc;
+        if ((rc = launch_gemm<true, true, 2>(mode, A, B, K, y, N, e, st, 1, nullptr, &row_tile))) return rc;
     }
     ww_prof_scope ps_(ctx, WW_K_NHWC, st);
     return ww_bn_act_from_partials(ctx, y, M, N, bn, act, a, ss, mr, (const float *)scratch, (M + row_tile - 1) / row_tile, residual, st);
@@ -544,12 +568,12 @@ extern "C" int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const f
     const Epilogue none = {};
     if (dx) {   // dx[m][k] = sum_n dpre[m][n] w[n][k] : A = dpre (n contiguous), B(k, n) = w[n][k] (row index contiguous)
         const GemmOperand A{dpre, N, 1, M}, B{w, 1, K, K};
-        if ((rc = launch_gemm<true, false, false>(mode, A, B, N, dx, K, none, st))) return rc;
+        if ((rc = launch_gemm<true, false, 0>(mode, A, B, N, dx, K, none, st))) return rc;
     }
     {           // dw[n][k] = sum_m dpre[m][n] x[m][k] : A(n, m) = dpre[m][n], B(k, m) = x[m][k]
         const GemmOperand A{dpre, 1, N, N}, B{x, 1, K, K};
         float *part = (float *)scratch + (size_t)M * N;
-        if ((rc = launch_gemm<false, false, false>(mode, A, B, M, dw, K, none, st, dw_splits(M, K, N), part))) return rc;
+        if ((rc = launch_gemm<false, false, 0>(mode, A, B, M, dw, K, none, st, dw_splits(M, K, N), part))) return rc;
     }
     if (db) {
         hipLaunchKernelGGL(k_colsum_any, dim3((N + 63) / 64), dim3(1024), 0, st, dpre, M, N, db);

@@ -98,7 +98,8 @@ class CNNSmallWakeword(nn.Module):
         self.sample_offset = 0       # first global sample index of this rank's shard (data parallel)
         self._pending_tracked = 0
         self._reset_caches()
-        self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_tracked())
+        self.register_state_dict_pre_hook(CNNSmallWakeword._state_dict_hook)     # (a plain function: the module stays picklable)
+        self.register_load_state_dict_pre_hook(CNNSmallWakeword._load_hook)
 
     # ------------------------------------------------------------------ parameter plumbing
     def _bns(self):
@@ -135,6 +136,14 @@ class CNNSmallWakeword(nn.Module):
             for bn in self._bns():
                 bn.num_batches_tracked += self._pending_tracked
             self._pending_tracked = 0
+
+    @staticmethod
+    def _state_dict_hook(module, prefix, keep_vars):
+        module._flush_tracked()
+
+    @staticmethod
+    def _load_hook(module, state_dict, prefix, *args):
+        module._pending_tracked = 0             # the loaded num_batches_tracked is the truth: nothing pending carries over
 
     def _prepare(self, dev):
         tensors = self._ordered()

@@ -265,12 +265,21 @@ class _BN(nn.Module):
         # one training forward = one increment of num_batches_tracked; as a device op that was a kernel launch per BatchNorm
         # layer per step (34 of the step's ~540 launches, 2.5 % of its GPU time) for a number nothing on the device reads
         self._pending_tracked = 0
-        self.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m._flush_tracked())
+        self.register_state_dict_pre_hook(_BN._state_dict_hook)      # (plain functions: the module stays picklable)
+        self.register_load_state_dict_pre_hook(_BN._load_hook)
 
     def _flush_tracked(self):
         if self._pending_tracked:
             self.num_batches_tracked += self._pending_tracked
             self._pending_tracked = 0
+
+    @staticmethod
+    def _state_dict_hook(module, prefix, keep_vars):
+        module._flush_tracked()
+
+    @staticmethod
+    def _load_hook(module, state_dict, prefix, *args):
+        module._pending_tracked = 0             # the loaded num_batches_tracked is the truth: nothing pending carries over
 
 
 class ConvBNAct(nn.Sequential):

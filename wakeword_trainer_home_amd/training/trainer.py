@@ -75,6 +75,8 @@ _SAVE_EVERY = {"every_epoch": 1, "every_5_epochs": 5, "every_10_epochs": 10}
 
 
 class Trainer:
+    MAX_GRAPHS = 2
+
     def __init__(self, model: nn.Module, train_loader: DataLoader, val_loader: DataLoader, config: Any,
                  checkpoint_dir: Optional[Path] = None, device: str = "cuda", criterion: Optional[nn.Module] = None):
         enforce_cuda()
@@ -128,7 +130,13 @@ class Trainer:
         import torch.distributed as dist
         self._dist = dist if (dist.is_available() and dist.is_initialized()
                               and getattr(config.training, "data_parallel", True)) else None
-        self.dp_overlap = bool(getattr(config.training, "dp_overlap", False))   # two gradient buckets, see _step_native
+        # two gradient buckets, the late layers' reduced under the early layers' backward (_step_native: cnn_small's 82 KB bucket,
+        # only when asked; _step_autograd_async: bucketed autograd models -- asked for, or by bucket size when "auto")
+        _ov = getattr(config.training, "dp_overlap", False)
+        self.dp_overlap = _ov is True
+        self._dp_overlap_auto = isinstance(_ov, str) and _ov.lower() == "auto"
+        self._ov = None                    # overlap state of a bucketed autograd model: cut offset, hooks, countdown
+        self.last_collective = None        # which form the last data-parallel step used (bench / probes report it)
         self.world_size = self._dist.get_world_size() if self._dist else 1
         self.rank = self._dist.get_rank() if self._dist else 0
         if self._dist:
@@ -171,10 +179,14 @@ class Trainer:
         # on when asked for, or unasked for a model that prefers it (replayed steps are bit-identical to eager ones, tests/test_hip_graph.py)
         # (the unasked form only where the in-graph gradient all-reduce can be captured: no process group, or RCCL -- gloo cannot)
         capturable = self._dist is None or str(self._dist.get_backend()).lower() == "nccl"
-        self.use_hip_graph = bool(getattr(config.training, "hip_graph", False)) or (
+        self._graph_asked = bool(getattr(config.training, "hip_graph", False))     # asked for: a failing capture raises
+        self.use_hip_graph = self._graph_asked or (
             bool(getattr(config.training, "hip_graph_auto", True)) and bool(getattr(model, "prefers_hip_graph", False)) and capturable)
-        self._graph = None                 # dict: captured graph + its static buffers + host mirror of the control block
-        self._graph_seen = None            # feature shape of the last eager step (a shape is captured when it repeats)
+        # captured graphs by _graph_key (feature shape + everything a capture bakes by value): the full batch and the ragged
+        # last batch of an epoch each keep theirs (MAX_GRAPHS of them; further shapes run eagerly)
+        self._graphs = {}
+        self._graph = None                 # the graph used last: captured graph + static buffers + host mirror of the control block
+        self._graph_seen = {}              # _graph_key -> eager steps seen (a key is captured when it repeats)
         self._eager_native_steps = 0
         self.audio_augmentation = None     # data.augmentation.AudioAugmentation; applied to (B,N) training batches
         logger.info("Trainer initialized (device=%s, model=%s, native=%s, optimizer=%s, scheduler=%s, loss=%s, "
@@ -287,6 +299,13 @@ class Trainer:
             if not self.native:
                 self.model.gather_grads()
             self._reduce_inline(self.model.flat_grad_ext)
+            if not self.native:
+                # the averaged values live in the bucket; a gradient that autograd allocated elsewhere (layers that do not
+                # write into their grad_slot: the recurrent ones) still holds the LOCAL values -- rebind it to its bucket view,
+                # so clip_gradients / torch.optim / a later gather_grads() all see the reduced gradient
+                for v, p_ in zip(self.model._fb_views, self.model._fb_plist):
+                    if p_.grad.data_ptr() != v.data_ptr():
+                        p_.grad = v
             return
         buf, views, params = self._pack_buffer()
         have = [(v, p.grad) for v, p in zip(views, params) if p.grad is not None]
@@ -299,7 +318,56 @@ class Trainer:
         self._reduce_inline(buf)
         torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
 
-    def _vote_skip(self, bad: bool) -> bool:
+    # Overlapped all-reduce for bucketed autograd models (MobileNetV3: one 6.1 MB fp32 bucket).  The bucket is in parameters()
+    # order, so its TAIL holds the late layers, whose gradients the backward produces FIRST.  The tail (>= half of the bytes:
+    # from the last inverted-residual blocks on) is all-reduced on the process group's stream as soon as its last gradient
+    # has been accumulated, under the backward of the early layers; the head follows in-stream after the backward.  Each
+    # hand-off to the collective's stream and back stalls the main queue ~20 us on this stack (profiles/
+    # r02_allreduce_microbench.json), so the split only pays when the collective it hides is longer than that: "auto"
+    # takes it from DP_OVERLAP_MIN_BYTES up (4 MB: ~40 us of hand-offs against >= 40 us of exposed all-reduce at the
+    # ~100 GB/s a direct xGMI reduce-scatter + all-gather moves a bucket of this size; UNMEASURED at N > 1 on this box).
+    DP_OVERLAP_MIN_BYTES = 4 << 20
+
+    def _overlap_wanted(self) -> bool:
+        if not (self._dist and self._fused_optimizer and hasattr(self.model, "flat_grad_ext") and not self.native):
+            return False
+        if self.dp_overlap:
+            return True
+        return self._dp_overlap_auto and self.model.flat_grad.numel() * 4 >= self.DP_OVERLAP_MIN_BYTES
+
+    def _overlap_arm(self):
+        """Hooks on the tail's parameters (once): the LAST of them to receive its gradient starts the tail's all-reduce."""
+        plist, views = self.model._fb_plist, self.model._fb_views
+        if self._ov is not None and self._ov["ptr"] == self.model.flat_param.data_ptr():
+            return self._ov
+        total, acc, first = self.model.flat_grad.numel(), 0, len(plist)
+        for i in range(len(plist) - 1, -1, -1):                    # smallest tail holding at least half of the elements
+            acc += plist[i].numel()
+            first = i
+            if 2 * acc >= total:
+                break
+        ov = {"ptr": self.model.flat_param.data_ptr(), "first": first, "cut": total - acc, "left": 0, "handles": [],
+              "n_tail": len(plist) - first, "hooks": [], "armed": False}
+
+        def hook(param, _ov=ov, _self=self):
+            if not _ov["armed"]:
+                return
+            _ov["left"] -= 1
+            if _ov["left"] == 0:                                  # the tail is complete: gather what was born outside, reduce
+                ext = _self.model.flat_grad_ext
+                with torch.no_grad():
+                    todo = [(v, q) for v, q in zip(views[_ov["first"]:], plist[_ov["first"]:]) if q.grad.data_ptr() != v.data_ptr()]
+                    if todo:
+                        torch._foreach_copy_([v for v, _ in todo], [q.grad for _, q in todo])
+                        for v, q in todo:
+                            q.grad = v                            # gather_grads() after the backward must not copy them again
+                _ov["handles"].append(_self._reduce_start(ext[_ov["cut"]:]))     # incl. the found_inf slot behind the bucket
+        for q in plist[first:]:
+            ov["hooks"].append(q.register_post_accumulate_grad_hook(hook))
+        self._ov = ov
+        return ov
+
+
         """Reference-style step in data-parallel mode: the ranks agree BEFORE the gradient all-reduce whether this batch is
         skipped (a non-finite loss or an exception in the forward pass on one rank), so no rank is left waiting in a
         collective its peers never enter."""
@@ -475,7 +543,7 @@ class Trainer:
         eager ones (tests/test_hip_graph.py)."""
         dev = torch.device(self.device)
         B = feats.shape[0]
-        g = {"in_shape": tuple(feats.shape), "act": self._graph_mode_key()}
+        g = {"in_shape": tuple(feats.shape), "act": self._graph_mode_key(), "key": self._graph_key(feats.shape)}
         g["feats_cur"] = torch.zeros(feats.shape, dtype=torch.float32, device=dev)
         g["tgt_cur"] = torch.zeros(B, dtype=torch.int64, device=dev)
         g["ctl"] = nat.step_ctl_new(dev, step=0, lr=get_learning_rate(self.optimizer), parity=0)
@@ -529,12 +597,16 @@ class Trainer:
         # buffers the graph's nodes point at but that were allocated outside its memory pool: keep them alive with it
         g["keepalive"] = [self.model.flat_grad_ext, self.model.flat_param, self.criterion.last_stats] + self._host_bufs
         g["keepalive"] += [slot["buf"] for m in self.model.modules() if hasattr(m, "_ws") for slot in m._ws.values()]
+        self._graphs[g["key"]] = g
         self._graph = g
         logger.info("HIP graph captured for the native step (features %s)", g["in_shape"])
 
     def _step_native_graph(self, feats, targets, idx, batch_idx):
         """Replay the captured step on this batch (its input stage has been waited for on the current stream)."""
         g = self._graph
+        if self.model.flat_param.data_ptr() != self.optimizer._flat_ptr:      # the check an eager optimizer.step() makes
+            raise nat.NativeError("the model's parameter bucket moved after the optimizer was created "
+                                  "(model.to(...) / dtype change): create the optimizer afterwards")
         g["feats_cur"].copy_(feats)
         g["tgt_cur"].copy_(targets)
         # host mirror of the control block: rewritten only when it would be wrong (lr change, eager step in between)
@@ -572,22 +644,60 @@ class Trainer:
         return tuple((m.act if isinstance(m, CNNSmallWakeword) else None, str(getattr(m, "mode", None)))
                      for m in self.model.modules() if isinstance(m, CNNSmallWakeword) or hasattr(m, "mode"))
 
+    def _graph_key(self, shape):
+        """Everything a captured step bakes BY VALUE: feature shape, storage / matrix modes, the clip norm, the optimizer's
+        hyper-parameters other than lr (lr, the Philox step and the slot parity live in the device control block), the loss
+        hyper-parameters, and where the parameter bucket is.  A change of any of them makes the next step eager and the one
+        after it a fresh capture, exactly as an eager step would honour the change."""
+        def plain(d, skip=()):
+            return tuple(sorted((k, tuple(v) if isinstance(v, (tuple, list)) else v) for k, v in d.items()
+                                if k not in skip and isinstance(v, (int, float, bool, str, tuple, list, type(None)))))
+        groups = tuple(plain(g, skip=("params", "lr", "initial_lr")) for g in self.optimizer.param_groups)
+        crit = plain({k: v for k, v in vars(self.criterion).items() if k in ("_eps", "_alpha", "_gamma", "smoothing", "alpha", "gamma")})
+        flat = getattr(self.model, "flat_param", None)
+        return (tuple(shape), self._graph_mode_key(), float(self.gradient_clip), groups, type(self.criterion).__name__, crit,
+                None if flat is None else flat.data_ptr())
+
     def _graph_step_or_capture(self, feats, targets, step_index, batch_idx):
-        """Graph mode of a sync-free step: replay when a graph for this feature shape exists, else None (the caller runs
-        the eager step; ``_graph_after_eager`` then captures a shape the second time it is seen)."""
-        g = self._graph
-        if g is not None and self.use_hip_graph and tuple(feats.shape) == g["in_shape"] and g["act"] == self._graph_mode_key():
-            return self._step_native_graph(feats, targets, step_index, batch_idx)
-        return None
+        """Graph mode of a sync-free step: replay when a graph for this key (shape + baked values) exists, else None (the
+        caller runs the eager step; ``_graph_after_eager`` then captures a key the second time it is seen)."""
+        if not (self.use_hip_graph and self._graphs):
+            return None
+        g = self._graphs.get(self._graph_key(feats.shape))
+        if g is None:
+            return None
+        self._graph = g
+        return self._step_native_graph(feats, targets, step_index, batch_idx)
 
     def _graph_after_eager(self, feats):
         if not (self.use_hip_graph and self._fused_optimizer):
             return
-        shape = tuple(feats.shape)
-        if self._graph is None or self._graph["in_shape"] != shape or self._graph["act"] != self._graph_mode_key():
-            if self._graph_seen == shape:
-                self._graph_capture(feats)         # second batch of this shape: workspaces, tables and buckets are warm
-            self._graph_seen = shape
+        key = self._graph_key(feats.shape)
+        if key in self._graphs:
+            return
+        seen = self._graph_seen.get(key, 0)
+        self._graph_seen[key] = seen + 1
+        if seen == 0:
+            return                                 # second batch with this key: workspaces, tables and buckets are warm
+        # graphs whose baked values went stale (same shape, other clip norm / hyper-parameters / bucket) are dropped first
+        for k in [k for k in self._graphs if k[0] == key[0]]:
+            del self._graphs[k]
+        if len(self._graphs) >= self.MAX_GRAPHS:
+            return                                 # the frequent shapes have theirs; this one stays eager
+        try:
+            self._graph_capture(feats)
+        except Exception as e:                     # noqa: BLE001
+            if self._graph_asked:
+                raise                              # hip_graph=True was asked for: its failure is the caller's to see
+            # an UNASKED capture (hip_graph_auto) must never end a run the eager step completes: log once, stay eager.
+            # (_graph_capture's finally block has restored the optimizer parity, the BatchNorm counters, the control-block
+            # binding and the gradient views; the step that preceded the attempt ran eagerly and is complete.)
+            logger.warning("HIP graph capture failed (%s: %s); continuing with eager steps", type(e).__name__, e)
+            self.use_hip_graph = False
+            self._graphs.clear()
+            self._graph = None
+            self.optimizer.zero_grad(set_to_none=True)     # gradients of the aborted capture may live in its dropped pool
+            torch.cuda.synchronize(self.device)
 
     def _step_autograd_async(self, inputs, targets, batch_idx):
         """Training step of a HIP-backed autograd model without host reads: forward / native loss / backward through
@@ -607,8 +717,15 @@ class Trainer:
         self.criterion.found_inf_out = flag
         if self.loss_scale is not None:
             self.criterion.loss_scale_slot = self.optimizer.scale_slot
-        self.criterion(self.model(inputs), targets).backward()     # no reference to the autograd graph survives this line: a
-        stats = self.criterion.last_stats                          # later graph capture needs fresh AccumulateGrad nodes
+        ov = self._overlap_arm() if self._overlap_wanted() else None
+        if ov is not None:
+            ov["left"], ov["handles"], ov["armed"] = ov["n_tail"], [], True
+        try:
+            self.criterion(self.model(inputs), targets).backward()     # no reference to the autograd graph survives this line: a
+        finally:                                                       # later graph capture needs fresh AccumulateGrad nodes
+            if ov is not None:
+                ov["armed"] = False
+        stats = self.criterion.last_stats
         if self._host_bufs is None:
             self._host_bufs = [torch.empty(nat.STEP_STATS_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)]
         # two pinned records, alternating: the fused optimizer's slot parity picks one (the same rule a graph replay follows)
@@ -619,7 +736,13 @@ class Trainer:
             # update + the 48-byte statistics record in one launch -- as the native cnn_small step does
             self.model.gather_grads()
             if self._dist:
-                self._reduce_inline(self.model.flat_grad_ext)
+                if ov is not None and ov["handles"]:
+                    self._reduce_inline(self.model.flat_grad_ext[:ov["cut"]])      # the head, in-stream
+                    self._reduce_finish(ov["handles"])                             # the tail has been running since mid-backward
+                    self.last_collective = "overlapped"
+                else:
+                    self._reduce_inline(self.model.flat_grad_ext)
+                    self.last_collective = "in-stream"
             self.optimizer.step(max_norm=max(float(self.gradient_clip), 0.0), stats=stats, stats_host=buf, gathered=True,
                                 found_inf_extra=flag, loss_scale=self.loss_scale)
         else:
