@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 11
+#define WW_ABI_VERSION 12
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -410,6 +410,26 @@ int ww_gru_fwd(ww_ctx *ctx, int mode /* WW_ACT_F32 | WW_ACT_BF16: matrix type of
 int ww_gru_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *dy, long ldy,
                const float *dh_n, int B, int T, int I, int H, int reverse, void *ws, size_t ws_bytes, float *dx, long lddx,
                int accumulate_dx, float *dw_ih, float *dw_hh, float *db_ih, float *db_hh, float *dh0, ww_stream_t stream);
+
+/* Both directions of a bidirectional layer (nn.GRU(bidirectional=True), architectures.py:228-235) with ONE recurrent launch per
+ * pass: the persistent kernel runs direction 0 (t = 0..T-1) and direction 1 (t = T-1..0) as the two rows of its grid -- twice
+ * the resident workgroups of a per-direction launch, no second stream, so a captured HIP graph keeps the concurrency that two
+ * streams give an eager step.  y / dy: (B,T,2H) with row stride ldy >= 2H, direction d owns columns [d*H, (d+1)*H).  Each
+ * direction has its own workspace (ww_gru_workspace_bytes, 256-byte aligned, kept from forward to backward).  Backward-only
+ * members may be NULL in the forward call and vice versa; h0 / h_n / dh_n / dh0 are nullable.  dx = sum over both directions. */
+typedef struct ww_gru_dir {
+    const float *w_ih, *w_hh, *b_ih, *b_hh;      /* nn.GRU layout: (3H,I), (3H,H), (3H), (3H); gate order r|z|n */
+    const float *h0;                             /* (B,H) initial state or NULL (zeros) */
+    float *h_n;                                  /* (B,H) final state out, or NULL */
+    void *ws;
+    const float *dh_n;                           /* backward: gradient of h_n, or NULL */
+    float *dw_ih, *dw_hh, *db_ih, *db_hh;        /* backward: parameter gradients (written) */
+    float *dh0;                                  /* backward: gradient of h0 out, or NULL */
+} ww_gru_dir;
+int ww_gru_bidir_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const ww_gru_dir *dir /* [2] */, int B, int T, int I, int H,
+                     float *y, long ldy, size_t ws_bytes, ww_stream_t stream);
+int ww_gru_bidir_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const ww_gru_dir *dir /* [2] */, const float *dy, long ldy,
+                     int B, int T, int I, int H, size_t ws_bytes, float *dx, long lddx, ww_stream_t stream);
 
 /* Fused clip + optimizer step on flat fp32 buckets.  Replaces, for one step, the reference's
  * clip_gradients(...) ; optimizer.step()  (src/training/trainer.py:185-193) with torch.optim's own update rules

@@ -14,7 +14,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 BWD_ALL, BWD_LATE, BWD_EARLY = 0, 1, 2
 ACT_F32, ACT_BF16, ACT_F16 = 0, 1, 2
 LOSS_CE, LOSS_FOCAL = 0, 1
@@ -59,6 +59,12 @@ class OptimCfg(C.Structure):
 
 
 OPT_ADAM, OPT_ADAMW, OPT_SGD = 0, 1, 2
+
+
+class GruDir(C.Structure):
+    """ww_gru_dir: one direction of a bidirectional GRU layer (include/wwhip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("w_ih", "w_hh", "b_ih", "b_hh", "h0", "h_n", "ws", "dh_n", "dw_ih", "dw_hh", "db_ih",
+                                          "db_hh", "dh0")]
 
 
 class StepCtl(C.Structure):
@@ -142,6 +148,8 @@ _SIGS = {
     "ww_add_f32": (C.c_int, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "ww_gru_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ww_gru_fwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_long, _vp, _vp, _sz, _vp]),
+    "ww_gru_bidir_fwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _i, _i, _i, _i, _vp, C.c_long, _sz, _vp]),
+    "ww_gru_bidir_bwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, C.c_long, _i, _i, _i, _i, _sz, _vp, C.c_long, _vp]),
     "ww_gru_bwd": (C.c_int, [_vp, _i, _vp, C.c_long, _vp, _vp, _vp, C.c_long, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp, C.c_long, _i,
                              _vp, _vp, _vp, _vp, _vp, _vp]),
     "ww_clip_optim_step": (C.c_int, [_vp, C.POINTER(OptimCfg), _vp, _vp, _vp, _vp, _sz, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -758,6 +766,56 @@ def gru_bwd(x, w_ih, w_hh, dy, dh_n, ws, reverse=False, dx=None, accumulate_dx=F
                                  B, T, I, H, int(reverse), _p(ws), ws.numel() * 4, _p(dx), lddx, int(accumulate_dx),
                                  _p(dw_ih), _p(dw_hh), _p(db_ih), _p(db_hh), _p(dh0), _stream(dev)), "ww_gru_bwd")
     return dw_ih, dw_hh, db_ih, db_hh, dh0
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def gru_bidir_fwd(x, params, y, ws, mode=torch.float32):
+    """Both directions of a bidirectional layer, ONE recurrent launch: x (B,T,I); params = [(w_ih, w_hh, b_ih, b_hh)] x 2
+    (forward, reverse); y (B,T,2H) written; ws = two gru_workspace tensors.  -> [h_n forward, h_n reverse], each (B,H)."""
+    dev = _dev(*params[0], *params[1], ws[0], ws[1])
+    _dev_rows(x, y)
+    B, T, I = x.shape
+    H = params[0][1].shape[1]
+    ldx, ldy = _bt_rows(x, "x"), _bt_rows(y, "y")
+    if tuple(y.shape) != (B, T, 2 * H) or any(tuple(p[0].shape) != (3 * H, I) or tuple(p[1].shape) != (3 * H, H) for p in params):
+        raise ValueError("GRU parameter / output shapes do not match (w_ih (3H,I), w_hh (3H,H), y (B,T,2H))")
+    h_n = [torch.empty((B, H), dtype=torch.float32, device=dev) for _ in range(2)]
+    keep = [[t.contiguous() for t in p] for p in params]
+    dirs = (GruDir * 2)()
+    for k in range(2):
+        dirs[k].w_ih, dirs[k].w_hh, dirs[k].b_ih, dirs[k].b_hh = (t.data_ptr() for t in keep[k])
+        dirs[k].h_n, dirs[k].ws = h_n[k].data_ptr(), ws[k].data_ptr()
+    with _guard(dev):
+        _check(load().ww_gru_bidir_fwd(ctx(dev), act_code(mode), _p(x), ldx, C.byref(dirs), B, T, I, H, _p(y), ldy,
+                                       min(ws[0].numel(), ws[1].numel()) * 4, _stream(dev)), "ww_gru_bidir_fwd")
+    return h_n
+
+
+def gru_bidir_bwd(x, params, dy, dh_n, ws, dx=None, mode=torch.float32):
+    """Backward of gru_bidir_fwd: dy (B,T,2H) or None, dh_n = [(B,H) | None] x 2; dx (B,T,I) written when given.
+    -> [(dw_ih, dw_hh, db_ih, db_hh)] x 2."""
+    dev = _dev(params[0][0], params[1][0], ws[0], ws[1])
+    _dev_rows(x, dy, dx)
+    B, T, I = x.shape
+    H = params[0][1].shape[1]
+    ldx = _bt_rows(x, "x")
+    ldy = _bt_rows(dy, "dy") if dy is not None else 2 * H
+    lddx = _bt_rows(dx, "dx") if dx is not None else I
+    keep = [[p[0].contiguous(), p[1].contiguous()] for p in params]
+    grads = [(torch.empty_like(p[0]), torch.empty_like(p[1]), torch.empty(3 * H, dtype=torch.float32, device=dev),
+              torch.empty(3 * H, dtype=torch.float32, device=dev)) for p in params]
+    dirs = (GruDir * 2)()
+    for k in range(2):
+        dirs[k].w_ih, dirs[k].w_hh = keep[k][0].data_ptr(), keep[k][1].data_ptr()
+        dirs[k].ws, dirs[k].dh_n = ws[k].data_ptr(), _ptr(dh_n[k])
+        dirs[k].dw_ih, dirs[k].dw_hh, dirs[k].db_ih, dirs[k].db_hh = (g.data_ptr() for g in grads[k])
+    with _guard(dev):
+        _check(load().ww_gru_bidir_bwd(ctx(dev), act_code(mode), _p(x), ldx, C.byref(dirs), _p(dy), ldy, B, T, I, H,
+                                       min(ws[0].numel(), ws[1].numel()) * 4, _p(dx), lddx, _stream(dev)), "ww_gru_bidir_bwd")
+    return grads
 
 
 def step_ctl_new(dev, step=0, lr=0.0, parity=0):

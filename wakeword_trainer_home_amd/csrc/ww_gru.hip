@@ -46,14 +46,24 @@ template <bool FAST> __device__ __forceinline__ float gate_tanh(float x) {
 }
 
 struct GruSaved { float *r, *z, *n, *hn, *hp; };    // (B*T, 128) each: gates, W_hn h + b_hn, h_{t-1}
+// per-direction arguments of the recurrent kernels: gridDim.y = 2 runs BOTH directions of a bidirectional layer in one launch
+// (blockIdx.y picks the set) -- twice the resident workgroups, no second stream, and a captured HIP graph keeps the concurrency
+struct GruFwdDir { const float *gi, *w_hh, *b_hh, *h0; float *y, *hn_out; GruSaved sv; int reverse; };
+struct GruBwdDir { const float *w_hh, *dy, *dhn; GruSaved sv; float *dgi, *dgh, *dh0, *bias_part; int reverse; };
+__device__ __forceinline__ GruSaved pick(bool second, const GruSaved &a, const GruSaved &b) {
+    return GruSaved{second ? b.r : a.r, second ? b.z : a.z, second ? b.n : a.n, second ? b.hn : a.hn, second ? b.hp : a.hp};
+}
 
-// grid ceil(B/16), block 512 = 8 waves; wave w owns hidden units [16w, 16w+16).  BF16: h and W_hh enter the MFMA as bf16
+// grid (ceil(B/16), directions), block 512 = 8 waves; wave w owns hidden units [16w, 16w+16).  BF16: h and W_hh enter the MFMA as bf16
 // (v_mfma_f32_16x16x32_bf16, 12 instead of 96 matrix instructions per step); h itself, the gates and the update stay fp32.
 template <int MODE>
-__global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, const float *__restrict__ w_hh,
-                                                 const float *__restrict__ b_hh, const float *__restrict__ h0, int B, int T,
-                                                 int reverse, float *__restrict__ y, long ldy, long bsy,
-                                                 float *__restrict__ hn_out, GruSaved sv, int y_vec) {
+__global__ __launch_bounds__(512) void k_gru_fwd(GruFwdDir d0, GruFwdDir d1, int B, int T, long ldy, long bsy, int y_vec) {
+    const bool second = blockIdx.y != 0;
+    const float *__restrict__ gi = second ? d1.gi : d0.gi, *__restrict__ w_hh = second ? d1.w_hh : d0.w_hh;
+    const float *__restrict__ b_hh = second ? d1.b_hh : d0.b_hh, *__restrict__ h0 = second ? d1.h0 : d0.h0;
+    float *__restrict__ y = second ? d1.y : d0.y, *__restrict__ hn_out = second ? d1.hn_out : d0.hn_out;
+    const GruSaved sv = pick(second, d0.sv, d1.sv);
+    const int reverse = second ? d1.reverse : d0.reverse;
     constexpr bool BF16 = MODE != 0;
     typedef typename ModeH<MODE>::type H;
     typedef typename H16<H>::x8 bf16x8;
@@ -185,10 +195,14 @@ __global__ __launch_bounds__(512) void k_gru_fwd(const float *__restrict__ gi, c
 
 // same decomposition; wave w owns OUTPUT units [16w,16w+16) of dh_{t-1} = dh*z + dGh W_hh
 template <int MODE>
-__global__ __launch_bounds__(512) void k_gru_bwd(const float *__restrict__ w_hh, const float *__restrict__ dy, long ldy,
-                                                 long bsy, const float *__restrict__ dhn, int B, int T, int reverse,
-                                                 GruSaved sv, float *__restrict__ dgi, float *__restrict__ dgh,
-                                                 float *__restrict__ dh0, float *__restrict__ bias_part, int dy_vec) {
+__global__ __launch_bounds__(512) void k_gru_bwd(GruBwdDir d0, GruBwdDir d1, long ldy, long bsy, int B, int T, int dy_vec) {
+    const bool second = blockIdx.y != 0;
+    const float *__restrict__ w_hh = second ? d1.w_hh : d0.w_hh, *__restrict__ dy = second ? d1.dy : d0.dy;
+    const float *__restrict__ dhn = second ? d1.dhn : d0.dhn;
+    const GruSaved sv = pick(second, d0.sv, d1.sv);
+    float *__restrict__ dgi = second ? d1.dgi : d0.dgi, *__restrict__ dgh = second ? d1.dgh : d0.dgh;
+    float *__restrict__ dh0 = second ? d1.dh0 : d0.dh0, *__restrict__ bias_part = second ? d1.bias_part : d0.bias_part;
+    const int reverse = second ? d1.reverse : d0.reverse;
     constexpr bool BF16 = MODE != 0;
     typedef typename ModeH<MODE>::type H;
     typedef typename H16<H>::x8 bf16x8;
@@ -437,6 +451,99 @@ extern "C" size_t ww_gru_workspace_bytes(int B, int T, int I, int H) {
     return ws_layout(B, T, I).total;
 }
 
+// ---- host side: a layer = 1 or 2 directions.  Per direction: the input projection GEMM, then ONE recurrent launch for all
+// directions (gridDim.y), then (backward) the weight-gradient / bias / dX products per direction on the same stream.
+namespace {
+struct FwdDirHost { const float *w_ih, *w_hh, *b_ih, *b_hh, *h0; float *y, *h_n; char *ws; int reverse; };
+struct BwdDirHost { const float *w_ih, *w_hh, *dy, *dh_n; char *ws; float *dw_ih, *dw_hh, *db_ih, *db_hh, *dh0; int reverse; };
+
+int gru_project(ww_ctx *ctx, int mode, const float *x, long ldx, const FwdDirHost &d, const WsLayout &L, int B, int T, int I,
+                hipStream_t st) {
+    // Gi[(b,t)][3H] = x[(b,t)][:] W_ih^T + b_ih for all time steps at once.  16-bit matrix modes with I a multiple of 64 (the
+    // CRNN's 64 conv channels, every second layer's 256): both operands are rounded ONCE into 16-bit copies (the dGh region of
+    // the workspace is idle in the forward pass) and the product runs on ww_gemm16_nt's 128 x 128 LDS-DMA tiles with b_ih added
+    // in its epilogue -- the same operand roundings as k_gemm's LDS fill, 3-5x faster than its 64 x 64 tiles at these shapes.
+    char *w = d.ws;
+    const long Mrows = (long)B * T;
+    const size_t xh_bytes = ((size_t)Mrows * I * 2 + 255) & ~(size_t)255, wh_bytes = (size_t)3 * GH * I * 2;
+    static const int use_gemm16 = ww_env_int("WW_GRU_GEMM16", 1);      // A/B knob: 0 = the k_gemm path for every shape
+    if (use_gemm16 && mode != WW_ACT_F32 && I % 64 == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)d.w_ih) & 15) == 0 &&
+        xh_bytes + wh_bytes <= (size_t)Mrows * 3 * GH * sizeof(float)) {
+        void *xh = w + L.dgh, *wh = w + L.dgh + xh_bytes;
+        const long n4 = Mrows * (I / 4) + 3L * GH * I / 4;
+        const int grid = (int)std::min<long>((n4 + 4 * 256 - 1) / (4 * 256), 4096);
+        if (mode == WW_ACT_BF16)
+            hipLaunchKernelGGL(k_to16_pair<ww_bf16>, dim3(grid), dim3(256), 0, st, x, ldx, Mrows, I, d.w_ih, 3L * GH * I, (ww_bf16 *)xh, (ww_bf16 *)wh);
+        else
+            hipLaunchKernelGGL(k_to16_pair<ww_f16>, dim3(grid), dim3(256), 0, st, x, ldx, Mrows, I, d.w_ih, 3L * GH * I, (ww_f16 *)xh, (ww_f16 *)wh);
+        WW_LAUNCH_CHECK();
+        return ww_gemm16_nt_bias(ctx, mode, xh, wh, w + L.gi, 1, Mrows, 3 * GH, I, d.b_ih, st);
+    }
+    return ww_gemm(mode, x, ldx, 1, B * T, d.w_ih, I, 1, 3 * GH, I, (float *)(w + L.gi), 3 * GH, d.b_ih, 0, 1, nullptr, st);
+}
+
+int gru_layer_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const FwdDirHost *d, int nd, int B, int T, int I, long ldy,
+                  hipStream_t st) {
+    const WsLayout L = ws_layout(B, T, I);
+    int rc;
+    for (int k = 0; k < nd; ++k)
+        if ((rc = gru_project(ctx, mode, x, ldx, d[k], L, B, T, I, st))) return rc;
+    GruFwdDir a[2];
+    int y_vec = ldy % 4 == 0;
+    for (int k = 0; k < 2; ++k) {
+        const FwdDirHost &h = d[k < nd ? k : 0];
+        a[k] = GruFwdDir{(const float *)(h.ws + L.gi), h.w_hh, h.b_hh, h.h0, h.y, h.h_n, saved(h.ws, L), h.reverse};
+        y_vec = y_vec && (((uintptr_t)h.y & 15) == 0);
+    }
+    const size_t smem = (size_t)2 * 5 * GBT * HS_LD * sizeof(float);
+    auto go = [&](auto kern) -> int {
+        WW_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3((B + GBT - 1) / GBT, nd), dim3(512), smem, st, a[0], a[1], B, T, ldy, (long)T * ldy, y_vec);
+        return WW_OK;
+    };
+    if ((rc = mode == WW_ACT_BF16 ? go(k_gru_fwd<1>) : mode == WW_ACT_F16 ? go(k_gru_fwd<2>) : go(k_gru_fwd<0>))) return rc;
+    WW_LAUNCH_CHECK();
+    return WW_OK;
+}
+
+int gru_layer_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const BwdDirHost *d, int nd, long ldy, int B, int T, int I,
+                  float *dx, long lddx, int accumulate_dx, hipStream_t st) {
+    const WsLayout L = ws_layout(B, T, I);
+    const int nblk = (B + GBT - 1) / GBT;
+    const size_t bpart_off = (size_t)GRU_SPLITS * 3 * GH * std::max(I, GH);
+    GruBwdDir a[2];
+    int dy_vec = ldy % 4 == 0;
+    for (int k = 0; k < 2; ++k) {
+        const BwdDirHost &h = d[k < nd ? k : 0];
+        a[k] = GruBwdDir{h.w_hh, h.dy, h.dh_n, saved(h.ws, L), (float *)(h.ws + L.gi), (float *)(h.ws + L.dgh), h.dh0,
+                         (float *)(h.ws + L.part) + bpart_off, h.reverse};
+        dy_vec = dy_vec && (!h.dy || ((uintptr_t)h.dy & 15) == 0);
+    }
+    const dim3 grid(nblk, nd);
+    if (mode == WW_ACT_BF16) hipLaunchKernelGGL(k_gru_bwd<1>, grid, dim3(512), 0, st, a[0], a[1], ldy, (long)T * ldy, B, T, dy_vec);
+    else if (mode == WW_ACT_F16) hipLaunchKernelGGL(k_gru_bwd<2>, grid, dim3(512), 0, st, a[0], a[1], ldy, (long)T * ldy, B, T, dy_vec);
+    else hipLaunchKernelGGL(k_gru_bwd<0>, grid, dim3(512), 0, st, a[0], a[1], ldy, (long)T * ldy, B, T, dy_vec);
+    WW_LAUNCH_CHECK();
+    const int M = B * T;
+    const int splits = M >= 4096 ? GRU_SPLITS : 1;
+    int rc;
+    for (int k = 0; k < nd; ++k) {
+        const BwdDirHost &h = d[k];
+        float *dgi = (float *)(h.ws + L.gi), *dgh = (float *)(h.ws + L.dgh), *part = (float *)(h.ws + L.part);
+        const GruSaved sv = saved(h.ws, L);
+        // dW_hh[c][k] = sum_m dGh[m][c] h_prev[m][k]   ;   dW_ih[c][i] = sum_m dGi[m][c] x[m][i]
+        if ((rc = ww_gemm(mode, dgh, 1, 3 * GH, 3 * GH, sv.hp, 1, GH, GH, M, h.dw_hh, GH, nullptr, 0, splits, part, st))) return rc;
+        if ((rc = ww_gemm(mode, dgi, 1, 3 * GH, 3 * GH, x, 1, ldx, I, M, h.dw_ih, I, nullptr, 0, splits, part, st))) return rc;
+        // db_ih | db_hh: fixed-order sum of the per-block partials the recurrent kernel left (one launch for both: 768 columns)
+        if ((rc = ww_colsum_pair(part + bpart_off, nblk, 3 * GH, h.db_ih, h.db_hh, st))) return rc;
+        // dx[m][i] (+)= sum_c dGi[m][c] W_ih[c][i]   (the second direction adds to the first one's)
+        if (dx && (rc = ww_gemm(mode, dgi, 3 * GH, 1, M, h.w_ih, 1, I, I, 3 * GH, dx, lddx, nullptr, accumulate_dx || k > 0, 1, nullptr, st)))
+            return rc;
+    }
+    return WW_OK;
+}
+}  // namespace
+
 extern "C" int ww_gru_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *b_ih,
                           const float *b_hh, const float *h0, int B, int T, int I, int H, int reverse, float *y, long ldy,
                           float *h_n, void *ws, size_t ws_bytes, ww_stream_t stream) {
@@ -445,44 +552,9 @@ extern "C" int ww_gru_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
     WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16 || mode == WW_ACT_F16, WW_E_INVALID, "ww_gru_fwd: unknown mode %d", mode);
     WW_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && y, WW_E_INVALID, "ww_gru_fwd: null argument");
     WW_REQUIRE(ldx >= I && ldy >= H, WW_E_INVALID, "ww_gru_fwd: row strides smaller than the feature sizes");
-    const WsLayout L = ws_layout(B, T, I);
-    char *w = (char *)ws;
-    hipStream_t st = (hipStream_t)stream;
-    ww_prof_scope ps_(ctx, WW_K_GRU, st);
-    // Gi[(b,t)][3H] = x[(b,t)][:] W_ih^T + b_ih for all time steps at once
-    // input projection of all time steps.  16-bit matrix modes with I a multiple of 64 (the CRNN's 64 conv channels, every
-    // second layer's 256): both operands are rounded ONCE into 16-bit copies (the dGh region of the workspace is idle in the
-    // forward pass) and the product runs on ww_gemm16_nt's 128 x 128 LDS-DMA tiles with b_ih added in its epilogue -- the same
-    // operand roundings as k_gemm's LDS fill, 3-5x faster than its 64 x 64 tiles on fp32 operands at these shapes.
-    const long Mrows = (long)B * T;
-    const size_t xh_bytes = ((size_t)Mrows * I * 2 + 255) & ~(size_t)255, wh_bytes = (size_t)3 * GH * I * 2;
-    static const int use_gemm16 = ww_env_int("WW_GRU_GEMM16", 1);      // A/B knob: 0 = the k_gemm path for every shape
-    if (use_gemm16 && mode != WW_ACT_F32 && I % 64 == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)w_ih) & 15) == 0 &&
-        xh_bytes + wh_bytes <= (size_t)Mrows * 3 * GH * sizeof(float)) {
-        void *xh = w + L.dgh, *wh = w + L.dgh + xh_bytes;
-        const long n4 = Mrows * (I / 4) + 3L * GH * I / 4;
-        const int grid = (int)std::min<long>((n4 + 4 * 256 - 1) / (4 * 256), 4096);
-        if (mode == WW_ACT_BF16)
-            hipLaunchKernelGGL(k_to16_pair<ww_bf16>, dim3(grid), dim3(256), 0, st, x, ldx, Mrows, I, w_ih, 3L * GH * I, (ww_bf16 *)xh, (ww_bf16 *)wh);
-        else
-            hipLaunchKernelGGL(k_to16_pair<ww_f16>, dim3(grid), dim3(256), 0, st, x, ldx, Mrows, I, w_ih, 3L * GH * I, (ww_f16 *)xh, (ww_f16 *)wh);
-        WW_LAUNCH_CHECK();
-        rc = ww_gemm16_nt_bias(ctx, mode, xh, wh, w + L.gi, 1, Mrows, 3 * GH, I, b_ih, st);
-    } else {
-        rc = ww_gemm(mode, x, ldx, 1, B * T, w_ih, I, 1, 3 * GH, I, (float *)(w + L.gi), 3 * GH, b_ih, 0, 1, nullptr, st);
-    }
-    if (rc) return rc;
-    const size_t smem = (size_t)2 * 5 * GBT * HS_LD * sizeof(float);
-    const int y_vec = (ldy % 4 == 0) && (((uintptr_t)y & 15) == 0);
-    auto go = [&](auto kern) -> int {
-        WW_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, dim3((B + GBT - 1) / GBT), dim3(512), smem, st, (const float *)(w + L.gi), w_hh, b_hh, h0, B, T,
-                           reverse, y, ldy, (long)T * ldy, h_n, saved(w, L), y_vec);
-        return WW_OK;
-    };
-    if ((rc = mode == WW_ACT_BF16 ? go(k_gru_fwd<1>) : mode == WW_ACT_F16 ? go(k_gru_fwd<2>) : go(k_gru_fwd<0>))) return rc;
-    WW_LAUNCH_CHECK();
-    return WW_OK;
+    ww_prof_scope ps_(ctx, WW_K_GRU, (hipStream_t)stream);
+    const FwdDirHost d{w_ih, w_hh, b_ih, b_hh, h0, y, h_n, (char *)ws, reverse};
+    return gru_layer_fwd(ctx, mode, x, ldx, &d, 1, B, T, I, ldy, (hipStream_t)stream);
 }
 
 extern "C" int ww_gru_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const float *w_ih, const float *w_hh, const float *dy,
@@ -494,37 +566,48 @@ extern "C" int ww_gru_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const
     WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16 || mode == WW_ACT_F16, WW_E_INVALID, "ww_gru_bwd: unknown mode %d", mode);
     WW_REQUIRE(x && w_ih && w_hh && dw_ih && dw_hh && db_ih && db_hh, WW_E_INVALID, "ww_gru_bwd: null argument");
     WW_REQUIRE(dy || dh_n, WW_E_INVALID, "ww_gru_bwd: need dy and/or dh_n");
-    const WsLayout L = ws_layout(B, T, I);
-    char *w = (char *)ws;
-    hipStream_t st = (hipStream_t)stream;
-    ww_prof_scope ps_(ctx, WW_K_GRU, st);
-    float *dgi = (float *)(w + L.gi), *dgh = (float *)(w + L.dgh), *part = (float *)(w + L.part);
-    const GruSaved sv = saved(w, L);
-    float *bpart = part + (size_t)GRU_SPLITS * 3 * GH * std::max(I, GH);
-    const int nblk = (B + GBT - 1) / GBT;
-    const int dy_vec = dy && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0);
-    if (mode == WW_ACT_BF16)
-        hipLaunchKernelGGL(k_gru_bwd<1>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
-                           dgh, dh0, bpart, dy_vec);
-    else if (mode == WW_ACT_F16)
-        hipLaunchKernelGGL(k_gru_bwd<2>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
-                           dgh, dh0, bpart, dy_vec);
-    else
-        hipLaunchKernelGGL(k_gru_bwd<0>, dim3(nblk), dim3(512), 0, st, w_hh, dy, ldy, (long)T * ldy, dh_n, B, T, reverse, sv, dgi,
-                           dgh, dh0, bpart, dy_vec);
-    WW_LAUNCH_CHECK();
-    const int M = B * T;
-    const int splits = M >= 4096 ? GRU_SPLITS : 1;
-    // dW_hh[c][k] = sum_m dGh[m][c] h_prev[m][k]   ;   dW_ih[c][i] = sum_m dGi[m][c] x[m][i]
-    if ((rc = ww_gemm(mode, dgh, 1, 3 * GH, 3 * GH, sv.hp, 1, GH, GH, M, dw_hh, GH, nullptr, 0, splits, part, st))) return rc;
-    if ((rc = ww_gemm(mode, dgi, 1, 3 * GH, 3 * GH, x, 1, ldx, I, M, dw_ih, I, nullptr, 0, splits, part, st))) return rc;
-    // db_ih | db_hh: fixed-order sum of the per-block partials the recurrent kernel left (one launch for both: 768 columns)
-    if ((rc = ww_colsum_pair(bpart, nblk, 3 * GH, db_ih, db_hh, st))) return rc;
-    // dx[m][i] (+)= sum_c dGi[m][c] W_ih[c][i]
-    if (dx) {
-        WW_REQUIRE(lddx >= I, WW_E_INVALID, "ww_gru_bwd: dx row stride smaller than the input size");
-        if ((rc = ww_gemm(mode, dgi, 3 * GH, 1, M, w_ih, 1, I, I, 3 * GH, dx, lddx, nullptr, accumulate_dx, 1, nullptr, st)))
-            return rc;
+    WW_REQUIRE(!dx || lddx >= I, WW_E_INVALID, "ww_gru_bwd: dx row stride smaller than the input size");
+    ww_prof_scope ps_(ctx, WW_K_GRU, (hipStream_t)stream);
+    const BwdDirHost d{w_ih, w_hh, dy, dh_n, (char *)ws, dw_ih, dw_hh, db_ih, db_hh, dh0, reverse};
+    return gru_layer_bwd(ctx, mode, x, ldx, &d, 1, ldy, B, T, I, dx, lddx, accumulate_dx, (hipStream_t)stream);
+}
+
+// Both directions of a bidirectional layer: dir[0] runs t = 0..T-1, dir[1] t = T-1..0; y / dy are (B,T,2H) buffers (row stride
+// ldy >= 2H) whose column halves belong to the two directions; ONE recurrent launch (gridDim.y = 2) per pass.
+extern "C" int ww_gru_bidir_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const ww_gru_dir *dir, int B, int T, int I, int H,
+                                float *y, long ldy, size_t ws_bytes, ww_stream_t stream) {
+    WW_REQUIRE(ctx && dir, WW_E_INVALID, "ww_gru_bidir_fwd: null argument");
+    WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16 || mode == WW_ACT_F16, WW_E_INVALID, "ww_gru_bidir_fwd: unknown mode %d", mode);
+    WW_REQUIRE(x && y && ldx >= I && ldy >= 2 * H, WW_E_INVALID, "ww_gru_bidir_fwd: null x / y or row strides too small");
+    FwdDirHost d[2];
+    for (int k = 0; k < 2; ++k) {
+        int rc = check_gru("ww_gru_bidir_fwd", ctx, B, T, I, H, dir[k].ws, ws_bytes);
+        if (rc) return rc;
+        WW_REQUIRE(dir[k].w_ih && dir[k].w_hh && dir[k].b_ih && dir[k].b_hh, WW_E_INVALID, "ww_gru_bidir_fwd: null parameter");
+        d[k] = FwdDirHost{dir[k].w_ih, dir[k].w_hh, dir[k].b_ih, dir[k].b_hh, dir[k].h0, y + (size_t)k * GH, dir[k].h_n,
+                          (char *)dir[k].ws, k};
     }
-    return WW_OK;
+    WW_REQUIRE(d[0].ws != d[1].ws, WW_E_INVALID, "ww_gru_bidir_fwd: the two directions need their own workspaces");
+    ww_prof_scope ps_(ctx, WW_K_GRU, (hipStream_t)stream);
+    return gru_layer_fwd(ctx, mode, x, ldx, d, 2, B, T, I, ldy, (hipStream_t)stream);
+}
+
+extern "C" int ww_gru_bidir_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const ww_gru_dir *dir, const float *dy, long ldy,
+                                int B, int T, int I, int H, size_t ws_bytes, float *dx, long lddx, ww_stream_t stream) {
+    WW_REQUIRE(ctx && dir && x, WW_E_INVALID, "ww_gru_bidir_bwd: null argument");
+    WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16 || mode == WW_ACT_F16, WW_E_INVALID, "ww_gru_bidir_bwd: unknown mode %d", mode);
+    WW_REQUIRE(!dy || ldy >= 2 * H, WW_E_INVALID, "ww_gru_bidir_bwd: dy row stride smaller than 2H");
+    WW_REQUIRE(!dx || lddx >= I, WW_E_INVALID, "ww_gru_bidir_bwd: dx row stride smaller than the input size");
+    BwdDirHost d[2];
+    for (int k = 0; k < 2; ++k) {
+        int rc = check_gru("ww_gru_bidir_bwd", ctx, B, T, I, H, dir[k].ws, ws_bytes);
+        if (rc) return rc;
+        WW_REQUIRE(dir[k].w_ih && dir[k].w_hh && dir[k].dw_ih && dir[k].dw_hh && dir[k].db_ih && dir[k].db_hh, WW_E_INVALID,
+                   "ww_gru_bidir_bwd: null parameter / gradient pointer");
+        WW_REQUIRE(dy || dir[k].dh_n, WW_E_INVALID, "ww_gru_bidir_bwd: need dy and/or dh_n");
+        d[k] = BwdDirHost{dir[k].w_ih, dir[k].w_hh, dy ? dy + (size_t)k * GH : nullptr, dir[k].dh_n, (char *)dir[k].ws, dir[k].dw_ih,
+                          dir[k].dw_hh, dir[k].db_ih, dir[k].db_hh, dir[k].dh0, k};
+    }
+    ww_prof_scope ps_(ctx, WW_K_GRU, (hipStream_t)stream);
+    return gru_layer_bwd(ctx, mode, x, ldx, d, 2, dy ? ldy : 2 * GH, B, T, I, dx, lddx, 0, (hipStream_t)stream);
 }

@@ -21,7 +21,11 @@ class _GRUStackFn(torch.autograd.Function):
 
     @staticmethod
     def _par(mod, dev):
-        return mod.num_directions == 2 and mod.overlap_directions
+        return mod.num_directions == 2 and mod.overlap_directions and not mod.fused_directions
+
+    @staticmethod
+    def _fused(mod):
+        return mod.num_directions == 2 and mod.fused_directions
 
     @staticmethod
     def forward(ctx, x, mod, step, *params):
@@ -42,7 +46,11 @@ class _GRUStackFn(torch.autograd.Function):
                 ws_k[d] = nat.gru_workspace(B, T, cur.shape[2], H, dev)
                 h_k[d] = nat.gru_fwd(cur, w_ih, w_hh, b_ih, b_hh, out[:, :, d * H:(d + 1) * H], ws_k[d], reverse=(d == 1),
                                      mode=mod.mode)
-            if side is not None:
+            if _GRUStackFn._fused(mod):                      # both directions: one recurrent launch (gridDim.y = 2)
+                ws_k = [nat.gru_workspace(B, T, cur.shape[2], H, dev) for _ in range(2)]
+                h_k = nat.gru_bidir_fwd(cur, [params[4 * (k * nd + d):4 * (k * nd + d) + 4] for d in range(2)], out, ws_k,
+                                        mode=mod.mode)
+            elif side is not None:
                 side.wait_stream(main)                       # `cur` and `out` are ready / allocated
                 with torch.cuda.stream(side):
                     run(1)
@@ -88,7 +96,12 @@ class _GRUStackFn(torch.autograd.Function):
                 g = nat.gru_bwd(xin, w_ih, w_hh, dyd, dhn[d], ctx.workspaces[k][d], reverse=(d == 1), dx=dx_d,
                                 accumulate_dx=acc, mode=mod.mode)
                 grads[4 * (k * nd + d):4 * (k * nd + d) + 4] = g[:4]
-            if side is not None:
+            if _GRUStackFn._fused(mod):
+                g = nat.gru_bidir_bwd(xin, [params[4 * (k * nd + d):4 * (k * nd + d) + 2] for d in range(2)], dy, dhn,
+                                      ctx.workspaces[k], dx=dx, mode=mod.mode)
+                for d in range(2):
+                    grads[4 * (k * nd + d):4 * (k * nd + d) + 4] = g[d]
+            elif side is not None:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     dx1 = torch.empty_like(xin) if need_dx else None       # its own dx: the two run concurrently
@@ -125,7 +138,10 @@ class NativeGRU(nn.Module):
         self.num_directions = 2 if bidirectional else 1
         self.dropout, self.dropout_seed = float(dropout), dropout_seed
         self.dropout_step, self.sample_offset = 0, 0
-        self.overlap_directions = True       # reverse direction on a second HIP stream
+        # both directions of a layer in ONE recurrent launch (ww_gru_bidir_*); False: one launch per direction, the reverse one
+        # on a second HIP stream when overlap_directions (the round-2 form, kept for A/B measurements)
+        self.fused_directions = True
+        self.overlap_directions = True
         self._side = {}
         k = 1.0 / math.sqrt(hidden_size)
         self._names = []

@@ -367,7 +367,7 @@ class Trainer:
         self._ov = ov
         return ov
 
-
+    def _vote_skip(self, bad: bool) -> bool:
         """Reference-style step in data-parallel mode: the ranks agree BEFORE the gradient all-reduce whether this batch is
         skipped (a non-finite loss or an exception in the forward pass on one rank), so no rank is left waiting in a
         collective its peers never enter."""
