@@ -431,6 +431,17 @@ int ww_gru_bidir_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const ww_g
 int ww_gru_bidir_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const ww_gru_dir *dir /* [2] */, const float *dy, long ldy,
                      int B, int T, int I, int H, size_t ws_bytes, float *dx, long lddx, ww_stream_t stream);
 
+/* Deferred partial sums.  The parameter-gradient kernels of the generic layers (ww_linear_mfma_bwd's split-K dW product,
+ * ww_dwconv_nhwc_bwd, ww_stem3x3s2_bwd_dw) end in "sum the per-block partials into the gradient" -- a 4-5 us launch each that
+ * nothing needs before the optimizer.  While ww_ctx_set_deferred_reduce(ctx, 1) is in force those calls QUEUE that last step
+ * (their `scratch` argument then holds the partials and must stay untouched until the flush; dw / the gradient output is not
+ * valid before it) and ww_deferred_reduce_flush runs everything queued as ONE launch (fixed order, double accumulation).
+ * The autograd models flush at the end of backward (and before a mid-backward all-reduce).  Replaces nothing in the reference:
+ * its weight gradients come out of cuDNN / cuBLAS calls (src/training/trainer.py:182).                                      */
+int ww_ctx_set_deferred_reduce(ww_ctx *ctx, int on);
+int ww_deferred_reduce_pending(ww_ctx *ctx);
+int ww_deferred_reduce_flush(ww_ctx *ctx, ww_stream_t stream);
+
 /* Fused clip + optimizer step on flat fp32 buckets.  Replaces, for one step, the reference's
  * clip_gradients(...) ; optimizer.step()  (src/training/trainer.py:185-193) with torch.optim's own update rules
  * (create_optimizer, src/training/optimizer_factory.py:165-199: Adam, AdamW, SGD with nesterov=True).

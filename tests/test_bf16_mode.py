@@ -142,8 +142,9 @@ def test_cnn_small_bf16_close_to_fp32_oracle(nat, B, Fd, T, p, min_cos):
 
 
 def test_trainer_bf16_tracks_reference_trace(golden_dir, tmp_path):
-    """mixed_precision=True selects bf16 storage; per-step loss stays within 2e-2 of the reference fp32 trace
-    (stated bf16 tolerance; the fp32 mode holds 1e-3)."""
+    """mixed_precision=True selects bf16 storage; per-step loss stays within 5e-4 of the REAL reference Trainer's fp32 trace
+    (src/training/trainer.py:165-203 run on CPU, tests/golden/g2_*; measured on MI355X: 4.5e-5 -- the bound is 10x that, inside
+    the 1e-3 the fp32 mode is held to)."""
     from wakeword_trainer_home_amd.config import WakewordConfig
     from wakeword_trainer_home_amd.models import create_model
     from wakeword_trainer_home_amd.training import Trainer
@@ -167,5 +168,5 @@ def test_trainer_bf16_tracks_reference_trace(golden_dir, tmp_path):
     t.add_callback(type("R", (), {"on_batch_end": lambda self, i, l, a: losses.append(l)})())
     t.train()
     d = np.abs(np.array(losses) - tr["step_loss"])
-    assert d.max() < 2e-2, d
+    assert d.max() < 5e-4, d
     print(f"bf16 storage: max |loss - ref| = {d.max():.2e}")

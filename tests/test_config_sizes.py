@@ -25,8 +25,9 @@ def _cos(a, b):
 def test_config2_bf16_training_step_at_batch_512_matches_oracle():
     """bench.py's configuration: bf16 activation/gradient storage, B=512 feature maps (512,1,40,151), dropout 0.3 on.
     This is the shape that selects k_pw_bwd_bf16's WIDE_IMG variant, its y_out recompute and the pooled-gradient shortcut
-    of the last layer.  Reference step: src/training/trainer.py:165-203.  Bounds (bf16: 8 mantissa bits, 18 stored
-    tensors): loss within 5e-3, gradient norm within 3 %, direction of the whole gradient cos > 0.995, of every conv /
+    of the last layer.  Reference step: src/training/trainer.py:165-203.  Bounds = 10x what an MI355X measures (r03: loss 7e-6,
+    gradient norm 1.5e-5 relative, cos 0.99997; the line this test prints is kept under profiles/): loss within 7e-5, gradient
+    norm within 2e-4, direction of the whole gradient cos > 0.9997, of every conv /
     classifier weight tensor > 0.95 (worst: the stem's, 0.969 -- the last stop of the backward chain, and its input has a
     mean of -4 against a spread of 2: sum(dy) is exactly 0 behind a BatchNorm, so mean * sum(rounding errors of dy) is pure
     noise on top of sum(dy * (x - mean))) and of every BatchNorm weight / bias gradient > 0.9 (those 64-vectors are sums with
@@ -66,16 +67,16 @@ def test_config2_bf16_training_step_at_batch_512_matches_oracle():
     acc_ref = float((out.argmax(1) == y).float().mean())
 
     assert s["found_inf"] == 0.0 and s["count"] == B
-    assert abs(s["loss"] - loss.item()) <= 5e-3, (s["loss"], loss.item())
-    assert abs(s["grad_norm"] - gn_ref) <= 3e-2 * gn_ref, (s["grad_norm"], gn_ref)
+    assert abs(s["loss"] - loss.item()) <= 7e-5, (s["loss"], loss.item())
+    assert abs(s["grad_norm"] - gn_ref) <= 2e-4 * gn_ref, (s["grad_norm"], gn_ref)
     assert abs(s["correct"] / B - acc_ref) <= 0.02                     # logits within a bf16 step of 0 may flip the argmax
     gd, go = torch.cat([g_dev[n].flatten() for n in g_ref]), torch.cat([g.flatten() for g in g_ref.values()])
-    assert _cos(gd, go) > 0.995, _cos(gd, go)
+    assert _cos(gd, go) > 0.9997, _cos(gd, go)
     per = {n: _cos(g_dev[n].flatten(), g.flatten()) for n, g in g_ref.items() if g.norm() > 1e-6 * go.norm()}
     worst_w = min((c, n) for n, c in per.items() if "bn" not in n)
     worst_bn = min((c, n) for n, c in per.items() if "bn" in n)
     assert worst_w[0] > 0.95, worst_w
-    assert worst_bn[0] > 0.9, worst_bn
+    assert worst_bn[0] > 0.93, worst_bn
     worst = (worst_w, worst_bn)
     for (n, b), (_, c) in zip(model.named_buffers(), oracle.named_buffers()):
         if b.is_floating_point():
@@ -88,8 +89,9 @@ def test_config2_bf16_training_step_at_batch_512_matches_oracle():
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_config3_mobilenetv3_training_step_at_per_gpu_batch_256(mode):
-    """config 3: global batch 2048 over 8 ranks = 256 per GPU.  fp32 matrix mode: logits / loss 5e-4, whole gradient 5e-3 of
-    its norm; bf16 matrix mode (operands rounded, fp32 accumulation): logits 5e-2, gradient direction cos > 0.99."""
+    """config 3: global batch 2048 over 8 ranks = 256 per GPU.  Bounds <= 10x the measured values (r03, fp32: logits 7e-7, loss
+    equal to 6 digits, gradient 1.6e-6 of its norm, running statistics 1.1e-7; bf16 matrix mode -- operands rounded, fp32
+    accumulation --: logits 1.4e-2, loss 2.2e-5, cos 0.9987, running statistics 2.5e-3 of a standard deviation)."""
     from wakeword_trainer_home_amd.models import create_model
     from oracle.mobilenetv3 import MobileNetV3Oracle
     B = 256
@@ -106,15 +108,15 @@ def test_config3_mobilenetv3_training_step_at_per_gpu_batch_256(mode):
     ref = oracle(x, step=0, training=True)
     lo = torch.nn.functional.cross_entropy(ref, y)
     lo.backward()
-    tol = 5e-4 if mode == "fp32" else 5e-2
+    tol, ltol = (7e-6, 5e-6) if mode == "fp32" else (5e-2, 2e-4)
     derr = (out.detach().cpu().double() - ref.detach()).abs().max().item()
     assert derr <= tol * max(ref.abs().max().item(), 1.0), derr
-    assert abs(loss.item() - lo.item()) <= tol
+    assert abs(loss.item() - lo.item()) <= ltol, (loss.item(), lo.item())
     gd = torch.cat([p.grad.flatten().cpu().double() for p in model.parameters()])
     go = torch.cat([p.grad.flatten() for p in oracle.parameters()])
     rel = ((gd - go).norm() / go.norm()).item()
     if mode == "fp32":
-        assert rel <= 5e-3, rel
+        assert rel <= 2e-5, rel
     else:
         assert _cos(gd, go) > 0.99, _cos(gd, go)
     # running statistics after the step (torchvision's momentum 0.01, initial mean 0 / var 1), measured in units of the
@@ -129,7 +131,7 @@ def test_config3_mobilenetv3_training_step_at_per_gpu_batch_256(mode):
         var_b = ((ob[n.replace("running_mean", "running_var")].double() - 0.99) / 0.01).clamp_min(1e-12)
         r = ((b.cpu().double() - ob[n].double()).abs() / 0.01 / var_b.sqrt()).max().item()
         worst_rs = max(worst_rs, r)
-        assert r <= (1e-4 if mode == "fp32" else 2e-2), (n, r)
+        assert r <= (2e-6 if mode == "fp32" else 2e-2), (n, r)
         # (the batch variance is recovered from fp32 running_var ~ 1: one ulp of it is 6e-6 of variance -- percent-sized next
         # to the 2e-4 variance of a nearly dead channel; the denominator is floored at 0.05 so those do not set the bound)
         rv = (model.get_buffer(n.replace("running_mean", "running_var")).cpu().double() - ob[n.replace("running_mean", "running_var")].double()).abs() / 0.01 / (var_b + 0.05)
@@ -177,10 +179,12 @@ def test_config4_large_dataset_augmentation_at_batch_128():
 @pytest.mark.parametrize("act", ["fp32", "bf16", "fp16"])
 def test_config5_crnn_training_step_at_per_gpu_batch_512(act):
     """config 5: global batch 4096 over 8 ranks = 512 per GPU; conv front-end + bidirectional 2-layer GRU, dropout on.
-    fp32: logits / loss 5e-4, recurrent gradients 5e-3 and conv-stack gradients 2e-2 of their norms; bf16 storage + bf16
-    matrix operands: logits 5e-2, gradient directions cos > 0.99 (recurrent) / 0.97 (conv stack); fp16 storage + fp16 matrix
-    operands (config 5 as BASELINE words it): logits 1e-2, cos > 0.999 / 0.995 -- the backward runs on the loss times 65536
-    (GradScaler's initial scale, what the Trainer's device scaler applies) and the gradients are divided by it."""
+    Bounds <= 10x the measured values (r03: fp32 logits 2.3e-7, loss equal to 6 digits, recurrent gradients 2.6e-7 of their
+    norm; bf16 storage + bf16 matrix operands: logits 1.5e-3, loss 3e-5, recurrent gradients 2.5e-3, conv-stack direction cos
+    0.9949; fp16 storage + fp16 matrix operands (config 5 as BASELINE words it): logits 2.4e-4, loss 1e-6, recurrent 3.2e-4,
+    conv cos 0.9994) -- the fp16 backward runs on the loss times 65536 (GradScaler's initial scale, what the Trainer's device
+    scaler applies) and the gradients are divided by it.  The conv-stack gradient of the fp32 mode keeps its 2e-2-of-the-norm
+    bound: single ReLU decisions of activations within round-off of zero move it (see test_gru.py)."""
     from wakeword_trainer_home_amd.models import create_model
     from oracle.crnn import CRNNOracle
     B = 512
@@ -198,21 +202,22 @@ def test_config5_crnn_training_step_at_per_gpu_batch_512(act):
     ref = oracle(x, step=0, training=True)
     lo = torch.nn.functional.cross_entropy(ref, y)
     lo.backward()
-    tol = {"fp32": 5e-4, "bf16": 5e-2, "fp16": 1e-2}[act]
+    tol, ltol, rtol = {"fp32": (2.5e-6, 5e-6, 3e-6), "bf16": (1.5e-2, 3e-4, 2.5e-2), "fp16": (2.5e-3, 2e-5, 3.2e-3)}[act]
     derr = (out.detach().cpu().double() - ref.detach()).abs().max().item()
     assert derr <= tol, derr
-    assert abs(loss.item() - lo.item()) <= tol
+    assert abs(loss.item() - lo.item()) <= ltol, (loss.item(), lo.item())
     gd = torch.cat([p.grad.flatten().cpu().double() for n, p in model.named_parameters() if n.startswith("rnn.")]) / S
     go = torch.cat([p.grad.flatten() for p in oracle.rnn.parameters()])
     fd = torch.cat([p.grad.flatten().cpu().double() for n, p in model.named_parameters() if n.startswith("front.")]) / S
     fo = torch.cat([p.grad.flatten() for n, p in oracle.front.named_parameters() if not n.startswith("classifier")])
     assert torch.isfinite(gd).all() and torch.isfinite(fd).all()
+    rrel, frel = ((gd - go).norm() / go.norm()).item(), ((fd - fo).norm() / fo.norm()).item()
+    assert rrel <= rtol, rrel
     if act == "fp32":
-        assert ((gd - go).norm() / go.norm()).item() <= 5e-3
-        assert ((fd - fo).norm() / fo.norm()).item() <= 2e-2
+        assert frel <= 2e-2, frel
     elif act == "bf16":
-        assert _cos(gd, go) > 0.99 and _cos(fd, fo) > 0.97, (_cos(gd, go), _cos(fd, fo))
+        assert _cos(fd, fo) > 0.97, _cos(fd, fo)
     else:
-        assert _cos(gd, go) > 0.999 and _cos(fd, fo) > 0.995, (_cos(gd, go), _cos(fd, fo))
+        assert _cos(fd, fo) > 0.995, _cos(fd, fo)
     print(f"config 5 crnn B=512 {act}: logits err {derr:.2e}, loss {loss.item():.6f} vs {lo.item():.6f}, "
-          f"rnn grad rel {((gd - go).norm() / go.norm()).item():.2e} cos {_cos(gd, go):.5f}, conv grad cos {_cos(fd, fo):.5f}")
+          f"rnn grad rel {rrel:.2e} cos {_cos(gd, go):.5f}, conv grad rel {frel:.2e} cos {_cos(fd, fo):.5f}")

@@ -70,7 +70,7 @@ def _trainer(tmp_path, golden_dir, amp, init_scale=None):
 
 def test_trainer_fp16_tracks_reference_trace(golden_dir, tmp_path):
     """mixed_precision=True + amp_dtype='fp16' through the Trainer on the reference's B=128 trace (captured from the real
-    reference Trainer in fp32): per-step loss within 5e-3; the scaler is the device one, its scale stayed at GradScaler's
+    reference Trainer in fp32): per-step loss within 2.5e-4 (10x the 2.2e-5 measured on MI355X); the scaler is the device one, its scale stayed at GradScaler's
     initial 65536 and its growth tracker counted every applied step; the checkpoint's scaler_state_dict has GradScaler's keys."""
     from wakeword_trainer_home_amd import _native as nat
     from wakeword_trainer_home_amd.training.optimizer_factory import DeviceGradScaler
@@ -80,7 +80,7 @@ def test_trainer_fp16_tracks_reference_trace(golden_dir, tmp_path):
     t.add_callback(type("R", (), {"on_batch_end": lambda self, i, l, a: losses.append(l)})())
     t.train()
     d = np.abs(np.array(losses) - tr["step_loss"])
-    assert len(losses) == len(tr["step_loss"]) and d.max() < 5e-3, d
+    assert len(losses) == len(tr["step_loss"]) and d.max() < 2.5e-4, d
     sd = t.scaler.state_dict()
     assert set(sd) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
     assert sd["scale"] == 65536.0 and sd["_growth_tracker"] == len(losses) == t.optimizer.step_count()

@@ -13,9 +13,16 @@ def _rel(a, b):
     return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
 
 
+@pytest.fixture(params=[8, 16])
+def gru_rows(request, monkeypatch):
+    """Both workgroup shapes of the recurrent kernels (8 or 16 batch rows per workgroup; the library picks by batch size)."""
+    monkeypatch.setenv("WW_GRU_ROWS", str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize("B,T,I", [(5, 7, 40), (33, 76, 64), (16, 3, 9), (70, 20, 256)])
 @pytest.mark.parametrize("reverse", [False, True])
-def test_gru_direction_matches_torch(B, T, I, reverse):
+def test_gru_direction_matches_torch(B, T, I, reverse, gru_rows):
     from wakeword_trainer_home_amd import _native as nat
     H = 128
     torch.manual_seed(B + T)
@@ -57,6 +64,52 @@ def test_gru_direction_matches_torch(B, T, I, reverse):
     out2, hn2 = ref(x.detach(), h0g)
     ((out2[:, :, sl] * dy).sum() + (hn2[1 if reverse else 0] * dhn).sum()).backward()
     assert _rel(dh0.cpu().double(), h0g.grad[1 if reverse else 0]) <= tol
+
+
+@pytest.mark.parametrize("B,T,I", [(5, 7, 40), (33, 76, 64), (70, 20, 256)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gru_bidirectional_layer_in_one_launch(B, T, I, mode, gru_rows):
+    """ww_gru_bidir_fwd/bwd (both directions as the two rows of ONE recurrent launch) against float64 torch.nn.GRU
+    (bidirectional=True) in the fp32 mode, and BIT-identical to the two per-direction launches it replaces in either mode
+    (same kernels, same per-direction arithmetic; dx is the forward direction's product plus the reverse one's, in that order)."""
+    from wakeword_trainer_home_amd import _native as nat
+    H = 128
+    torch.manual_seed(B * T)
+    ref = torch.nn.GRU(I, H, num_layers=1, batch_first=True, bidirectional=True).double()
+    x = torch.randn(B, T, I, dtype=torch.float64, requires_grad=True)
+    out, hn = ref(x)
+    dy = torch.randn(B, T, 2 * H, dtype=torch.float64)
+    dhn = torch.randn(2, B, H, dtype=torch.float64)
+    ((out * dy).sum() + (hn * dhn).sum()).backward()
+    f = lambda t: t.detach().float().to(DEV)
+    m = {"fp32": torch.float32, "bf16": torch.bfloat16}[mode]
+    names = [["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"], ["weight_ih_l0_reverse", "weight_hh_l0_reverse",
+                                                                            "bias_ih_l0_reverse", "bias_hh_l0_reverse"]]
+    params = [[f(getattr(ref, n)) for n in ns] for ns in names]
+    xd, dyd = f(x), f(dy)
+    ws = [nat.gru_workspace(B, T, I, H, DEV) for _ in range(2)]
+    y = torch.zeros(B, T, 2 * H, device=DEV)
+    h_n = nat.gru_bidir_fwd(xd, params, y, ws, mode=m)
+    dx = torch.zeros(B, T, I, device=DEV)
+    grads = nat.gru_bidir_bwd(xd, params, dyd, [f(dhn[0]), f(dhn[1])], ws, dx=dx, mode=m)
+    # the per-direction launches
+    ws1 = [nat.gru_workspace(B, T, I, H, DEV) for _ in range(2)]
+    y1 = torch.zeros(B, T, 2 * H, device=DEV)
+    h1 = [nat.gru_fwd(xd, *params[d], y1[:, :, d * H:(d + 1) * H], ws1[d], reverse=(d == 1), mode=m) for d in range(2)]
+    dx1 = torch.zeros(B, T, I, device=DEV)
+    g1 = [nat.gru_bwd(xd, params[d][0], params[d][1], dyd[:, :, d * H:(d + 1) * H], f(dhn[d]), ws1[d], reverse=(d == 1), dx=dx1,
+                      accumulate_dx=(d == 1), mode=m) for d in range(2)]
+    assert torch.equal(y, y1) and torch.equal(h_n[0], h1[0]) and torch.equal(h_n[1], h1[1]) and torch.equal(dx, dx1)
+    for d in range(2):
+        for a, b in zip(grads[d], g1[d][:4]):
+            assert torch.equal(a, b)
+    if mode == "fp32":
+        assert (y.cpu().double() - out.detach()).abs().max().item() <= 2e-5
+        assert (torch.stack(h_n).cpu().double() - hn.detach()).abs().max().item() <= 2e-5
+        assert _rel(dx.cpu().double(), x.grad) <= 2e-4
+        for d in range(2):
+            for a, n in zip(grads[d], names[d]):
+                assert _rel(a.cpu().double(), getattr(ref, n).grad) <= 2e-4, n
 
 
 def test_gru_argument_checks():
@@ -266,7 +319,7 @@ def test_gruwakeword_bf16_matrix_mode():
 
 
 @pytest.mark.parametrize("reverse", [False, True])
-def test_gru_direction_bf16_mode(reverse):
+def test_gru_direction_bf16_mode(reverse, gru_rows):
     """mode=bf16: h and W_hh enter the per-step MFMA as bf16 (fp32 accumulation, fp32 state): outputs within 2e-2 of the
     float64 nn.GRU over 76 steps, weight-gradient direction cos > 0.999."""
     from wakeword_trainer_home_amd import _native as nat

@@ -95,3 +95,40 @@ def test_linear_argument_checks():
         MFMALinear(8, 3, activation="relu")
     with pytest.raises(nat.NativeError):
         MFMALinear(8, 3)(torch.zeros(4, 8))
+
+
+def test_deferred_partial_sums_equal_the_immediate_ones():
+    """ww_ctx_set_deferred_reduce: the weight-gradient calls queue their "sum the partials" step and ONE ww_deferred_reduce_flush
+    launch runs all of them -- several items of different sizes / split counts in one batch, against the float64 products and
+    against the immediate (per-call) sums of the same partials.  Shapes: a split-K dW (M = 30720 rows, 60 splits), a small one
+    (no split: nothing is queued), a depthwise 5x5 weight gradient and the stem's."""
+    from wakeword_trainer_home_amd import _native as nat
+    g = torch.Generator().manual_seed(3)
+    lib, cx = nat.load(), nat.ctx(DEV)
+    jobs = []
+    for M, K, N in ((30720, 96, 576), (7680, 576, 96), (40, 16, 8)):
+        x, w, dy = torch.randn(M, K, generator=g).to(DEV), (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+        jobs.append(("pw", x, w, dy))
+    xdw, wdw = torch.randn(32, 5, 19, 96, generator=g).to(DEV), torch.randn(96, 1, 5, 5, generator=g).to(DEV)
+    dydw = torch.randn(32, 5, 19, 96, generator=g).to(DEV)
+    xs, dys = torch.randn(16, 40, 151, generator=g).to(DEV), torch.randn(16, 20, 76, 16, generator=g).to(DEV)
+    now = [nat.linear_mfma_bwd(x, w, None, dy, mode=torch.bfloat16, need_db=False)[1] for _, x, w, dy in jobs]
+    now.append(nat.dwconv_nhwc_bwd(xdw, wdw, dydw, 5, 1)[1])
+    now.append(nat.stem3x3s2_bwd_dw(xs, dys, (16, 1, 3, 3)))
+    assert lib.ww_deferred_reduce_pending(cx) == 0
+    later = [nat.linear_mfma_bwd(x, w, None, dy, mode=torch.bfloat16, need_db=False, defer=True)[1] for _, x, w, dy in jobs]
+    later.append(nat.dwconv_nhwc_bwd(xdw, wdw, dydw, 5, 1, defer=True)[1])
+    later.append(nat.stem3x3s2_bwd_dw(xs, dys, (16, 1, 3, 3), defer=True))
+    assert lib.ww_deferred_reduce_pending(cx) == 4                      # the (40,16,8) product has no split to defer
+    nat.deferred_flush(DEV)
+    assert lib.ww_deferred_reduce_pending(cx) == 0
+    torch.cuda.synchronize()
+    for a, b in zip(now, later):
+        # same partials; the flush sums them in double, the immediate kernels in float / two-level double: round-off apart
+        assert _rel(b.double(), a.double()) <= 2e-6
+    r = lambda t: t.cpu().bfloat16().double()
+    for (_, x, w, dy), dw in zip(jobs, later):
+        assert _rel(dw.cpu().double(), r(dy).t() @ r(x)) <= 2e-5
+    ref = torch.nn.functional.conv2d(xdw.cpu().double().permute(0, 3, 1, 2).reshape(1, 32 * 96, 5, 19),
+                                     dydw.cpu().double().permute(0, 3, 1, 2).reshape(32 * 96, 1, 5, 19), padding=2, groups=32 * 96)
+    assert _rel(later[3].cpu().double().reshape(96, 5, 5), ref.reshape(32, 96, 5, 5).sum(0)) <= 2e-5

@@ -3,6 +3,7 @@
 There is deliberately NO fallback: if the shared library is missing, or a tensor is not
 on an MI355X, these wrappers raise.  PyTorch is used for device memory and streams only.
 """
+import contextlib
 import ctypes as C
 import math
 import os
@@ -175,6 +176,9 @@ _SIGS = {
     "ww_grad_norm_clip": (C.c_int, [_vp, _vp, _sz, _f, _vp, _vp, _vp]),
     "ww_prof_num_classes": (C.c_int, []),
     "ww_prof_class_name": (C.c_char_p, [_i]),
+    "ww_ctx_set_deferred_reduce": (C.c_int, [_vp, _i]),
+    "ww_deferred_reduce_pending": (C.c_int, [_vp]),
+    "ww_deferred_reduce_flush": (C.c_int, [_vp, _vp]),
     "ww_prof_enable": (C.c_int, [_vp, C.c_uint32]),
     "ww_prof_collect": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "ww_prob_threshold": (_u64, [C.c_double]),
@@ -463,9 +467,60 @@ def _out(buf, shape, dev):
     return buf
 
 
+# ---- deferred partial sums (include/wwhip.h: ww_ctx_set_deferred_reduce).  The backward nodes of the autograd models queue the
+# "sum the partials" step of their weight-gradient kernels; ONE launch at the end of the backward pass (an autograd-engine
+# callback) runs them all.  A queued gradient is not valid before the flush, so a node may only defer a gradient that autograd
+# ADOPTS without reading it: a fresh bucket slot (models/flat_buckets.grad_slot) of a parameter that has no gradient yet.
+_defer = {}          # device -> {"armed": the end-of-backward callback is queued, "keep": partial buffers alive until the flush}
+
+
+def defer_begin(dev):
+    """Called from a backward node: True when partial sums may be deferred in this backward pass (arms the flush callback)."""
+    dev = torch.device(dev)
+    st = _defer.setdefault(dev, {"armed": False, "keep": []})
+    if not st["armed"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda d=dev: _defer_end(d))
+        except Exception:                          # not inside an autograd backward pass: nothing would flush
+            return False
+        st["armed"] = True
+    return True
+
+
+def _defer_end(dev):
+    deferred_flush(dev)
+    _defer[dev]["armed"] = False
+
+
+def deferred_flush(dev):
+    """Run everything queued so far as one launch on the current stream (also used before a mid-backward all-reduce)."""
+    dev = torch.device(dev)
+    st = _defer.get(dev)
+    if st is None or not st["keep"]:
+        return
+    with _guard(dev):
+        _check(load().ww_deferred_reduce_flush(ctx(dev), _stream(dev)), "ww_deferred_reduce_flush")
+    st["keep"].clear()
+
+
+class _deferring:
+    """with _deferring(dev, scratch): the C call inside queues its partial-sum step; `scratch` lives until the flush."""
+
+    def __init__(self, dev, *keep):
+        self.dev, self.keep = torch.device(dev), keep
+
+    def __enter__(self):
+        _check(load().ww_ctx_set_deferred_reduce(ctx(self.dev), 1), "ww_ctx_set_deferred_reduce")
+
+    def __exit__(self, *exc):
+        load().ww_ctx_set_deferred_reduce(ctx(self.dev), 0)
+        _defer.setdefault(self.dev, {"armed": False, "keep": []})["keep"].extend(self.keep)
+
+
 def linear_mfma_bwd(x, w, pre, dy, act=LIN_NONE, dropout_p=0.0, seed=0, step=0, sample_offset=0, mode=torch.float32,
-                    need_dx=True, need_db=True, dw_out=None, db_out=None):
-    """-> (dx | None, dw, db | None).  dw_out / db_out: write the parameter gradients there (returned as given)."""
+                    need_dx=True, need_db=True, dw_out=None, db_out=None, defer=False):
+    """-> (dx | None, dw, db | None).  dw_out / db_out: write the parameter gradients there (returned as given).
+    defer: queue the split-K sum of dw (valid after deferred_flush)."""
     dev = _dev(x, w, pre, dy)
     _lin_check(x, w, None)
     M, K = x.shape
@@ -478,9 +533,10 @@ def linear_mfma_bwd(x, w, pre, dy, act=LIN_NONE, dropout_p=0.0, seed=0, step=0, 
     nbytes = load().ww_linear_mfma_bwd_scratch_bytes(M, K, N)
     scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     epi = LinearEpi(act, dropout_p, seed, step, sample_offset)
-    with _guard(dev):
-        _check(load().ww_linear_mfma_bwd(ctx(dev), act_code(mode), _p(x.contiguous()), _p(w.contiguous()), _p(pre),
-                                         _p(dy.contiguous()), M, K, N, C.byref(epi), _p(dx), _p(dw), _p(db), _p(scratch), nbytes,
+    xc, dyc = x.contiguous(), dy.contiguous()
+    with _guard(dev), (_deferring(dev, scratch) if defer else contextlib.nullcontext()):
+        _check(load().ww_linear_mfma_bwd(ctx(dev), act_code(mode), _p(xc), _p(w.contiguous()), _p(pre),
+                                         _p(dyc), M, K, N, C.byref(epi), _p(dx), _p(dw), _p(db), _p(scratch), nbytes,
                                          _stream(dev)), "ww_linear_mfma_bwd")
     return dx, dw, db
 
@@ -587,14 +643,17 @@ def dwconv_nhwc_fwd(x, w, k, stride):
     return y
 
 
-def dwconv_nhwc_bwd(x, w, dy, k, stride, need_dx=True, dw_out=None):
+def dwconv_nhwc_bwd(x, w, dy, k, stride, need_dx=True, dw_out=None, defer=False):
+    """defer: queue the sum of the weight-gradient partials (dw valid after deferred_flush); the partials then get a buffer of
+    their own instead of the per-(C, device) scratch the next layer call would overwrite."""
     dev = _dev(x, w, dy)
     B, H, W, Cn = x.shape
     dx = torch.empty_like(x) if need_dx else None
     dw = _out(dw_out, tuple(w.shape), dev)
-    with _guard(dev):
+    scratch = torch.empty(load().ww_nhwc_scratch_bytes(Cn) // 4, dtype=torch.float32, device=dev) if defer else nhwc_scratch(Cn, dev)
+    with _guard(dev), (_deferring(dev, scratch) if defer else contextlib.nullcontext()):
         _check(load().ww_dwconv_nhwc_bwd(ctx(dev), _p(x), _p(w), _p(dy), B, H, W, Cn, k, stride, _p(dx), _p(dw),
-                                         _p(nhwc_scratch(Cn, dev)), _stream(dev)), "ww_dwconv_nhwc_bwd")
+                                         _p(scratch), _stream(dev)), "ww_dwconv_nhwc_bwd")
     return dx, dw
 
 
@@ -695,13 +754,14 @@ def stem3x3s2_bn_act_fwd(x, w, bn: BN, act):
     return y, a, ss, mr
 
 
-def stem3x3s2_bwd_dw(x, dy, w_shape, dw_out=None):
+def stem3x3s2_bwd_dw(x, dy, w_shape, dw_out=None, defer=False):
     dev = _dev(x, dy)
     B, H, W = x.shape
     Cn = dy.shape[-1]
     dw = _out(dw_out, tuple(w_shape), dev)
-    with _guard(dev):
-        _check(load().ww_stem3x3s2_bwd_dw(ctx(dev), _p(x), _p(dy), B, H, W, Cn, _p(dw), _p(nhwc_scratch(Cn, dev)), _stream(dev)),
+    scratch = torch.empty(load().ww_nhwc_scratch_bytes(Cn) // 4, dtype=torch.float32, device=dev) if defer else nhwc_scratch(Cn, dev)
+    with _guard(dev), (_deferring(dev, scratch) if defer else contextlib.nullcontext()):
+        _check(load().ww_stem3x3s2_bwd_dw(ctx(dev), _p(x), _p(dy), B, H, W, Cn, _p(dw), _p(scratch), _stream(dev)),
                "ww_stem3x3s2_bwd_dw")
     return dw
 

@@ -53,6 +53,8 @@ extern "C" int ww_ctx_create(int device, ww_ctx **out) {
     c->logmel_wgs = 0;
     c->tw16k = nullptr;
     c->norm_partials = nullptr;
+    c->defer_on = 0;
+    c->deferred = new std::vector<ww_reduce_item>();
     c->prof_recs = new std::vector<ww_prof_rec>();
     c->prof_free = new std::vector<ww_prof_rec>();
     *out = c;
@@ -110,7 +112,72 @@ extern "C" int ww_ctx_destroy(ww_ctx *ctx) {
         for (auto &r : *v) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         delete v;
     }
+    delete ctx->deferred;
     delete ctx;
+    return WW_OK;
+}
+
+// ---- deferred partial sums.  The weight-gradient kernels of the generic layers (split-K GEMMs, depthwise / stem weight gradients)
+// end in "sum the per-block partials" -- a 4-5 us launch each, ~35 of them in a MobileNetV3 step, every one a pure latency chain
+// nothing waits for before the optimizer.  While the context is deferring they are queued, and ONE launch runs them all.
+constexpr int RED_MAX = 64;
+struct ReduceBatch { ww_reduce_item it[RED_MAX]; int first_block[RED_MAX + 1]; int count; };
+// grid = sum over items of ceil(n / 1024), block 256: thread = 4 consecutive outputs of one item, partial rows summed in order
+// z = 0 .. splits-1 in double (8 rows of loads in flight); deterministic
+__global__ __launch_bounds__(256) void k_reduce_items(ReduceBatch b) {
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.first_block[i + 1]) ++i;
+    const float *__restrict__ part = b.it[i].part;
+    float *__restrict__ dst = b.it[i].dst;
+    const long n = b.it[i].n;
+    const int splits = b.it[i].splits, acc = b.it[i].accumulate;
+    const long i0 = ((long)((int)blockIdx.x - b.first_block[i]) * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    if ((n & 3) == 0 && (((uintptr_t)part | (uintptr_t)dst) & 15) == 0) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int z0 = 0; z0 < splits; z0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(part + (long)min(z0 + u, splits - 1) * n + i0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (z0 + u < splits) { s0 += v[u].x; s1 += v[u].y; s2 += v[u].z; s3 += v[u].w; }
+        }
+        float4 o = make_float4((float)s0, (float)s1, (float)s2, (float)s3);
+        if (acc) { const float4 c = *reinterpret_cast<const float4 *>(dst + i0); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+        *reinterpret_cast<float4 *>(dst + i0) = o;
+    } else {
+        for (long j = i0; j < min(n, i0 + 4); ++j) {
+            double s = 0.0;
+            for (int z = 0; z < splits; ++z) s += part[(long)z * n + j];
+            dst[j] = acc ? dst[j] + (float)s : (float)s;
+        }
+    }
+}
+extern "C" int ww_ctx_set_deferred_reduce(ww_ctx *ctx, int on) {
+    WW_REQUIRE(ctx != nullptr, WW_E_INVALID, "ww_ctx_set_deferred_reduce: ctx is null");
+    ctx->defer_on = on != 0;
+    return WW_OK;
+}
+extern "C" int ww_deferred_reduce_pending(ww_ctx *ctx) { return ctx ? (int)ctx->deferred->size() : 0; }
+extern "C" int ww_deferred_reduce_flush(ww_ctx *ctx, ww_stream_t stream) {
+    WW_REQUIRE(ctx != nullptr, WW_E_INVALID, "ww_deferred_reduce_flush: ctx is null");
+    std::vector<ww_reduce_item> &q = *ctx->deferred;
+    for (size_t base = 0; base < q.size(); base += RED_MAX) {
+        ReduceBatch b;
+        b.count = (int)std::min<size_t>(RED_MAX, q.size() - base);
+        int blocks = 0;
+        for (int i = 0; i < b.count; ++i) {
+            b.it[i] = q[base + i];
+            b.first_block[i] = blocks;
+            blocks += (int)((b.it[i].n + 1023) / 1024);
+        }
+        for (int i = b.count; i <= RED_MAX; ++i) b.first_block[i] = blocks;
+        for (int i = b.count; i < RED_MAX; ++i) b.it[i] = ww_reduce_item{nullptr, nullptr, 0, 0, 0};
+        if (blocks > 0) hipLaunchKernelGGL(k_reduce_items, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    q.clear();
+    WW_LAUNCH_CHECK();
     return WW_OK;
 }
 

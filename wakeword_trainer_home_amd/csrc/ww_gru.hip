@@ -56,8 +56,15 @@ __device__ __forceinline__ GruSaved pick(bool second, const GruSaved &a, const G
 
 // grid (ceil(B/16), directions), block 512 = 8 waves; wave w owns hidden units [16w, 16w+16).  BF16: h and W_hh enter the MFMA as bf16
 // (v_mfma_f32_16x16x32_bf16, 12 instead of 96 matrix instructions per step); h itself, the gates and the update stay fp32.
-template <int MODE>
+// ROWS = batch rows a workgroup owns: 16 (the MFMA tile's height) or 8.  The recurrence is bound by the ELEMENTWISE instructions
+// a CU issues per time step (gates, saved-tensor traffic), not by its 12 MFMAs, and at the per-GPU batches of data-parallel
+// training B/16 workgroups cover a fraction of the 256 CUs -- so with ROWS = 8 twice as many CUs each do half the elementwise
+// work (the MFMA tile keeps 16 rows, the lower 8 unused): the 4 result rows of lanes 0-31 are split with lanes 32-63 by
+// v_permlane32_swap, every lane then owns 2 cells instead of 4.
+template <int MODE, int ROWS>
 __global__ __launch_bounds__(512) void k_gru_fwd(GruFwdDir d0, GruFwdDir d1, int B, int T, long ldy, long bsy, int y_vec) {
+    constexpr bool HALF = ROWS == 8;
+    constexpr int NC = HALF ? 2 : 4;             // cells (batch rows of its unit) per lane
     const bool second = blockIdx.y != 0;
     const float *__restrict__ gi = second ? d1.gi : d0.gi, *__restrict__ w_hh = second ? d1.w_hh : d0.w_hh;
     const float *__restrict__ b_hh = second ? d1.b_hh : d0.b_hh, *__restrict__ h0 = second ? d1.h0 : d0.h0;
@@ -73,9 +80,10 @@ __global__ __launch_bounds__(512) void k_gru_fwd(GruFwdDir d0, GruFwdDir d1, int
     // holds 4 ROWS of one unit) and written out one step later as float4 along the UNIT axis by thread (row, 4 units):
     // 6 vector stores per thread and step instead of 24 scalar ones -- the store issue, not the MFMAs, bounded a step.
     // Two parities: a tile is rewritten two steps after it was filled, with a barrier in between.
-    extern __shared__ __align__(16) float gru_sav[];           // [2][5][GBT][HS_LD]
+    extern __shared__ __align__(16) float gru_sav[];           // [2][5][ROWS][HS_LD]
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
-    const int b0 = blockIdx.x * GBT, u = 16 * w + j;
+    const int b0 = blockIdx.x * ROWS, u = 16 * w + j;
+    const int crow0 = HALF ? 4 * (kq & 1) + 2 * (kq >> 1) : 4 * kq;      // first of this lane's NC consecutive batch rows
     float wreg[BF16 ? 1 : 3][BF16 ? 1 : 32];      // fp32: B operand of k-step kk, gate g: W_hh[g*128 + u][4kk + kq]
     bf16x8 wb[BF16 ? 3 : 1][BF16 ? 4 : 1];        // bf16: W_hh[g*128 + u][32kk + 8kq .. +7]
     if constexpr (BF16) {
@@ -97,28 +105,28 @@ __global__ __launch_bounds__(512) void k_gru_fwd(GruFwdDir d0, GruFwdDir d1, int
     const float bhr = b_hh[u], bhz = b_hh[GH + u], bhn = b_hh[2 * GH + u];
     for (int e = tid; e < GBT * GH; e += 512) {
         const int row = e >> 7, c = e & 127;
-        const float hv = (h0 && b0 + row < B) ? h0[(size_t)(b0 + row) * GH + c] : 0.f;
+        const float hv = (h0 && row < ROWS && b0 + row < B) ? h0[(size_t)(b0 + row) * GH + c] : 0.f;
         hs[0][row][c] = hv;
-        if constexpr (BF16) hb[0][row][c] = (H)hv;
+        if constexpr (BF16) { hb[0][row][c] = (H)hv; hb[1][row][c] = (H)0.f; }     // (rows >= ROWS stay zero operands)
     }
     __syncthreads();
     // input projections of a step are loaded TWO steps ahead (register sets A / B, alternating): a step is ~0.5 us of
     // MFMA + gate work, an HBM/L2 round trip 1-2 us -- loaded at the top of the step that needs them (first version) the
     // latency was most of the step
-    const float *gbase[4];                       // row (b, t = 0) of this lane's four batch rows, at its unit
+    const float *gbase[NC];                      // row (b, t = 0) of this lane's batch rows, at its unit
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) gbase[reg] = gi + (size_t)min(b0 + 4 * kq + reg, B - 1) * T * (3 * GH) + u;
-    auto load_gi = [&](int it, float (&gr)[4], float (&gz)[4], float (&gn)[4]) {
+    for (int reg = 0; reg < NC; ++reg) gbase[reg] = gi + (size_t)min(b0 + crow0 + reg, B - 1) * T * (3 * GH) + u;
+    auto load_gi = [&](int it, float (&gr)[NC], float (&gz)[NC], float (&gn)[NC]) {
         if (it >= T) return;
         const size_t toff = (size_t)(reverse ? T - 1 - it : it) * (3 * GH);      // wave-uniform
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
+        for (int reg = 0; reg < NC; ++reg) {
             const float *g3 = gbase[reg] + toff;
             gr[reg] = g3[0]; gz[reg] = g3[GH]; gn[reg] = g3[2 * GH];
         }
     };
     const int frow = tid >> 5, fc0 = 4 * (tid & 31);
-    const bool frow_ok = b0 + frow < B;
+    const bool frow_ok = frow < ROWS && b0 + frow < B;           // (ROWS = 8: the upper four waves have nothing to flush)
     const size_t fm0 = (size_t)(b0 + frow) * T * GH + fc0;                 // element (b, t = 0, fc0) of the (B*T, 128) tensors
     float *const fy0 = y + (size_t)(b0 + frow) * bsy + fc0;
     const float *const fs0 = gru_sav + frow * HS_LD + fc0;
@@ -126,22 +134,22 @@ __global__ __launch_bounds__(512) void k_gru_fwd(GruFwdDir d0, GruFwdDir d1, int
         if (!frow_ok) return;
         const int t = reverse ? T - 1 - it : it, par = it & 1;
         const size_t m = fm0 + (size_t)t * GH;
-        const float *sp = fs0 + (size_t)par * 5 * GBT * HS_LD;
+        const float *sp = fs0 + (size_t)par * 5 * ROWS * HS_LD;
         *reinterpret_cast<float4 *>(sv.r + m) = *reinterpret_cast<const float4 *>(sp);
-        *reinterpret_cast<float4 *>(sv.z + m) = *reinterpret_cast<const float4 *>(sp + GBT * HS_LD);
-        *reinterpret_cast<float4 *>(sv.n + m) = *reinterpret_cast<const float4 *>(sp + 2 * GBT * HS_LD);
-        *reinterpret_cast<float4 *>(sv.hn + m) = *reinterpret_cast<const float4 *>(sp + 3 * GBT * HS_LD);
-        *reinterpret_cast<float4 *>(sv.hp + m) = *reinterpret_cast<const float4 *>(sp + 4 * GBT * HS_LD);
+        *reinterpret_cast<float4 *>(sv.z + m) = *reinterpret_cast<const float4 *>(sp + ROWS * HS_LD);
+        *reinterpret_cast<float4 *>(sv.n + m) = *reinterpret_cast<const float4 *>(sp + 2 * ROWS * HS_LD);
+        *reinterpret_cast<float4 *>(sv.hn + m) = *reinterpret_cast<const float4 *>(sp + 3 * ROWS * HS_LD);
+        *reinterpret_cast<float4 *>(sv.hp + m) = *reinterpret_cast<const float4 *>(sp + 4 * ROWS * HS_LD);
         const float4 h4 = *reinterpret_cast<const float4 *>(&hs[par ^ 1][frow][fc0]);
         float *yo = fy0 + (size_t)t * ldy;
         if (y_vec) *reinterpret_cast<float4 *>(yo) = h4;
         else { yo[0] = h4.x; yo[1] = h4.y; yo[2] = h4.z; yo[3] = h4.w; }
     };
-    auto step = [&](int it, float (&sr)[4], float (&sz)[4], float (&sn)[4]) {
+    auto step = [&](int it, float (&sr)[NC], float (&sz)[NC], float (&sn)[NC]) {
         const int cur = it & 1;
-        float gir[4], giz[4], gin[4];
+        float gir[NC], giz[NC], gin[NC];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) { gir[reg] = sr[reg]; giz[reg] = sz[reg]; gin[reg] = sn[reg]; }
+        for (int reg = 0; reg < NC; ++reg) { gir[reg] = sr[reg]; giz[reg] = sz[reg]; gin[reg] = sn[reg]; }
         load_gi(it + 2, sr, sz, sn);            // the set is free again: refill it for the step after next
         if (it > 0) flush(it - 1);
         floatx4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -160,9 +168,19 @@ __global__ __launch_bounds__(512) void k_gru_fwd(GruFwdDir d0, GruFwdDir d1, int
                 for (int g = 0; g < 3; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wreg[g][kk], acc[g], 0, 0, 0);
             }
         }
+        if constexpr (HALF) {                   // lanes 32-63 take over result rows 2, 3 of lanes 0-31 (rows 8-15 are unused)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {     // D[row = 4kq + reg][unit u]
-            const int row = 4 * kq + reg;
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, acc[g][c]),
+                                                                     __builtin_bit_cast(unsigned, acc[g][c + 2]), false, false);
+                    acc[g][c] = __builtin_bit_cast(float, sw[0]);
+                }
+        }
+#pragma unroll
+        for (int reg = 0; reg < NC; ++reg) {    // D[row = crow0 + reg][unit u]
+            const int row = crow0 + reg;
             const float hnv = acc[2][reg] + bhn;
             const float r = gate_sigmoid<BF16>(gir[reg] + acc[0][reg] + bhr);
             const float z = gate_sigmoid<BF16>(giz[reg] + acc[1][reg] + bhz);
@@ -171,13 +189,13 @@ __global__ __launch_bounds__(512) void k_gru_fwd(GruFwdDir d0, GruFwdDir d1, int
             const float h = (1.0f - z) * n + z * hp;
             hs[cur ^ 1][row][u] = h;
             if constexpr (BF16) hb[cur ^ 1][row][u] = (H)h;
-            float *sp = gru_sav + (size_t)cur * 5 * GBT * HS_LD + row * HS_LD + u;
-            sp[0] = r; sp[GBT * HS_LD] = z; sp[2 * GBT * HS_LD] = n; sp[3 * GBT * HS_LD] = hnv; sp[4 * GBT * HS_LD] = hp;
+            float *sp = gru_sav + (size_t)cur * 5 * ROWS * HS_LD + row * HS_LD + u;
+            sp[0] = r; sp[ROWS * HS_LD] = z; sp[2 * ROWS * HS_LD] = n; sp[3 * ROWS * HS_LD] = hnv; sp[4 * ROWS * HS_LD] = hp;
         }
         __syncthreads();
     };
     {
-        float ar[4], az[4], an[4], br[4], bz[4], bn[4];
+        float ar[NC], az[NC], an[NC], br[NC], bz[NC], bn[NC];
         load_gi(0, ar, az, an);
         load_gi(1, br, bz, bn);
         for (int it = 0; it < T; it += 2) {
@@ -187,14 +205,14 @@ __global__ __launch_bounds__(512) void k_gru_fwd(GruFwdDir d0, GruFwdDir d1, int
         flush(T - 1);
     }
     if (hn_out)
-        for (int e = tid; e < GBT * GH; e += 512) {
+        for (int e = tid; e < ROWS * GH; e += 512) {
             const int row = e >> 7, c = e & 127;
             if (b0 + row < B) hn_out[(size_t)(b0 + row) * GH + c] = hs[T & 1][row][c];
         }
 }
 
 // same decomposition; wave w owns OUTPUT units [16w,16w+16) of dh_{t-1} = dh*z + dGh W_hh
-template <int MODE>
+template <int MODE, int ROWS>
 __global__ __launch_bounds__(512) void k_gru_bwd(GruBwdDir d0, GruBwdDir d1, long ldy, long bsy, int B, int T, int dy_vec) {
     const bool second = blockIdx.y != 0;
     const float *__restrict__ w_hh = second ? d1.w_hh : d0.w_hh, *__restrict__ dy = second ? d1.dy : d0.dy;
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd(GruBwdDir d0, GruBwdDir d1, lon
     __shared__ __align__(16) float dg[BF16 ? 1 : GBT][DG_LD];      // fp32 operand tile
     __shared__ __align__(16) H dgb[BF16 ? GBT : 1][DGB_LD];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, j = l & 15, kq = l >> 4;
-    const int b0 = blockIdx.x * GBT, u = 16 * w + j;
+    const int b0 = blockIdx.x * ROWS, u = 16 * w + j;
     float wreg[BF16 ? 1 : 96];         // fp32: B operand of k-step cc: W_hh[4cc + kq][u]  (contraction over the 384 gate rows)
     bf16x8 wb[BF16 ? 12 : 1];          // bf16: W_hh[32cc + 8kq .. +7][u]
     if constexpr (BF16) {
@@ -227,7 +245,13 @@ __global__ __launch_bounds__(512) void k_gru_bwd(GruBwdDir d0, GruBwdDir d1, lon
     }
     for (int e = tid; e < GBT * GH; e += 512) {
         const int row = e >> 7, c = e & 127;
-        dhs[row][c] = (dhn && b0 + row < B) ? dhn[(size_t)(b0 + row) * GH + c] : 0.f;
+        dhs[row][c] = (dhn && row < ROWS && b0 + row < B) ? dhn[(size_t)(b0 + row) * GH + c] : 0.f;
+    }
+    if constexpr (ROWS < GBT) {                     // operand rows nobody writes stay zero (their result rows are never read)
+        for (int e = tid; e < (GBT - ROWS) * 3 * GH; e += 512) {
+            const int row = ROWS + e / (3 * GH), c = e % (3 * GH);
+            if constexpr (BF16) dgb[row][c] = (H)0.f; else dg[row][c] = 0.f;
+        }
     }
     __syncthreads();
     // elementwise part: thread = (batch row, 4 consecutive units) -> every tensor moves as ONE float4 per thread and step
@@ -237,11 +261,12 @@ __global__ __launch_bounds__(512) void k_gru_bwd(GruBwdDir d0, GruBwdDir d1, lon
     const int erow = tid >> 5, ec0 = 4 * (tid & 31);
     const int eb = min(b0 + erow, B - 1);
     const bool erow_ok = b0 + erow < B;
+    const bool ewave = erow < ROWS;                 // wave-uniform (two rows per wave): ROWS = 8 leaves the elementwise part to waves 0-3
     const size_t em0 = (size_t)eb * T * GH + ec0;                        // (b, t = 0, ec0) of the (B*T, 128) tensors
     const float *const edy0 = dy ? dy + (size_t)eb * bsy + ec0 : nullptr;
     struct Saved { float4 r, z, n, hn, hp, dy; };
     auto prefetch = [&](int it, Saved &S) {
-        if (it >= T) return;
+        if (it >= T || !ewave) return;
         const int t = reverse ? it : T - 1 - it;        // the forward pass's time order, backwards
         const size_t i = em0 + (size_t)t * GH;
         S.r = *reinterpret_cast<const float4 *>(sv.r + i);
@@ -259,6 +284,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd(GruBwdDir d0, GruBwdDir d1, lon
     float sar[4] = {0.f, 0.f, 0.f, 0.f}, saz[4] = {0.f, 0.f, 0.f, 0.f}, san[4] = {0.f, 0.f, 0.f, 0.f}, shn[4] = {0.f, 0.f, 0.f, 0.f};
     auto step = [&](int it, Saved &S) {
         const int t = reverse ? it : T - 1 - it;
+        if (ewave) {
         const float pr[4] = {S.r.x, S.r.y, S.r.z, S.r.w}, pz[4] = {S.z.x, S.z.y, S.z.z, S.z.w};
         const float pn[4] = {S.n.x, S.n.y, S.n.z, S.n.w}, phn[4] = {S.hn.x, S.hn.y, S.hn.z, S.hn.w};
         const float php[4] = {S.hp.x, S.hp.y, S.hp.z, S.hp.w}, pdy[4] = {S.dy.x, S.dy.y, S.dy.z, S.dy.w};
@@ -298,6 +324,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd(GruBwdDir d0, GruBwdDir d1, lon
             *reinterpret_cast<float4 *>(&dg[erow][2 * GH + ec0]) = make_float4(dhn_[0], dhn_[1], dhn_[2], dhn_[3]);
         }
         *reinterpret_cast<float4 *>(&dhs[erow][ec0]) = make_float4(keep[0], keep[1], keep[2], keep[3]);   // this thread's cells only
+        }
         __syncthreads();
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
         if constexpr (BF16) {
@@ -323,7 +350,7 @@ __global__ __launch_bounds__(512) void k_gru_bwd(GruBwdDir d0, GruBwdDir d1, lon
         }
     }
     if (dh0)
-        for (int e = tid; e < GBT * GH; e += 512) {
+        for (int e = tid; e < ROWS * GH; e += 512) {
             const int row = e >> 7, c = e & 127;
             if (b0 + row < B) dh0[(size_t)(b0 + row) * GH + c] = dhs[row][c];
         }
@@ -335,12 +362,12 @@ __global__ __launch_bounds__(512) void k_gru_bwd(GruBwdDir d0, GruBwdDir d1, lon
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             __syncthreads();
-            *reinterpret_cast<float4 *>(&dhs[erow][ec0]) = make_float4(src[k][0], src[k][1], src[k][2], src[k][3]);
+            if (ewave) *reinterpret_cast<float4 *>(&dhs[erow][ec0]) = make_float4(src[k][0], src[k][1], src[k][2], src[k][3]);
             __syncthreads();
             if (tid < 128) {
                 float t = 0.f;
 #pragma unroll
-                for (int r = 0; r < GBT; ++r) t += dhs[r][tid];
+                for (int r = 0; r < ROWS; ++r) t += dhs[r][tid];
                 if (k == 0) { o[tid] = t; o[3 * GH + tid] = t; }
                 else if (k == 1) { o[GH + tid] = t; o[4 * GH + tid] = t; }
                 else if (k == 2) o[2 * GH + tid] = t;
@@ -411,7 +438,7 @@ WsLayout ws_layout(long B, long T, int I) {
     L.gi = take(M * 3 * GH);        // projections, overwritten by dGi in the backward pass
     L.dgh = take(M * 3 * GH);
     L.r = take(M * GH); L.z = take(M * GH); L.n = take(M * GH); L.hn = take(M * GH); L.hp = take(M * GH);
-    L.part = take((size_t)GRU_SPLITS * 3 * GH * std::max(I, GH) + (size_t)((B + GBT - 1) / GBT) * 6 * GH);
+    L.part = take((size_t)GRU_SPLITS * 3 * GH * std::max(I, GH) + (size_t)((B + 7) / 8) * 6 * GH);      // (8-row workgroups: B/8 bias partials)
     L.total = o;
     return L;
 }
@@ -454,6 +481,13 @@ extern "C" size_t ww_gru_workspace_bytes(int B, int T, int I, int H) {
 // ---- host side: a layer = 1 or 2 directions.  Per direction: the input projection GEMM, then ONE recurrent launch for all
 // directions (gridDim.y), then (backward) the weight-gradient / bias / dX products per direction on the same stream.
 namespace {
+// batch rows per workgroup of the recurrent kernels: 8 while 16-row workgroups would leave more than half of the CUs idle
+// (WW_GRU_ROWS = 8 | 16 overrides, for A/B measurements)
+int gru_rows(int B, int nd) {
+    const int forced = ww_env_int("WW_GRU_ROWS", 0);          // (read per call: the tests switch it inside one process)
+    if (forced == 8 || forced == 16) return forced;
+    return (long)((B + GBT - 1) / GBT) * nd <= 128 ? 8 : GBT;
+}
 struct FwdDirHost { const float *w_ih, *w_hh, *b_ih, *b_hh, *h0; float *y, *h_n; char *ws; int reverse; };
 struct BwdDirHost { const float *w_ih, *w_hh, *dy, *dh_n; char *ws; float *dw_ih, *dw_hh, *db_ih, *db_hh, *dh0; int reverse; };
 
@@ -495,13 +529,16 @@ int gru_layer_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const FwdDirH
         a[k] = GruFwdDir{(const float *)(h.ws + L.gi), h.w_hh, h.b_hh, h.h0, h.y, h.h_n, saved(h.ws, L), h.reverse};
         y_vec = y_vec && (((uintptr_t)h.y & 15) == 0);
     }
-    const size_t smem = (size_t)2 * 5 * GBT * HS_LD * sizeof(float);
+    const int rows = gru_rows(B, nd);
+    const size_t smem = (size_t)2 * 5 * rows * HS_LD * sizeof(float);
     auto go = [&](auto kern) -> int {
         WW_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, dim3((B + GBT - 1) / GBT, nd), dim3(512), smem, st, a[0], a[1], B, T, ldy, (long)T * ldy, y_vec);
+        hipLaunchKernelGGL(kern, dim3((B + rows - 1) / rows, nd), dim3(512), smem, st, a[0], a[1], B, T, ldy, (long)T * ldy, y_vec);
         return WW_OK;
     };
-    if ((rc = mode == WW_ACT_BF16 ? go(k_gru_fwd<1>) : mode == WW_ACT_F16 ? go(k_gru_fwd<2>) : go(k_gru_fwd<0>))) return rc;
+    if (rows == 8) rc = mode == WW_ACT_BF16 ? go(k_gru_fwd<1, 8>) : mode == WW_ACT_F16 ? go(k_gru_fwd<2, 8>) : go(k_gru_fwd<0, 8>);
+    else rc = mode == WW_ACT_BF16 ? go(k_gru_fwd<1, 16>) : mode == WW_ACT_F16 ? go(k_gru_fwd<2, 16>) : go(k_gru_fwd<0, 16>);
+    if (rc) return rc;
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
@@ -509,7 +546,8 @@ int gru_layer_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const FwdDirH
 int gru_layer_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const BwdDirHost *d, int nd, long ldy, int B, int T, int I,
                   float *dx, long lddx, int accumulate_dx, hipStream_t st) {
     const WsLayout L = ws_layout(B, T, I);
-    const int nblk = (B + GBT - 1) / GBT;
+    const int rows = gru_rows(B, nd);
+    const int nblk = (B + rows - 1) / rows;
     const size_t bpart_off = (size_t)GRU_SPLITS * 3 * GH * std::max(I, GH);
     GruBwdDir a[2];
     int dy_vec = ldy % 4 == 0;
@@ -520,9 +558,10 @@ int gru_layer_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const BwdDirH
         dy_vec = dy_vec && (!h.dy || ((uintptr_t)h.dy & 15) == 0);
     }
     const dim3 grid(nblk, nd);
-    if (mode == WW_ACT_BF16) hipLaunchKernelGGL(k_gru_bwd<1>, grid, dim3(512), 0, st, a[0], a[1], ldy, (long)T * ldy, B, T, dy_vec);
-    else if (mode == WW_ACT_F16) hipLaunchKernelGGL(k_gru_bwd<2>, grid, dim3(512), 0, st, a[0], a[1], ldy, (long)T * ldy, B, T, dy_vec);
-    else hipLaunchKernelGGL(k_gru_bwd<0>, grid, dim3(512), 0, st, a[0], a[1], ldy, (long)T * ldy, B, T, dy_vec);
+#define WW_GRU_BWD(M_, R_) hipLaunchKernelGGL((k_gru_bwd<M_, R_>), grid, dim3(512), 0, st, a[0], a[1], ldy, (long)T * ldy, B, T, dy_vec)
+    if (rows == 8) { if (mode == WW_ACT_BF16) WW_GRU_BWD(1, 8); else if (mode == WW_ACT_F16) WW_GRU_BWD(2, 8); else WW_GRU_BWD(0, 8); }
+    else { if (mode == WW_ACT_BF16) WW_GRU_BWD(1, 16); else if (mode == WW_ACT_F16) WW_GRU_BWD(2, 16); else WW_GRU_BWD(0, 16); }
+#undef WW_GRU_BWD
     WW_LAUNCH_CHECK();
     const int M = B * T;
     const int splits = M >= 4096 ? GRU_SPLITS : 1;

@@ -65,6 +65,8 @@ enum {
     WW_K_STEM_BWD, WW_K_FINALIZE, WW_K_CLIP, WW_K_AUDIO_AUG, WW_K_LINEAR, WW_K_GRU, WW_K_NHWC, WW_K_NCLASS
 };
 struct ww_prof_rec { int cls; hipEvent_t a, b; };
+// A "sum the partials" step of a parameter-gradient kernel, left for ww_deferred_reduce_flush: dst[i] (+)= sum_z part[z*n + i]
+struct ww_reduce_item { const float *part; float *dst; long n; int splits; int accumulate; };
 struct ww_ctx {
     int device;
     ww_feat_tables *tables;
@@ -75,7 +77,15 @@ struct ww_ctx {
     uint32_t prof_mask;
     std::vector<ww_prof_rec> *prof_recs;   // recorded, not yet collected
     std::vector<ww_prof_rec> *prof_free;   // event pairs ready for reuse
+    int defer_on;                          // ww_ctx_set_deferred_reduce: partial-sum steps are queued instead of launched
+    std::vector<ww_reduce_item> *deferred; // queued partial sums (ww_deferred_reduce_flush runs them as ONE launch)
 };
+// queue dst[i] (+)= sum_z part[z*n + i] when the context is deferring (returns true), else leave it to the caller
+static inline bool ww_defer(ww_ctx *ctx, const float *part, float *dst, long n, int splits, int accumulate) {
+    if (!ctx || !ctx->defer_on) return false;
+    ctx->deferred->push_back(ww_reduce_item{part, dst, n, splits, accumulate});
+    return true;
+}
 struct ww_prof_scope {   // RAII: records an event pair around the launches issued in its lifetime
     ww_ctx *ctx; hipStream_t st; ww_prof_rec r; bool on;
     ww_prof_scope(ww_ctx *c, int cls, hipStream_t s) : ctx(c), st(s), on(false) {

@@ -384,7 +384,7 @@ int make_epilogue(const ww_ctx *ctx, const ww_linear_epi *epi, const float *bias
 // splits > 1: partial products into `part` (splits x rows x cols), then summed in fixed order into C
 template <bool KCA, bool KCB, int EPI>
 int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, float *C, long ldc, const Epilogue &e,
-                hipStream_t st, int splits = 1, float *part = nullptr, int *row_tile_out = nullptr) {
+                hipStream_t st, int splits = 1, float *part = nullptr, int *row_tile_out = nullptr, ww_ctx *defer_ctx = nullptr) {
     auto aligned = [](const GemmOperand &o, bool kc) {
         const long ld = kc ? o.s_row : o.s_k;
         return (int)(((uintptr_t)o.p & 15) == 0 && (ld & 3) == 0);
@@ -421,7 +421,7 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
 #undef WW_GEMM_LAUNCH
 #undef WW_GEMM_LAUNCH_K32
     WW_LAUNCH_CHECK();
-    if (nz > 1) {
+    if (nz > 1 && !(ldc == B.rows && ww_defer(defer_ctx, part, C, sstride, nz, e.accumulate))) {
         const long n = sstride;
         const int g = (int)std::min<long>((n / 4 + 255) / 256 + 1, 2048);
         hipLaunchKernelGGL(k_splitk_sum, dim3(g), dim3(256), 0, st, part, n, nz, C, e.accumulate);
@@ -535,9 +535,13 @@ extern "C" int ww_conv1x1_bn_act_fwd(ww_ctx *ctx, int mode, const float *x, cons
 // for a 1x1 convolution is hundreds of thousands while N x K is a handful of 64 x 64 tiles -- the splits are what fills the
 // chip: enough of them for ~1024 workgroups, each at least 512 rows deep
 static int dw_splits(int M, int K, int N) {
+    // rows of the contraction per split: ONE 128-deep K stage.  A split's time is a chain of dependent stages (fetch -> LDS ->
+    // MFMA, ~3 us each at these sizes), so shallower splits finish sooner and the deferred reduction sums the extra partials for
+    // free (MobileNetV3 B=256, WW_DW_MIN_ROWS = 512 / 256 / 128: 2.694 / 2.579 / 2.566 ms per step, profiles/r03_e_*)
+    static const int min_rows = std::max(128, ww_env_int("WW_DW_MIN_ROWS", 128));
     const long tiles = (long)((N + 63) / 64) * ((K + 63) / 64);
     long s = (1024 + tiles - 1) / tiles;
-    s = std::min<long>(s, M / 512);
+    s = std::min<long>(s, M / min_rows);
     return (int)std::max<long>(1, std::min<long>(s, 256));
 }
 extern "C" size_t ww_linear_mfma_bwd_scratch_bytes(int M, int K, int N) {
@@ -573,7 +577,7 @@ extern "C" int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const f
     {           // dw[n][k] = sum_m dpre[m][n] x[m][k] : A(n, m) = dpre[m][n], B(k, m) = x[m][k]
         const GemmOperand A{dpre, 1, N, N}, B{x, 1, K, K};
         float *part = (float *)scratch + (size_t)M * N;
-        if ((rc = launch_gemm<false, false, 0>(mode, A, B, M, dw, K, none, st, dw_splits(M, K, N), part))) return rc;
+        if ((rc = launch_gemm<false, false, 0>(mode, A, B, M, dw, K, none, st, dw_splits(M, K, N), part, nullptr, ctx))) return rc;
     }
     if (db) {
         hipLaunchKernelGGL(k_colsum_any, dim3((N + 63) / 64), dim3(1024), 0, st, dpre, M, N, db);

@@ -1245,6 +1245,7 @@ extern "C" int ww_dwconv_nhwc_bwd(ww_ctx *ctx, const float *x, const float *w, c
                            (P + chunks - 1) / chunks, part);
     }
     WW_LAUNCH_CHECK();
+    if (ww_defer(ctx, part, dw, (long)C * k * k, chunks, 0)) return WW_OK;      // (the caller keeps `scratch` until the flush)
     return ww_colsum_rows_small(part, chunks, C * k * k, dw, st);
 }
 
@@ -1324,6 +1325,7 @@ extern "C" int ww_stem3x3s2_bwd_dw(ww_ctx *ctx, const float *x, const float *dy,
     const int L = 256 / (C / 4), blocks = (int)std::max<long>(1, std::min<long>(STEM_BLOCKS, (P + L - 1) / L));
     hipLaunchKernelGGL(k_stem3x3s2_dw, dim3(blocks), dim3(256), 0, st, x, dy, g, (float *)scratch);
     WW_LAUNCH_CHECK();
+    if (ww_defer(ctx, (const float *)scratch, dw, (long)C * 9, blocks, 0)) return WW_OK;
     return ww_colsum_rows_small((const float *)scratch, blocks, C * 9, dw, st);
 }
 extern "C" int ww_im2col3x3s2(ww_ctx *ctx, const float *x, int B, int H, int W, float *cols, ww_stream_t stream) {

@@ -186,15 +186,19 @@ class _ConvBNActFn(torch.autograd.Function):
         # parameter gradients are written straight into their slots of the model's flat bucket where there is one (grad_slot)
         dy, dgamma, dbeta = nat.bn_act_bwd(y, da.contiguous(), ss, mr, act, training, Cn, dgamma_out=grad_slot(gamma),
                                            dbeta_out=grad_slot(beta))
+        # the weight gradient is born in its bucket slot, which autograd adopts without reading: the "sum the partials" launch
+        # of its kernel can wait for the ONE flush at the end of the backward pass (nat.defer_begin)
+        slot = grad_slot(wp)
+        defer = slot is not None and nat.defer_begin(y.device)
         if kind == "dw":
-            dx, dw = nat.dwconv_nhwc_bwd(src, w.contiguous(), dy, k, stride, need_dx=ctx.needs_input_grad[0], dw_out=grad_slot(wp))
+            dx, dw = nat.dwconv_nhwc_bwd(src, w.contiguous(), dy, k, stride, need_dx=ctx.needs_input_grad[0], dw_out=slot, defer=defer)
         elif kind == "stem_direct":
-            dx, dw = None, nat.stem3x3s2_bwd_dw(src, dy, w.shape, dw_out=grad_slot(wp))
+            dx, dw = None, nat.stem3x3s2_bwd_dw(src, dy, w.shape, dw_out=slot, defer=defer)
         else:
             need_dx = kind == "pw" and ctx.needs_input_grad[0]
             w2 = w.reshape(w.shape[0], -1)
             dx, dw, _ = nat.linear_mfma_bwd(src, w2, None, dy.reshape(-1, Cn), mode=mode, need_dx=need_dx, need_db=False,
-                                            dw_out=grad_slot(wp))
+                                            dw_out=slot, defer=defer)
             dx = dx.reshape(xshape) if dx is not None else None
             dw = dw.reshape(w.shape)
         return dx, dw, dgamma, dbeta, None, None, None, None, None, (da if ctx.needs_input_grad[9] else None)

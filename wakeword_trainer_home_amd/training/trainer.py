@@ -349,11 +349,14 @@ class Trainer:
         ov = {"ptr": self.model.flat_param.data_ptr(), "first": first, "cut": total - acc, "left": 0, "handles": [],
               "n_tail": len(plist) - first, "hooks": [], "armed": False}
 
+        ext_dev = self.model.flat_param.device
+
         def hook(param, _ov=ov, _self=self):
             if not _ov["armed"]:
                 return
             _ov["left"] -= 1
             if _ov["left"] == 0:                                  # the tail is complete: gather what was born outside, reduce
+                nat.deferred_flush(ext_dev)                       # partial sums the tail's backward nodes left queued
                 ext = _self.model.flat_grad_ext
                 with torch.no_grad():
                     todo = [(v, q) for v, q in zip(views[_ov["first"]:], plist[_ov["first"]:]) if q.grad.data_ptr() != v.data_ptr()]
