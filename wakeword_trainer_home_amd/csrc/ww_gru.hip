@@ -173,9 +173,11 @@ __global__ __launch_bounds__(512) void k_gru_fwd(GruFwdDir d0, GruFwdDir d1, int
             for (int g = 0; g < 3; ++g)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, acc[g][c]),
-                                                                     __builtin_bit_cast(unsigned, acc[g][c + 2]), false, false);
-                    acc[g][c] = __builtin_bit_cast(float, sw[0]);
+                    // (plain float copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this clang --
+                    //  the generated code swapped acc[g][0] with a copy of itself)
+                    const float keep = acc[g][c], give = acc[g][c + 2];
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(keep), __float_as_uint(give), false, false);
+                    acc[g][c] = __uint_as_float(sw[0]);
                 }
         }
 #pragma unroll

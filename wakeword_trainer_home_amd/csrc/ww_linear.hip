@@ -148,9 +148,20 @@ __device__ __forceinline__ typename H16<H>::x8 tr_frag(const H *tile, int ld, in
 // partials); 2 = the light one (bias, accumulate, BatchNorm partials) -- what the 1x1 convolutions and the recurrent layers' input
 // projections use.  The full epilogue costs ~60 SGPRs of live kernel arguments; compiled into the 18 conv launches of a MobileNetV3
 // step it made the kernel spill SGPRs and carry a scratch segment (r02: 36 B, i.e. scratch set-up at every dispatch).
-template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS = 0>
-__global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int K, int k_per_split, float *__restrict__ C,
-                                              long ldc, long split_stride, int vecA, int vecB, Epilogue e) {
+template <int MODE, bool KCA, bool KCB, int TM, int TN, int KS>
+struct GemmLds {
+    static constexpr bool BF16 = MODE != 0;
+    static constexpr int RA = 64 * TM, RB = 64 * TN;
+    static constexpr int KT = KS ? KS : (BF16 ? (TM * TN == 4 ? 64 : GKH) : GK);
+    static constexpr int A_BYTES = BF16 ? (KCA ? RA * (KT + 8) : KT * (RA + 8)) * 2 : (KCA ? RA * (KT + 4) : KT * (RA + 4)) * 4;
+    static constexpr int B_BYTES = BF16 ? (KCB ? RB * (KT + 8) : KT * (RB + 8)) * 2 : (KCB ? RB * (KT + 4) : KT * (RB + 4)) * 4;
+    static constexpr int BYTES = A_BYTES + B_BYTES;
+};
+// one block tile of the product: block (bx, by) of split bz (of nz); lds >= GemmLds<...>::BYTES, 16-byte aligned
+template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS>
+__device__ __forceinline__ void gemm_block(const GemmOperand &A, const GemmOperand &B, int K, int k_per_split, float *__restrict__ C,
+                                           long ldc, long split_stride, int vecA, int vecB, const Epilogue &e, unsigned char *lds,
+                                           int bx, int by, int bz, int nz) {
     constexpr bool BF16 = MODE != 0;
     typedef typename ModeH<MODE>::type H;
     typedef typename H16<H>::x8 bf16x8;
@@ -163,12 +174,12 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
     constexpr int LDH_KC = KT + 8, LDF_KC = KT + 4;
     constexpr int A_BYTES = BF16 ? (KCA ? RA * LDH_KC : KT * (RA + 8)) * 2 : (KCA ? RA * LDF_KC : KT * (RA + 4)) * 4;
     constexpr int B_BYTES = BF16 ? (KCB ? RB * LDH_KC : KT * (RB + 8)) * 2 : (KCB ? RB * LDF_KC : KT * (RB + 4)) * 4;
-    __shared__ __align__(16) unsigned char lds[A_BYTES + B_BYTES];
+    static_assert(A_BYTES + B_BYTES == GemmLds<MODE, KCA, KCB, TM, TN, KS>::BYTES, "LDS plan out of step");
     void *As = lds, *Bs = lds + A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5, rh = wv >> 1, nh = wv & 1;
-    const long m0 = (long)blockIdx.y * RA, n0 = (long)blockIdx.x * RB;
-    const int kb = blockIdx.z * k_per_split, ke = min(K, kb + k_per_split);
+    const long m0 = (long)by * RA, n0 = (long)bx * RB;
+    const int kb = bz * k_per_split, ke = min(K, kb + k_per_split);
     floatx16 acc[TM][TN];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
             }
         }
     }
-    C += (long)blockIdx.z * split_stride;
+    C += (long)bz * split_stride;
     DropCtx dctx = {};
     if (EPI == 1 && e.use_dropout) dctx = dropout_ctx_vgpr(e);
     float ssum[TN], qsum[TN];       // EPI && e.stat_part: this lane's column sums of what it stores
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
                 v = lin_act(e.act, v);
                 if (e.use_dropout) v = drop_keep(e, dctx, row, (int)col) ? v * e.drop_scale : 0.f;
             }
-            if (EPI && e.accumulate && gridDim.z == 1) v += C[row * ldc + col];
+            if (EPI && e.accumulate && nz == 1) v += C[row * ldc + col];
             C[row * ldc + col] = v;
             if (EPI == 2) { ssum[tn] += v; qsum[tn] = fmaf(v, v, qsum[tn]); }
         }
@@ -272,11 +283,42 @@ __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int 
             const long col = n0 + tid;
             if (col < B.rows) {
                 const float *lo = sred + (((0 * 2 + nh_) * TN + tn_) * 32 + r_) * 2, *hi = sred + (((1 * 2 + nh_) * TN + tn_) * 32 + r_) * 2;
-                float *o = e.stat_part + (size_t)blockIdx.y * 2 * B.rows;
+                float *o = e.stat_part + (size_t)by * 2 * B.rows;
                 o[col] = lo[0] + hi[0];
                 o[B.rows + col] = lo[1] + hi[1];
             }
         }
+    }
+}
+
+template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS = 0>
+__global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int K, int k_per_split, float *__restrict__ C,
+                                              long ldc, long split_stride, int vecA, int vecB, Epilogue e) {
+    __shared__ __align__(16) unsigned char lds[GemmLds<MODE, KCA, KCB, TM, TN, KS>::BYTES];
+    gemm_block<MODE, KCA, KCB, EPI, TM, TN, KS>(A, B, K, k_per_split, C, ldc, split_stride, vecA, vecB, e, lds, blockIdx.x, blockIdx.y,
+                                                blockIdx.z, gridDim.z);
+}
+
+// dX and dW of one 1x1 convolution / Linear in ONE launch: the two products are independent (both read dy), each alone is a
+// 6-14 us chain on a fraction of the CUs, and a kernel boundary between them buys nothing.  Blocks [0, nbw) run the split-K
+// weight-gradient tiles (partials: the sum is deferred or follows), blocks [nbw, nbw + nbx) the data-gradient tiles.
+struct PairSide { GemmOperand A, B; int K, kps; float *C; long ldc, sstride; int vecA, vecB, gx, gy, nz; };
+template <int MODE, int TMX, int KSX>
+__global__ __launch_bounds__(256) void k_gemm_pair(PairSide w, PairSide x, int nbw) {
+    typedef GemmLds<MODE, false, false, 1, 1, 0> LW;
+    typedef GemmLds<MODE, true, false, TMX, 1, KSX> LX;
+    __shared__ __align__(16) unsigned char lds[LW::BYTES > LX::BYTES ? LW::BYTES : LX::BYTES];
+    const Epilogue none = {};
+    int b = blockIdx.x;
+    if (b < nbw) {
+        const int bx = b % w.gx;
+        b /= w.gx;
+        gemm_block<MODE, false, false, 0, 1, 1, 0>(w.A, w.B, w.K, w.kps, w.C, w.ldc, w.sstride, w.vecA, w.vecB, none, lds, bx, b % w.gy,
+                                                   b / w.gy, w.nz);
+    } else {
+        b -= nbw;
+        gemm_block<MODE, true, false, 0, TMX, 1, KSX>(x.A, x.B, x.K, x.kps, x.C, x.ldc, x.sstride, x.vecA, x.vecB, none, lds, b % x.gx,
+                                                      b / x.gx, 0, 1);
     }
 }
 
@@ -430,6 +472,61 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
     return WW_OK;
 }
 
+// ---- the paired launch of ww_linear_mfma_bwd: dW (N x K) = dpre^T x split over the M rows, and dX (M x K) = dpre W
+struct GemmPlan { int cfg, kps, nz; bool shallow; };
+GemmPlan gemm_plan(int mode, const GemmOperand &A, const GemmOperand &B, int K, int splits) {      // launch_gemm's choices
+    GemmPlan p;
+    p.kps = K;
+    const int kt = mode != WW_ACT_F32 ? GKH : GK;
+    if (splits > 1) p.kps = ((K + splits - 1) / splits + kt - 1) / kt * kt;
+    p.nz = (K + p.kps - 1) / p.kps;
+    const long tiles128 = (long)((A.rows + 127) / 128) * ((B.rows + 127) / 128) * p.nz;
+    p.cfg = (mode != WW_ACT_F32 && A.rows >= 128 && B.rows >= 128 && tiles128 >= 256) ? 2 : (A.rows >= 8192 ? 1 : 0);
+    p.shallow = K <= 32 && p.nz == 1 && p.cfg != 2 && mode != WW_ACT_F32;
+    return p;
+}
+// returns 1 when the pair was launched (dW partials in `part` when nz > 1, their sum queued on ctx or launched), 0 when the
+// shapes want tile forms the paired kernel does not carry (the caller then issues the two products separately), < 0 on error
+int launch_gemm_pair(ww_ctx *ctx, int mode, const float *dpre, const float *x, const float *w, int M, int K, int N, float *dx,
+                     float *dw, int splits, float *part, hipStream_t st) {
+    static const int enabled = ww_env_int("WW_GEMM_PAIR", 1);
+    if (!enabled) return 0;
+    const GemmOperand Ax{dpre, N, 1, M}, Bx{w, 1, K, K};            // dx[m][k] = sum_n dpre[m][n] w[n][k]
+    const GemmOperand Aw{dpre, 1, N, N}, Bw{x, 1, K, K};            // dw[n][k] = sum_m dpre[m][n] x[m][k]
+    const GemmPlan px = gemm_plan(mode, Ax, Bx, N, 1), pw = gemm_plan(mode, Aw, Bw, M, splits);
+    if (px.cfg == 2 || pw.cfg != 0 || pw.shallow) return 0;
+    auto aligned = [](const GemmOperand &o, bool kc) {
+        const long ld = kc ? o.s_row : o.s_k;
+        return (int)(((uintptr_t)o.p & 15) == 0 && (ld & 3) == 0);
+    };
+    const int RAx = px.cfg ? 128 : 64;
+    PairSide sw{Aw, Bw, M, pw.kps, pw.nz > 1 ? part : dw, (long)K, (long)N * K, aligned(Aw, false), aligned(Bw, false),
+                (K + 63) / 64, (N + 63) / 64, pw.nz};
+    PairSide sx{Ax, Bx, N, N, dx, (long)K, 0, aligned(Ax, true), aligned(Bx, false), (K + 63) / 64, (M + RAx - 1) / RAx, 1};
+    const int nbw = sw.gx * sw.gy * sw.nz, nbx = sx.gx * sx.gy;
+    const dim3 grid(nbw + nbx);
+#define WW_PAIR(MODE_) \
+    do { \
+        if (px.shallow) { if (px.cfg) hipLaunchKernelGGL((k_gemm_pair<MODE_, 2, 32>), grid, dim3(256), 0, st, sw, sx, nbw); \
+                          else hipLaunchKernelGGL((k_gemm_pair<MODE_, 1, 32>), grid, dim3(256), 0, st, sw, sx, nbw); } \
+        else if (px.cfg) hipLaunchKernelGGL((k_gemm_pair<MODE_, 2, 0>), grid, dim3(256), 0, st, sw, sx, nbw); \
+        else hipLaunchKernelGGL((k_gemm_pair<MODE_, 1, 0>), grid, dim3(256), 0, st, sw, sx, nbw); \
+    } while (0)
+    if (mode == WW_ACT_BF16) WW_PAIR(1);
+    else if (mode == WW_ACT_F16) WW_PAIR(2);
+    else { if (px.cfg) hipLaunchKernelGGL((k_gemm_pair<0, 2, 0>), grid, dim3(256), 0, st, sw, sx, nbw);
+           else hipLaunchKernelGGL((k_gemm_pair<0, 1, 0>), grid, dim3(256), 0, st, sw, sx, nbw); }
+#undef WW_PAIR
+    WW_LAUNCH_CHECK();
+    if (pw.nz > 1 && !ww_defer(ctx, part, dw, (long)N * K, pw.nz, 0)) {
+        const long n = (long)N * K;
+        const int g = (int)std::min<long>((n / 4 + 255) / 256 + 1, 2048);
+        hipLaunchKernelGGL(k_splitk_sum, dim3(g), dim3(256), 0, st, part, n, pw.nz, dw, 0);
+        WW_LAUNCH_CHECK();
+    }
+    return 1;
+}
+
 int check_dims(const char *who, int mode, int M, int K, int N) {
     WW_REQUIRE(mode == WW_ACT_F32 || mode == WW_ACT_BF16 || mode == WW_ACT_F16, WW_E_INVALID, "%s: unknown mode %d", who, mode);
     WW_REQUIRE(M >= 1 && K >= 1 && N >= 1, WW_E_INVALID, "%s: bad shape M=%d K=%d N=%d", who, M, K, N);
@@ -570,11 +667,14 @@ extern "C" int ww_linear_mfma_bwd(ww_ctx *ctx, int mode, const float *x, const f
         dpre = (const float *)scratch;
     }
     const Epilogue none = {};
-    if (dx) {   // dx[m][k] = sum_n dpre[m][n] w[n][k] : A = dpre (n contiguous), B(k, n) = w[n][k] (row index contiguous)
+    float *const part0 = (float *)scratch + (size_t)M * N;
+    const int paired = dx ? launch_gemm_pair(ctx, mode, dpre, x, w, M, K, N, dx, dw, dw_splits(M, K, N), part0, st) : 0;
+    if (paired < 0) return paired;
+    if (dx && !paired) {   // dx[m][k] = sum_n dpre[m][n] w[n][k] : A = dpre (n contiguous), B(k, n) = w[n][k] (row index contiguous)
         const GemmOperand A{dpre, N, 1, M}, B{w, 1, K, K};
         if ((rc = launch_gemm<true, false, 0>(mode, A, B, N, dx, K, none, st))) return rc;
     }
-    {           // dw[n][k] = sum_m dpre[m][n] x[m][k] : A(n, m) = dpre[m][n], B(k, m) = x[m][k]
+    if (!paired) {   // dw[n][k] = sum_m dpre[m][n] x[m][k] : A(n, m) = dpre[m][n], B(k, m) = x[m][k]
         const GemmOperand A{dpre, 1, N, N}, B{x, 1, K, K};
         float *part = (float *)scratch + (size_t)M * N;
         if ((rc = launch_gemm<false, false, 0>(mode, A, B, M, dw, K, none, st, dw_splits(M, K, N), part, nullptr, ctx))) return rc;
