@@ -196,6 +196,9 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
 
         for (int round = 0; round < 2; ++round) {
             const int fa = round * 8 + 2 * wv, fb = fa + 1;  // local frame indices of this wave's pair
+            // a clip's last block holds frames past T (T = 151: 7 of its 16 are real): a pair with no real frame is skipped
+            // (wave-uniform; nothing below reads what such a pair would have written -- the write-out guards t < T)
+            if (t0 + fa >= a.T) continue;
             float re[16], im[16];
             // ---- pass 1: windowed load, radix-16 over n2, twiddle W1024^(lane*kb)
             int tb1 = lane, tb2 = 16 * (lane & 3);

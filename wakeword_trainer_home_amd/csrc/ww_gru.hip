@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void k_to16_pair(const float *__restrict__ x, 
 }
 
 struct WsLayout { size_t gi, dgh, r, z, n, hn, hp, part, total; };
-constexpr int GRU_SPLITS = 32;
+constexpr int GRU_SPLITS = 128;          // workspace bound of the weight-gradient GEMMs' K splits (gru_splits() picks the count)
 WsLayout ws_layout(long B, long T, int I) {
     WsLayout L;
     size_t o = 0;
@@ -566,7 +566,11 @@ int gru_layer_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const BwdDirH
 #undef WW_GRU_BWD
     WW_LAUNCH_CHECK();
     const int M = B * T;
-    const int splits = M >= 4096 ? GRU_SPLITS : 1;
+    // K splits of the weight-gradient products (contraction over the B*T rows, 12-24 output tiles): as for the 1x1 convolutions
+    // a split is a chain of dependent K stages, so more, shallower splits finish sooner -- bounded by the partial traffic
+    // (splits x 3H x max(I, H) floats written and re-read): CRNN B=512 step 2.604 / 2.592 / 2.626 ms at 32 / 64 / 128
+    // (profiles/r03_i_*; WW_GRU_SPLITS for measurements)
+    const int splits = M >= 4096 ? std::min(GRU_SPLITS, std::max(1, ww_env_int("WW_GRU_SPLITS", 64))) : 1;
     int rc;
     for (int k = 0; k < nd; ++k) {
         const BwdDirHost &h = d[k];

@@ -241,7 +241,7 @@ __device__ __forceinline__ void gemm_block(const GemmOperand &A, const GemmOpera
     }
     C += (long)bz * split_stride;
     DropCtx dctx = {};
-    if (EPI == 1 && e.use_dropout) dctx = dropout_ctx_vgpr(e);
+    if (EPI == 1 && e.use_dropout) dctx = dropout_ctx(e);
     float ssum[TN], qsum[TN];       // EPI && e.stat_part: this lane's column sums of what it stores
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -250,7 +250,37 @@ __device__ __forceinline__ void gemm_block(const GemmOperand &A, const GemmOpera
     if (col >= B.rows) continue;
     const float bias = (EPI && e.bias) ? e.bias[col] : 0.f;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm) {
+        // C += : the tile's 16 old values are loaded as ONE batch (clamped rows, unconditional) before the first store -- as
+        // `v += C[..]` inside the guarded store loop every element was its own load -> wait -> add -> store round trip
+        // (the accumulating dX product of a bidirectional GRU layer: 116 us against 47 for the plain one)
+        float cold[16];
+        if (EPI == 2 && e.accumulate && nz == 1) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long row = min(m0 + 32 * TM * rh + 32 * tm + (reg & 3) + 8 * (reg >> 2) + 4 * h, (long)A.rows - 1);
+                cold[reg] = C[row * ldc + col];
+            }
+            // (all 16 live at once: behind the guarded stores the compiler would sink each load next to its use again)
+            asm volatile("" : "+v"(cold[0]), "+v"(cold[1]), "+v"(cold[2]), "+v"(cold[3]), "+v"(cold[4]), "+v"(cold[5]), "+v"(cold[6]),
+                         "+v"(cold[7]), "+v"(cold[8]), "+v"(cold[9]), "+v"(cold[10]), "+v"(cold[11]), "+v"(cold[12]), "+v"(cold[13]),
+                         "+v"(cold[14]), "+v"(cold[15]));
+        } else {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) cold[reg] = 0.f;
+        }
+        // dropout decisions of the tile's 16 elements as a bit mask, from a loop that is NOT unrolled: sixteen inlined Philox
+        // rounds in the store loop below overflowed the scalar register file (spilled SGPRs and a 36-byte scratch segment,
+        // i.e. scratch set-up at every dispatch of the head's GEMM)
+        uint32_t keep = 0xFFFFu;
+        if (EPI == 1 && e.use_dropout) {
+            keep = 0u;
+#pragma nounroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long row = m0 + 32 * TM * rh + 32 * tm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                keep |= (drop_keep(e, dctx, row, (int)col) ? 1u : 0u) << reg;
+            }
+        }
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const long row = m0 + 32 * TM * rh + 32 * tm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -260,12 +290,14 @@ __device__ __forceinline__ void gemm_block(const GemmOperand &A, const GemmOpera
             if (EPI == 1) {
                 if (e.pre) e.pre[row * ldc + col] = v;
                 v = lin_act(e.act, v);
-                if (e.use_dropout) v = drop_keep(e, dctx, row, (int)col) ? v * e.drop_scale : 0.f;
+                if (e.use_dropout) v = ((keep >> reg) & 1u) ? v * e.drop_scale : 0.f;
             }
-            if (EPI && e.accumulate && nz == 1) v += C[row * ldc + col];
+            if (EPI == 1 && e.accumulate && nz == 1) v += C[row * ldc + col];
+            if (EPI == 2) v += cold[reg];
             C[row * ldc + col] = v;
             if (EPI == 2) { ssum[tn] += v; qsum[tn] = fmaf(v, v, qsum[tn]); }
         }
+    }
     }
     // BatchNorm statistics of a 1x1 convolution ride on its epilogue: the tile's column sums (the two half-waves by a shuffle,
     // the two row waves through LDS, fixed order) -> stat_part[row tile][2N]; the layer needs no pass over y for them
@@ -440,14 +472,17 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
     // traffic, not by the matrix cores) when both extents allow it and enough workgroups remain; 128 x 64 for very tall ones
     const long tiles128 = (long)((A.rows + 127) / 128) * ((B.rows + 127) / 128) * nz;
     // (the 128 x 128 form pays in bf16 mode only: in fp32 mode its 64 accumulator + 32 prefetch registers cost occupancy, 72 vs 82 TF)
-    const int cfg = (mode != WW_ACT_F32 && A.rows >= 128 && B.rows >= 128 && tiles128 >= 256) ? 2 : (A.rows >= 8192 ? 1 : 0);
+    // (the dense head's full epilogue -- EPI = 1 -- stays off the 128 x 128 form: with 64 accumulators beside the Philox dropout
+    // the kernel spilled scalar registers and carried a scratch segment; the head's GEMMs are far too small to miss that tile)
+    const int cfg = (EPI != 1 && mode != WW_ACT_F32 && A.rows >= 128 && B.rows >= 128 && tiles128 >= 256) ? 2 : (A.rows >= 8192 ? 1 : 0);
     const int RA = cfg ? 128 : 64, RBt = cfg == 2 ? 128 : 64;
     if (row_tile_out) *row_tile_out = RA;
     dim3 grid((B.rows + RBt - 1) / RBt, (A.rows + RA - 1) / RA, nz);
     float *dst = nz > 1 ? part : C;
     const long sstride = (long)A.rows * ldc;
 #define WW_GEMM_LAUNCH(BF, TM_, TN_) \
-    hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, TN_>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e)
+    do { if constexpr (!(EPI == 1 && TM_ * TN_ == 4)) \
+        hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, TN_>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e); } while (0)
 #define WW_GEMM_LAUNCH_K32(BF, TM_) \
     hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, 1, 32>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e)
     const bool shallow = K <= 32 && nz == 1 && cfg != 2;       // 16-bit modes: one 32-deep stage instead of a 128-deep one
