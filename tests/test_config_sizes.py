@@ -183,8 +183,8 @@ def test_config5_crnn_training_step_at_per_gpu_batch_512(act):
     norm; bf16 storage + bf16 matrix operands: logits 1.5e-3, loss 3e-5, recurrent gradients 2.5e-3, conv-stack direction cos
     0.9949; fp16 storage + fp16 matrix operands (config 5 as BASELINE words it): logits 2.4e-4, loss 1e-6, recurrent 3.2e-4,
     conv cos 0.9994) -- the fp16 backward runs on the loss times 65536 (GradScaler's initial scale, what the Trainer's device
-    scaler applies) and the gradients are divided by it.  The conv-stack gradient of the fp32 mode keeps its 2e-2-of-the-norm
-    bound: single ReLU decisions of activations within round-off of zero move it (see test_gru.py)."""
+    scaler applies) and the gradients are divided by it.  Conv-stack gradient, fp32 mode: 5.5e-4 of its norm measured (single
+    ReLU decisions of activations within round-off of zero move it, see test_gru.py), bound 5e-3."""
     from wakeword_trainer_home_amd.models import create_model
     from oracle.crnn import CRNNOracle
     B = 512
@@ -214,7 +214,7 @@ def test_config5_crnn_training_step_at_per_gpu_batch_512(act):
     rrel, frel = ((gd - go).norm() / go.norm()).item(), ((fd - fo).norm() / fo.norm()).item()
     assert rrel <= rtol, rrel
     if act == "fp32":
-        assert frel <= 2e-2, frel
+        assert frel <= 5e-3, frel
     elif act == "bf16":
         assert _cos(fd, fo) > 0.97, _cos(fd, fo)
     else:

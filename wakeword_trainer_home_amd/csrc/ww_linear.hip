@@ -528,8 +528,17 @@ int launch_gemm_pair(ww_ctx *ctx, int mode, const float *dpre, const float *x, c
     if (!enabled) return 0;
     const GemmOperand Ax{dpre, N, 1, M}, Bx{w, 1, K, K};            // dx[m][k] = sum_n dpre[m][n] w[n][k]
     const GemmOperand Aw{dpre, 1, N, N}, Bw{x, 1, K, K};            // dw[n][k] = sum_m dpre[m][n] x[m][k]
-    const GemmPlan px = gemm_plan(mode, Ax, Bx, N, 1), pw = gemm_plan(mode, Aw, Bw, M, splits);
+    GemmPlan px = gemm_plan(mode, Ax, Bx, N, 1);
+    const GemmPlan pw = gemm_plan(mode, Aw, Bw, M, splits);
     if (px.cfg == 2 || pw.cfg != 0 || pw.shallow) return 0;
+    // tall dX products (128-row tiles) with a deep K stage: the paired kernel's 128-row form needs 480 registers (one wave per
+    // SIMD: 43 us against 31 for the two separate launches at M = 194 560) -- WW_GEMM_PAIR_TALL: 0 = launch them separately,
+    // 1 = pair with 64-row dX tiles, 2 = pair with 128-row tiles
+    static const int tall = ww_env_int("WW_GEMM_PAIR_TALL", 1);
+    if (px.cfg == 1 && !px.shallow) {
+        if (tall == 0) return 0;
+        if (tall == 1) px.cfg = 0;
+    }
     auto aligned = [](const GemmOperand &o, bool kc) {
         const long ld = kc ? o.s_row : o.s_k;
         return (int)(((uintptr_t)o.p & 15) == 0 && (ld & 3) == 0);
