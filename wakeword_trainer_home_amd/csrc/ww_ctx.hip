@@ -97,6 +97,8 @@ static void free_tables(ww_feat_tables *t) {
         (void)hipFree(t->mel_len);
         (void)hipFree(t->mel_off);
         (void)hipFree(t->mel_w);
+        if (t->melp_tab) (void)hipFree(t->melp_tab);
+        if (t->melp_w) (void)hipFree(t->melp_w);
         if (t->dct) (void)hipFree(t->dct);
         delete t;
         t = n;
@@ -272,14 +274,39 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
                 dct[(size_t)c * M + m] = (float)v;
             }
     }
+    // padded-slot form of the band weights (k_logmel, n_fft 1024): two lanes share a band, each sums its half as a run of
+    // consecutive LDS slots of the power row -- no per-bin index arithmetic, adjacent slots pair into ds_read2
+    std::vector<int32_t> ptab;
+    std::vector<float> pw;
+    for (int m = 0; m < M; ++m) {
+        const int L = len[m], h0 = (L + 1) >> 1;
+        for (int half = 0; half < 2; ++half) {
+            const int j0 = half ? h0 : 0, j1 = half ? L : h0;
+            int slot0 = 0, steps = 0;
+            const int woff = (int)pw.size();
+            if (j1 > j0) {
+                const int b0 = start[m] + j0, b1 = start[m] + j1 - 1;
+                slot0 = b0 + (b0 >> 4);
+                const int slot1 = b1 + (b1 >> 4);
+                steps = (slot1 - slot0 + 1 + 3) / 4;
+                for (int p = slot0; p < slot0 + 4 * steps; ++p) {
+                    const int q = p / 17, r = p % 17, b = 16 * q + r;            // slot -> bin (r == 16: a pad slot)
+                    pw.push_back((r != 16 && b >= b0 && b <= b1) ? w[off[m] + (b - start[m])] : 0.f);
+                }
+            }
+            ptab.push_back(slot0); ptab.push_back(steps); ptab.push_back(woff);
+        }
+    }
     ww_feat_tables *t = new ww_feat_tables();
     memset(t, 0, sizeof(*t));
     t->cfg = *cfg;
+    t->n_melp_w = (int32_t)pw.size();
     t->max_len = max_len;
     t->n_mel_w = (int32_t)w.size();
     int rc;
     if ((rc = upload(&t->window, win)) || (rc = upload(&t->twiddle, tw)) || (rc = upload(&t->mel_start, start)) ||
-        (rc = upload(&t->mel_len, len)) || (rc = upload(&t->mel_off, off)) || (rc = upload(&t->mel_w, w))) {
+        (rc = upload(&t->mel_len, len)) || (rc = upload(&t->mel_off, off)) || (rc = upload(&t->mel_w, w)) ||
+        (rc = upload(&t->melp_tab, ptab)) || (rc = upload(&t->melp_w, pw))) {
         free_tables(t);
         return rc;
     }

@@ -36,6 +36,9 @@ struct FeatArgs {
     const float *dct;
     int span_len;
     int n_mel_w;
+    const int32_t *melp_tab;     // k_logmel: padded-slot band table / weights (ww_feat_tables)
+    const float *melp_w;
+    int n_melp_w;
 };
 
 // order a wave's own LDS traffic (cross-lane hand-off inside one wavefront): LDS processes one wave's operations in
@@ -97,19 +100,17 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
     float *lm = span + ((a.span_len + 3) & ~3);                       // FR x M (raw mel sums, then their logs)
     float *feat = lm + FR * a.M;                                      // FR x F (== lm when !use_dct)
     int *msk = reinterpret_cast<int *>(feat + (a.use_dct ? FR * a.F : 0));  // 2*WW_MAX_MASKS
-    int *mtab = msk + 2 * WW_MAX_MASKS;                               // 3*M : start, len, offset
-    float *mw = reinterpret_cast<float *>(mtab + 3 * a.M);            // n_mel_w band weights
+    int *mtab = msk + 2 * WW_MAX_MASKS;                               // 6*M : per (band, half) first slot, 4-slot steps, weight offset
+    float *mw = reinterpret_cast<float *>(mtab + 6 * a.M);            // n_melp_w band weights in the power rows' slot layout
     if (!a.use_dct) feat = lm;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // ---- once per workgroup (persistent grid): window and mel tables
     reinterpret_cast<float4 *>(wl)[tid] = reinterpret_cast<const float4 *>(a.window)[tid];
-    for (int i = tid; i < a.M; i += 256) {
-        mtab[3 * i] = a.mel_start[i];
-        mtab[3 * i + 1] = a.mel_len[i];
-        mtab[3 * i + 2] = a.mel_off[i];
-    }
-    for (int i = tid; i < a.n_mel_w; i += 256) mw[i] = a.mel_w[i];
+    // (the tiles' pad slots are never written -- the band sums multiply them by zero weights, so they must not hold NaN patterns)
+    for (int i = tid; i < 4 * XB; i += 256) xball[i] = 0.f;
+    for (int i = tid; i < 6 * a.M; i += 256) mtab[i] = a.melp_tab[i];
+    for (int i = tid; i < a.n_melp_w; i += 256) mw[i] = a.melp_w[i];
     const int K = use_mask ? (mp.n_f + mp.n_t) : 0;
 
     float *xb = xball + wv * XB;
@@ -233,8 +234,8 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
             // ---- pass 2: lane = kb*4 + q ; radix-16 over m (n1 = 4m + q), twiddle W64^(q*kc); written back in place
             fft16(re, im);
             {
-                const Tw6 tw2 = load_tw6(a.twiddle, tb2);
-                twiddle16(re, im, tw2);
+                const Tw6 tw2 = load_tw6(a.twiddle, tb2);        // (fetching both passes' factors at the top of the round: 128
+                twiddle16(re, im, tw2);                          //  VGPRs, 149 us alone either way, 1.260 vs 1.238 ms in the step)
             }
             // exchange 2 (planar) straight into the pass-3 butterflies' registers
             float4 ar[2], ai[2], br[2], bi[2];
@@ -283,25 +284,25 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                 }
             }
             wave_sync();
-            // ---- mel band sums: item = ((frame, mel), half); the two halves of a band sit in adjacent lanes
+            // ---- mel band sums: item = ((frame, mel), half); the two halves of a band sit in adjacent lanes.  A half is a run of
+            // consecutive slots of the power row (weights stored in the same slot layout, zero at the row's pad slots, which
+            // hold finite leftovers of the exchange): four slots per step, no per-bin index arithmetic
             for (int it0 = 0; it0 < 4 * a.M; it0 += 64) {
                 const int it = it0 + lane;
                 const bool act = it < 4 * a.M;
                 const int pair = act ? it >> 1 : 0, half = it & 1;
                 const int fr = pair >= a.M ? 1 : 0;
                 const int m = pair - fr * a.M;
-                const int s = mtab[3 * m], L = mtab[3 * m + 1];
-                const int h0 = (L + 1) >> 1;
-                const int j0 = half ? h0 : 0, j1 = half ? L : h0;
-                const float *wp = mw + mtab[3 * m + 2];
-                const float *pp = xb + fr * PB_LD;
+                const int *e = mtab + 3 * (2 * m + half);
+                const int steps = act ? e[1] : 0;
+                const float *wp = mw + e[2];
+                const float *pp = xb + fr * PB_LD + e[0];
                 float acc = 0.f;
-                if (act) {
-#pragma unroll 4
-                    for (int j = j0; j < j1; ++j) {
-                        const int bin = s + j;
-                        acc = fmaf(wp[j], pp[bin + (bin >> 4)], acc);
-                    }
+                for (int i = 0; i < steps; ++i) {
+                    acc = fmaf(wp[4 * i], pp[4 * i], acc);
+                    acc = fmaf(wp[4 * i + 1], pp[4 * i + 1], acc);
+                    acc = fmaf(wp[4 * i + 2], pp[4 * i + 2], acc);
+                    acc = fmaf(wp[4 * i + 3], pp[4 * i + 3], acc);
                 }
                 acc += __shfl_xor(acc, 1);
                 if (act && half == 0) lm[(fa + fr) * a.M + m] = acc;
@@ -511,6 +512,7 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
     a.dct = tb->dct;
     a.span_len = (FR - 1) * cfg->hop + WW_NFFT;
     a.n_mel_w = tb->n_mel_w;
+    a.melp_tab = tb->melp_tab; a.melp_w = tb->melp_w; a.n_melp_w = tb->n_melp_w;
     ww_mask_params mp = {};
     int use_mask = 0;
     if (sa) {
@@ -536,7 +538,7 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
         return WW_OK;
     }
     const size_t smem = ((size_t)4 * XB + WW_NFFT + ((a.span_len + 3) & ~3) + (size_t)FR * a.M +
-                         (a.use_dct ? (size_t)FR * a.F : 0) + 2 * WW_MAX_MASKS + (size_t)3 * a.M + a.n_mel_w) * sizeof(float);
+                         (a.use_dct ? (size_t)FR * a.F : 0) + 2 * WW_MAX_MASKS + (size_t)6 * a.M + a.n_melp_w) * sizeof(float);
     // Persistent grid: ctx->logmel_wgs workgroups (ww_ctx_set_logmel_workgroups; WW_LOGMEL_WGS overrides it for tuning),
     // 0 = one full residency round of the device.
     const int nblk = (a.T + FR - 1) / FR;

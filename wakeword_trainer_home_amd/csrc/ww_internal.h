@@ -56,6 +56,11 @@ struct ww_feat_tables {
     float *dct;            // (n_mfcc, n_mels) or null
     int32_t max_len;
     int32_t n_mel_w;       // number of floats in mel_w
+    // the same band weights laid out for k_logmel's power rows (bin j sits at slot j + (j >> 4)): per (band, half) the first
+    // slot, the number of 4-slot steps and the offset of its weights in melp_w (zero at pad slots and past the half's end)
+    int32_t *melp_tab;     // (2 * n_mels) x {slot0, steps, offset}
+    float *melp_w;
+    int32_t n_melp_w;
     ww_feat_tables *next;
 };
 
