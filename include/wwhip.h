@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 12
+#define WW_ABI_VERSION 13
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -441,6 +441,7 @@ int ww_gru_bidir_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const ww_g
 int ww_ctx_set_deferred_reduce(ww_ctx *ctx, int on);
 int ww_deferred_reduce_pending(ww_ctx *ctx);
 int ww_deferred_reduce_flush(ww_ctx *ctx, ww_stream_t stream);
+int ww_deferred_reduce_discard(ww_ctx *ctx);      /* forget what is queued (the backward pass that queued it did not complete) */
 
 /* Fused clip + optimizer step on flat fp32 buckets.  Replaces, for one step, the reference's
  * clip_gradients(...) ; optimizer.step()  (src/training/trainer.py:185-193) with torch.optim's own update rules

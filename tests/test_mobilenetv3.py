@@ -296,3 +296,47 @@ def test_trainer_step_uses_flat_buckets_and_fused_optimizer(tmp_path):
     topt.step()
     for p, r in zip(model.parameters(), ref):
         assert (p.detach() - r.detach()).abs().max().item() <= 5e-6
+
+
+def test_backward_that_raises_midway_leaves_no_stale_deferred_sums():
+    """The weight-gradient partial sums of a backward pass are queued and flushed by an autograd-engine callback at the END of
+    the pass.  A pass that raises midway never reaches it: the next forward must forget the stale queue (its buffers are gone)
+    and the next backward must arm a fresh flush -- the gradients of the step after the failure equal those of a model that
+    never failed, bit for bit."""
+    from tests.golden_util import make_inputs
+    from wakeword_trainer_home_amd import _native as nat
+    from wakeword_trainer_home_amd.models import create_model
+    x, y = make_inputs(12, 8)
+    x, y = x.to(DEV), y.to(DEV)
+
+    def grads(model):
+        model.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(model(x), y).backward()
+        return [p.grad.detach().clone() for p in model.parameters()]
+
+    torch.manual_seed(3)
+    clean = create_model("mobilenetv3", dropout=0.0).to(DEV).train()
+    torch.manual_seed(3)
+    hurt = create_model("mobilenetv3", dropout=0.0).to(DEV).train()
+    ref = grads(clean)
+
+    class Boom(RuntimeError):
+        pass
+
+    def explode(_):
+        raise Boom("backward interrupted")
+    hurt.zero_grad(set_to_none=True)
+    h = hurt.mobilenet.features[:6](x.float().contiguous())
+    h.register_hook(explode)                                    # fires after the late blocks' backward nodes have queued their sums
+    from wakeword_trainer_home_amd.models.mobilenet import _PoolFn
+    out = hurt.mobilenet.classifier(_PoolFn.apply(hurt.mobilenet.features[6:](h)))
+    with pytest.raises(Boom):
+        torch.nn.functional.cross_entropy(out, y).backward()
+    # (this PyTorch runs the engine's queued callbacks even when the pass raises, so the queue may already be empty here; the
+    #  reset at the next forward covers the versions / failure modes that do not)
+    hurt.load_state_dict(clean.state_dict())                    # (BatchNorm running statistics advanced in the failed forward)
+    clean2 = grads(clean)
+    got = grads(hurt)
+    assert nat.load().ww_deferred_reduce_pending(nat.ctx(DEV)) == 0
+    for a, b, c in zip(got, clean2, ref):
+        assert torch.equal(a, b)

@@ -15,7 +15,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 BWD_ALL, BWD_LATE, BWD_EARLY = 0, 1, 2
 ACT_F32, ACT_BF16, ACT_F16 = 0, 1, 2
 LOSS_CE, LOSS_FOCAL = 0, 1
@@ -179,6 +179,7 @@ _SIGS = {
     "ww_ctx_set_deferred_reduce": (C.c_int, [_vp, _i]),
     "ww_deferred_reduce_pending": (C.c_int, [_vp]),
     "ww_deferred_reduce_flush": (C.c_int, [_vp, _vp]),
+    "ww_deferred_reduce_discard": (C.c_int, [_vp]),
     "ww_prof_enable": (C.c_int, [_vp, C.c_uint32]),
     "ww_prof_collect": (C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "ww_prob_threshold": (_u64, [C.c_double]),
@@ -485,6 +486,16 @@ def defer_begin(dev):
             return False
         st["armed"] = True
     return True
+
+
+def defer_reset(dev):
+    """Start of a forward pass: whatever a previous backward pass left queued or armed is stale (that pass raised before its
+    end-of-backward callback ran) -- forget it, so the next backward arms a fresh flush."""
+    st = _defer.get(torch.device(dev))
+    if st is not None and (st["armed"] or st["keep"]):
+        _check(load().ww_deferred_reduce_discard(ctx(torch.device(dev))), "ww_deferred_reduce_discard")
+        st["armed"] = False
+        st["keep"].clear()
 
 
 def _defer_end(dev):
@@ -854,9 +865,10 @@ def gru_bidir_fwd(x, params, y, ws, mode=torch.float32):
     return h_n
 
 
-def gru_bidir_bwd(x, params, dy, dh_n, ws, dx=None, mode=torch.float32):
+def gru_bidir_bwd(x, params, dy, dh_n, ws, dx=None, mode=torch.float32, outs=None, defer=False):
     """Backward of gru_bidir_fwd: dy (B,T,2H) or None, dh_n = [(B,H) | None] x 2; dx (B,T,I) written when given.
-    -> [(dw_ih, dw_hh, db_ih, db_hh)] x 2."""
+    -> [(dw_ih, dw_hh, db_ih, db_hh)] x 2.  outs: the same structure of tensors to write the gradients into (bucket slots);
+    defer: queue the sums of the weight-gradient / bias partials (valid after deferred_flush; ``ws`` is kept until then)."""
     dev = _dev(params[0][0], params[1][0], ws[0], ws[1])
     _dev_rows(x, dy, dx)
     B, T, I = x.shape
@@ -865,14 +877,16 @@ def gru_bidir_bwd(x, params, dy, dh_n, ws, dx=None, mode=torch.float32):
     ldy = _bt_rows(dy, "dy") if dy is not None else 2 * H
     lddx = _bt_rows(dx, "dx") if dx is not None else I
     keep = [[p[0].contiguous(), p[1].contiguous()] for p in params]
-    grads = [(torch.empty_like(p[0]), torch.empty_like(p[1]), torch.empty(3 * H, dtype=torch.float32, device=dev),
-              torch.empty(3 * H, dtype=torch.float32, device=dev)) for p in params]
+    if outs is None:
+        outs = [(None, None, None, None)] * 2
+    grads = [(_out(o[0], tuple(p[0].shape), dev), _out(o[1], tuple(p[1].shape), dev), _out(o[2], (3 * H,), dev),
+              _out(o[3], (3 * H,), dev)) for p, o in zip(params, outs)]
     dirs = (GruDir * 2)()
     for k in range(2):
         dirs[k].w_ih, dirs[k].w_hh = keep[k][0].data_ptr(), keep[k][1].data_ptr()
         dirs[k].ws, dirs[k].dh_n = ws[k].data_ptr(), _ptr(dh_n[k])
         dirs[k].dw_ih, dirs[k].dw_hh, dirs[k].db_ih, dirs[k].db_hh = (g.data_ptr() for g in grads[k])
-    with _guard(dev):
+    with _guard(dev), (_deferring(dev, ws[0], ws[1]) if defer else contextlib.nullcontext()):
         _check(load().ww_gru_bidir_bwd(ctx(dev), act_code(mode), _p(x), ldx, C.byref(dirs), _p(dy), ldy, B, T, I, H,
                                        min(ws[0].numel(), ws[1].numel()) * 4, _p(dx), lddx, _stream(dev)), "ww_gru_bidir_bwd")
     return grads

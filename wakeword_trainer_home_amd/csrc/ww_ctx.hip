@@ -181,6 +181,12 @@ extern "C" int ww_ctx_set_deferred_reduce(ww_ctx *ctx, int on) {
     return WW_OK;
 }
 extern "C" int ww_deferred_reduce_pending(ww_ctx *ctx) { return ctx ? (int)ctx->deferred->size() : 0; }
+extern "C" int ww_deferred_reduce_discard(ww_ctx *ctx) {      // drop what is queued without running it (a backward pass that failed midway)
+    WW_REQUIRE(ctx != nullptr, WW_E_INVALID, "ww_deferred_reduce_discard: ctx is null");
+    ctx->deferred->clear();
+    ctx->defer_on = 0;
+    return WW_OK;
+}
 extern "C" int ww_deferred_reduce_flush(ww_ctx *ctx, ww_stream_t stream) {
     WW_REQUIRE(ctx != nullptr, WW_E_INVALID, "ww_deferred_reduce_flush: ctx is null");
     std::vector<ww_reduce_item> &q = *ctx->deferred;

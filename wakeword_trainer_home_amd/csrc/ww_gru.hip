@@ -493,8 +493,10 @@ int gru_rows(int B, int nd) {
 struct FwdDirHost { const float *w_ih, *w_hh, *b_ih, *b_hh, *h0; float *y, *h_n; char *ws; int reverse; };
 struct BwdDirHost { const float *w_ih, *w_hh, *dy, *dh_n; char *ws; float *dw_ih, *dw_hh, *db_ih, *db_hh, *dh0; int reverse; };
 
+// *xh_shared: the 16-bit copy of x another direction of the same layer has already made (both directions project the SAME input:
+// only the weights are converted then); set to this call's copy when it makes one
 int gru_project(ww_ctx *ctx, int mode, const float *x, long ldx, const FwdDirHost &d, const WsLayout &L, int B, int T, int I,
-                hipStream_t st) {
+                hipStream_t st, const void **xh_shared) {
     // Gi[(b,t)][3H] = x[(b,t)][:] W_ih^T + b_ih for all time steps at once.  16-bit matrix modes with I a multiple of 64 (the
     // CRNN's 64 conv channels, every second layer's 256): both operands are rounded ONCE into 16-bit copies (the dGh region of
     // the workspace is idle in the forward pass) and the product runs on ww_gemm16_nt's 128 x 128 LDS-DMA tiles with b_ih added
@@ -506,14 +508,18 @@ int gru_project(ww_ctx *ctx, int mode, const float *x, long ldx, const FwdDirHos
     if (use_gemm16 && mode != WW_ACT_F32 && I % 64 == 0 && ldx % 4 == 0 && (((uintptr_t)x | (uintptr_t)d.w_ih) & 15) == 0 &&
         xh_bytes + wh_bytes <= (size_t)Mrows * 3 * GH * sizeof(float)) {
         void *xh = w + L.dgh, *wh = w + L.dgh + xh_bytes;
-        const long n4 = Mrows * (I / 4) + 3L * GH * I / 4;
+        const bool have_x = xh_shared && *xh_shared;
+        const long rows = have_x ? 0 : Mrows;                          // rows of x this launch still has to convert
+        const long n4 = rows * (I / 4) + 3L * GH * I / 4;
         const int grid = (int)std::min<long>((n4 + 4 * 256 - 1) / (4 * 256), 4096);
         if (mode == WW_ACT_BF16)
-            hipLaunchKernelGGL(k_to16_pair<ww_bf16>, dim3(grid), dim3(256), 0, st, x, ldx, Mrows, I, d.w_ih, 3L * GH * I, (ww_bf16 *)xh, (ww_bf16 *)wh);
+            hipLaunchKernelGGL(k_to16_pair<ww_bf16>, dim3(grid), dim3(256), 0, st, x, ldx, rows, I, d.w_ih, 3L * GH * I, (ww_bf16 *)xh, (ww_bf16 *)wh);
         else
-            hipLaunchKernelGGL(k_to16_pair<ww_f16>, dim3(grid), dim3(256), 0, st, x, ldx, Mrows, I, d.w_ih, 3L * GH * I, (ww_f16 *)xh, (ww_f16 *)wh);
+            hipLaunchKernelGGL(k_to16_pair<ww_f16>, dim3(grid), dim3(256), 0, st, x, ldx, rows, I, d.w_ih, 3L * GH * I, (ww_f16 *)xh, (ww_f16 *)wh);
         WW_LAUNCH_CHECK();
-        return ww_gemm16_nt_bias(ctx, mode, xh, wh, w + L.gi, 1, Mrows, 3 * GH, I, d.b_ih, st);
+        const void *xa = have_x ? *xh_shared : xh;
+        if (xh_shared && !have_x) *xh_shared = xh;
+        return ww_gemm16_nt_bias(ctx, mode, xa, wh, w + L.gi, 1, Mrows, 3 * GH, I, d.b_ih, st);
     }
     return ww_gemm(mode, x, ldx, 1, B * T, d.w_ih, I, 1, 3 * GH, I, (float *)(w + L.gi), 3 * GH, d.b_ih, 0, 1, nullptr, st);
 }
@@ -522,8 +528,9 @@ int gru_layer_fwd(ww_ctx *ctx, int mode, const float *x, long ldx, const FwdDirH
                   hipStream_t st) {
     const WsLayout L = ws_layout(B, T, I);
     int rc;
+    const void *xh_shared = nullptr;
     for (int k = 0; k < nd; ++k)
-        if ((rc = gru_project(ctx, mode, x, ldx, d[k], L, B, T, I, st))) return rc;
+        if ((rc = gru_project(ctx, mode, x, ldx, d[k], L, B, T, I, st, &xh_shared))) return rc;
     GruFwdDir a[2];
     int y_vec = ldy % 4 == 0;
     for (int k = 0; k < 2; ++k) {
@@ -572,15 +579,22 @@ int gru_layer_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const BwdDirH
     // (profiles/r03_i_*; WW_GRU_SPLITS for measurements)
     const int splits = M >= 4096 ? std::min(GRU_SPLITS, std::max(1, ww_env_int("WW_GRU_SPLITS", 64))) : 1;
     int rc;
+    // While the context is deferring (ww_ctx_set_deferred_reduce) the three "sum the partials" launches of a direction are
+    // queued: the two weight-gradient products then keep their partials apart (dW_hh in the first, dW_ih in the second part of
+    // the region sized for GRU_SPLITS splits), and the bias partials are one 768-column item when db_ih | db_hh are adjacent
+    // (nn.GRU's parameter order, i.e. their slots of a flat gradient bucket)
+    const bool defer = ctx && ctx->defer_on && splits <= GRU_SPLITS / 2;
     for (int k = 0; k < nd; ++k) {
         const BwdDirHost &h = d[k];
         float *dgi = (float *)(h.ws + L.gi), *dgh = (float *)(h.ws + L.dgh), *part = (float *)(h.ws + L.part);
+        float *part_ih = defer ? part + (size_t)splits * 3 * GH * GH : part;
         const GruSaved sv = saved(h.ws, L);
         // dW_hh[c][k] = sum_m dGh[m][c] h_prev[m][k]   ;   dW_ih[c][i] = sum_m dGi[m][c] x[m][i]
-        if ((rc = ww_gemm(mode, dgh, 1, 3 * GH, 3 * GH, sv.hp, 1, GH, GH, M, h.dw_hh, GH, nullptr, 0, splits, part, st))) return rc;
-        if ((rc = ww_gemm(mode, dgi, 1, 3 * GH, 3 * GH, x, 1, ldx, I, M, h.dw_ih, I, nullptr, 0, splits, part, st))) return rc;
+        if ((rc = ww_gemm(mode, dgh, 1, 3 * GH, 3 * GH, sv.hp, 1, GH, GH, M, h.dw_hh, GH, nullptr, 0, splits, part, st, defer ? ctx : nullptr))) return rc;
+        if ((rc = ww_gemm(mode, dgi, 1, 3 * GH, 3 * GH, x, 1, ldx, I, M, h.dw_ih, I, nullptr, 0, splits, part_ih, st, defer ? ctx : nullptr))) return rc;
         // db_ih | db_hh: fixed-order sum of the per-block partials the recurrent kernel left (one launch for both: 768 columns)
-        if ((rc = ww_colsum_pair(part + bpart_off, nblk, 3 * GH, h.db_ih, h.db_hh, st))) return rc;
+        if (defer && h.db_hh == h.db_ih + 3 * GH) ww_defer(ctx, part + bpart_off, h.db_ih, 6 * GH, nblk, 0);
+        else if ((rc = ww_colsum_pair(part + bpart_off, nblk, 3 * GH, h.db_ih, h.db_hh, st))) return rc;
         // dx[m][i] (+)= sum_c dGi[m][c] W_ih[c][i]   (the second direction adds to the first one's)
         if (dx && (rc = ww_gemm(mode, dgi, 3 * GH, 1, M, h.w_ih, 1, I, I, 3 * GH, dx, lddx, nullptr, accumulate_dx || k > 0, 1, nullptr, st)))
             return rc;

@@ -581,16 +581,16 @@ int check_dims(const char *who, int mode, int M, int K, int N) {
 
 // internal entry points for the recurrent layers (ww_gru.hip)
 int ww_gemm(int mode, const float *A, long a_srow, long a_sk, int a_rows, const float *B, long b_srow, long b_sk, int b_rows,
-            int K, float *C, long ldc, const float *bias, int accumulate, int splits, float *part, hipStream_t st) {
+            int K, float *C, long ldc, const float *bias, int accumulate, int splits, float *part, hipStream_t st, ww_ctx *defer_ctx) {
     Epilogue e = {};
     e.bias = bias;
     e.accumulate = accumulate;
     const GemmOperand a{A, a_srow, a_sk, a_rows}, b{B, b_srow, b_sk, b_rows};
     const bool kca = a_sk == 1, kcb = b_sk == 1;
-    if (kca && kcb) return launch_gemm<true, true, 2>(mode, a, b, K, C, ldc, e, st, splits, part);
-    if (kca && !kcb) return launch_gemm<true, false, 2>(mode, a, b, K, C, ldc, e, st, splits, part);
-    if (!kca && kcb) return launch_gemm<false, true, 2>(mode, a, b, K, C, ldc, e, st, splits, part);
-    return launch_gemm<false, false, 2>(mode, a, b, K, C, ldc, e, st, splits, part);
+    if (kca && kcb) return launch_gemm<true, true, 2>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
+    if (kca && !kcb) return launch_gemm<true, false, 2>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
+    if (!kca && kcb) return launch_gemm<false, true, 2>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
+    return launch_gemm<false, false, 2>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
 }
 // a: rows x (2*cols) row-major; out0 = column sums of the left half, out1 of the right half (one launch)
 __global__ __launch_bounds__(1024) void k_colsum_pair(const float *__restrict__ a, int rows, int cols, float *__restrict__ out0,

@@ -380,5 +380,6 @@ class MobileNetV3Wakeword(FlatBuckets, nn.Module):
                                   f"'{x.device}', need an MI355X ('cuda') device -- there is no CPU fallback")
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError(f"mobilenetv3 expects (B,1,F,T) features, got {tuple(x.shape)}")
+        nat.defer_reset(x.device)              # (a previous backward pass that raised midway must not leave its queue behind)
         h = self.mobilenet.features(x.float().contiguous())          # (B,H,W,C) channels-last all the way
         return self.mobilenet.classifier(_PoolFn.apply(h))

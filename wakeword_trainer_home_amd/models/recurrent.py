@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import _native as nat
-from .flat_buckets import FlatBuckets
+from .flat_buckets import FlatBuckets, grad_slot
 from .heads import MFMALinear
 
 
@@ -78,6 +78,7 @@ class _GRUStackFn(torch.autograd.Function):
                 inputs.append(cur)
         ctx.mod, ctx.step, ctx.p = mod, step, p
         ctx.inputs, ctx.workspaces = inputs, workspaces
+        ctx.param_objs = params            # the Parameter objects themselves: their gradient-bucket slots (grad_slot)
         ctx.save_for_backward(*params)
         return torch.cat(h_last, dim=1) if nd == 2 else h_last[0]
 
@@ -106,8 +107,13 @@ class _GRUStackFn(torch.autograd.Function):
                                 accumulate_dx=acc, mode=mod.mode)
                 grads[4 * (k * nd + d):4 * (k * nd + d) + 4] = g[:4]
             if fused:
+                # gradients born in their slots of the model's flat bucket (autograd adopts them without reading), so the sums
+                # of the weight-gradient / bias partials can wait for the ONE flush at the end of the backward pass
+                slots = [tuple(grad_slot(q) for q in ctx.param_objs[4 * (k * nd + d):4 * (k * nd + d) + 4]) for d in range(2)]
+                have = all(s_ is not None for d_ in slots for s_ in d_)
                 g = nat.gru_bidir_bwd(xin, [params[4 * (k * nd + d):4 * (k * nd + d) + 2] for d in range(2)], dy, dhn,
-                                      ctx.workspaces[k], dx=dx, mode=mod.mode)
+                                      ctx.workspaces[k], dx=dx, mode=mod.mode, outs=slots if have else None,
+                                      defer=have and nat.defer_begin(dev))
                 for d in range(2):
                     grads[4 * (k * nd + d):4 * (k * nd + d) + 4] = g[d]
             elif side is not None:
@@ -176,6 +182,7 @@ class NativeGRU(nn.Module):
                                   f"'{x.device}', need an MI355X ('cuda') device -- there is no CPU fallback")
         if x.dim() != 3 or x.shape[2] != self.input_size:
             raise ValueError(f"expected input (B,T,{self.input_size}), got {tuple(x.shape)}")
+        nat.defer_reset(x.device)              # (a previous backward pass that raised midway must not leave its queue behind)
         step = self.dropout_step
         if self.training and self.dropout > 0 and self.num_layers > 1:
             self.dropout_step += 1
