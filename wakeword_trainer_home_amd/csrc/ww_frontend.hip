@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int FR = WW_FRAMES_PER_BLOCK;
+// (frames per item: 4 per wavefront of the workgroup, see k_logmel)
 constexpr int PB_LD = 548;                   // floats per power spectrum: bin j sits at j + (j >> 4) (bank spreading)
 
 #include "ww_fft.h"
@@ -89,28 +89,33 @@ __device__ __forceinline__ void twiddle16(float (&re)[16], float (&im)[16], cons
     }
 }
 
-template <typename WaveT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// WAVES = wavefronts per workgroup (4 or 8); an item is FRW = 4 * WAVES frames (two rounds of two frames per wave).  The 8-wave
+// form shares the window / mel tables / span of 32 frames among twice the waves: 2 workgroups = 16 waves per CU (4 per SIMD)
+// where the 4-wave form's LDS allows 3 workgroups = 12 waves, and a 32-frame span re-reads 864 of 5984 samples instead of 864 of
+// 3424 (HBM-side traffic x1.2 instead of x1.38).
+template <typename WaveT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ out, int use_mask, ww_mask_params mp,
                      int32_t *__restrict__ mask_idx, int nblk, long nitems) {
+    constexpr int NT = 64 * WAVES, FRW = 4 * WAVES;
     extern __shared__ __align__(16) unsigned char smem[];
-    float *xball = reinterpret_cast<float *>(smem);                   // 4 waves x XB
-    float *wl = xball + 4 * XB;                                       // the 1024 window samples
+    float *xball = reinterpret_cast<float *>(smem);                   // WAVES x XB
+    float *wl = xball + WAVES * XB;                                       // the 1024 window samples
     float *span = wl + WW_NFFT;                                       // span_len (16-byte aligned: vector staging)
     float *lm = span + ((a.span_len + 3) & ~3);                       // FR x M (raw mel sums, then their logs)
-    float *feat = lm + FR * a.M;                                      // FR x F (== lm when !use_dct)
-    int *msk = reinterpret_cast<int *>(feat + (a.use_dct ? FR * a.F : 0));  // 2*WW_MAX_MASKS
+    float *feat = lm + FRW * a.M;                                     // FR x F (== lm when !use_dct)
+    int *msk = reinterpret_cast<int *>(feat + (a.use_dct ? FRW * a.F : 0));  // 2*WW_MAX_MASKS
     int *mtab = msk + 2 * WW_MAX_MASKS;                               // 6*M : per (band, half) first slot, 4-slot steps, weight offset
     float *mw = reinterpret_cast<float *>(mtab + 6 * a.M);            // n_melp_w band weights in the power rows' slot layout
     if (!a.use_dct) feat = lm;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // ---- once per workgroup (persistent grid): window and mel tables
-    reinterpret_cast<float4 *>(wl)[tid] = reinterpret_cast<const float4 *>(a.window)[tid];
+    for (int i = tid; i < WW_NFFT / 4; i += NT) reinterpret_cast<float4 *>(wl)[i] = reinterpret_cast<const float4 *>(a.window)[i];
     // (the tiles' pad slots are never written -- the band sums multiply them by zero weights, so they must not hold NaN patterns)
-    for (int i = tid; i < 4 * XB; i += 256) xball[i] = 0.f;
-    for (int i = tid; i < 6 * a.M; i += 256) mtab[i] = a.melp_tab[i];
-    for (int i = tid; i < a.n_melp_w; i += 256) mw[i] = a.melp_w[i];
+    for (int i = tid; i < WAVES * XB; i += NT) xball[i] = 0.f;
+    for (int i = tid; i < 6 * a.M; i += NT) mtab[i] = a.melp_tab[i];
+    for (int i = tid; i < a.n_melp_w; i += NT) mw[i] = a.melp_w[i];
     const int K = use_mask ? (mp.n_f + mp.n_t) : 0;
 
     float *xb = xball + wv * XB;
@@ -135,7 +140,7 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
     const bool special = lane == 63;                           // unit 127 (u = 1)
 
     for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const int b = (int)(item / nblk), blk = (int)(item - (long)b * nblk), t0 = blk * FR;
+        const int b = (int)(item / nblk), blk = (int)(item - (long)b * nblk), t0 = blk * FRW;
         const WaveT *x = wave + (size_t)b * a.N;
         if (tid < K) {
             int s, w;
@@ -160,10 +165,10 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                     // and at one workgroup per CU beside a training step nothing else hides them)
                     const float4 *src = reinterpret_cast<const float4 *>(x + base);
                     const int n4 = a.span_len >> 2;
-                    for (int i0 = tid; i0 < n4; i0 += 4 * 256) {
+                    for (int i0 = tid; i0 < n4; i0 += 4 * NT) {
                         float4 v[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) v[u] = src[min(i0 + 256 * u, n4 - 1)];
+                        for (int u = 0; u < 4; ++u) v[u] = src[min(i0 + NT * u, n4 - 1)];
                         // all four must be live here (else the register allocator, at this kernel's pressure, funnels them through
                         // ONE register quad: load, wait, store, load ...); the stores are unconditional too (a clamped slot is
                         // rewritten with its own value): behind a guard the compiler sinks each load next to its store again
@@ -171,17 +176,17 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                                      "+v"(v[1].z), "+v"(v[1].w), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w),
                                      "+v"(v[3].x), "+v"(v[3].y), "+v"(v[3].z), "+v"(v[3].w));
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) reinterpret_cast<float4 *>(span)[min(i0 + 256 * u, n4 - 1)] = v[u];
+                        for (int u = 0; u < 4; ++u) reinterpret_cast<float4 *>(span)[min(i0 + NT * u, n4 - 1)] = v[u];
                     }
-                    for (int i = 4 * n4 + tid; i < a.span_len; i += 256) span[i] = x[base + i];
+                    for (int i = 4 * n4 + tid; i < a.span_len; i += NT) span[i] = x[base + i];
                 }
             }
             if (!fast) {
-                for (int i0 = tid; i0 < a.span_len; i0 += 8 * 256) {      // same batching for the reflected / int16 / unaligned spans
+                for (int i0 = tid; i0 < a.span_len; i0 += 8 * NT) {      // same batching for the reflected / int16 / unaligned spans
                     float v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        long idx = base + min(i0 + 256 * u, a.span_len - 1);
+                        long idx = base + min(i0 + NT * u, a.span_len - 1);
                         if (idx < 0) idx = -idx;
                         if (idx >= a.N) idx = 2L * (a.N - 1) - idx;
                         idx = idx < 0 ? 0 : (idx >= a.N ? a.N - 1 : idx);  // only frames >= T can get here
@@ -189,14 +194,14 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                     }
                     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) span[min(i0 + 256 * u, a.span_len - 1)] = v[u];
+                    for (int u = 0; u < 8; ++u) span[min(i0 + NT * u, a.span_len - 1)] = v[u];
                 }
             }
         }
         __syncthreads();
 
         for (int round = 0; round < 2; ++round) {
-            const int fa = round * 8 + 2 * wv, fb = fa + 1;  // local frame indices of this wave's pair
+            const int fa = round * 2 * WAVES + 2 * wv, fb = fa + 1;  // local frame indices of this wave's pair
             // a clip's last block holds frames past T (T = 151: 7 of its 16 are real): a pair with no real frame is skipped
             // (wave-uniform; nothing below reads what such a pair would have written -- the write-out guards t < T)
             if (t0 + fa >= a.T) continue;
@@ -310,11 +315,11 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
             wave_sync();
         }
         __syncthreads();
-        for (int it = tid; it < FR * a.M; it += 256) lm[it] = logf(lm[it] + a.log_eps);
+        for (int it = tid; it < FRW * a.M; it += NT) lm[it] = logf(lm[it] + a.log_eps);
         __syncthreads();
 
         if (a.use_dct) {
-            for (int it = tid; it < FR * a.F; it += 256) {
+            for (int it = tid; it < FRW * a.F; it += NT) {
                 const int fr = it / a.F, c = it - fr * a.F;
                 const float *d = a.dct + (size_t)c * a.M;
                 const float *l = lm + fr * a.M;
@@ -326,8 +331,8 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
         }
 
         // ---- masked, transposed write-out: out[b][0][f][t0 + i]
-        for (int it = tid; it < a.F * FR; it += 256) {
-            const int f = it / FR, i = it - f * FR;
+        for (int it = tid; it < a.F * FRW; it += NT) {
+            const int f = it / FRW, i = it - f * FRW;
             const int t = t0 + i;
             if (t < a.T) {
                 float v = feat[i * a.F + f];
@@ -510,7 +515,12 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
     a.window = tb->window; a.twiddle = tb->twiddle;
     a.mel_start = tb->mel_start; a.mel_len = tb->mel_len; a.mel_off = tb->mel_off; a.mel_w = tb->mel_w;
     a.dct = tb->dct;
-    a.span_len = (FR - 1) * cfg->hop + WW_NFFT;
+    // workgroup form: 8 waves / 32-frame items when the kernel has the device to itself, 4 waves / 16 frames when it runs
+    // beside a training step with a caller-chosen number of workgroups (half the per-CU footprint); WW_LOGMEL_WAVES overrides
+    static const int waves_env = ww_env_int("WW_LOGMEL_WAVES", 0);
+    const int waves = (waves_env == 4 || waves_env == 8) ? waves_env : (ctx->logmel_wgs > 0 ? 4 : 8);
+    const int FRW = 4 * waves;
+    a.span_len = (FRW - 1) * cfg->hop + WW_NFFT;
     a.n_mel_w = tb->n_mel_w;
     a.melp_tab = tb->melp_tab; a.melp_w = tb->melp_w; a.n_melp_w = tb->n_melp_w;
     ww_mask_params mp = {};
@@ -537,26 +547,26 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
         WW_LAUNCH_CHECK();
         return WW_OK;
     }
-    const size_t smem = ((size_t)4 * XB + WW_NFFT + ((a.span_len + 3) & ~3) + (size_t)FR * a.M +
-                         (a.use_dct ? (size_t)FR * a.F : 0) + 2 * WW_MAX_MASKS + (size_t)6 * a.M + a.n_melp_w) * sizeof(float);
+    const size_t smem = ((size_t)waves * XB + WW_NFFT + ((a.span_len + 3) & ~3) + (size_t)FRW * a.M +
+                         (a.use_dct ? (size_t)FRW * a.F : 0) + 2 * WW_MAX_MASKS + (size_t)6 * a.M + a.n_melp_w) * sizeof(float);
     // Persistent grid: ctx->logmel_wgs workgroups (ww_ctx_set_logmel_workgroups; WW_LOGMEL_WGS overrides it for tuning),
     // 0 = one full residency round of the device.
-    const int nblk = (a.T + FR - 1) / FR;
+    const int nblk = (a.T + FRW - 1) / FRW;
     const long nitems = (long)nblk * B;
     static const long wgs_env = [] { const char *e = getenv("WW_LOGMEL_WGS"); return e ? atol(e) : 0L; }();
-    const void *fn = wave_dtype == WW_WAVE_F32 ? (const void *)k_logmel<float> : (const void *)k_logmel<int16_t>;
+    const bool f32 = wave_dtype == WW_WAVE_F32;
+    const void *fn = waves == 8 ? (f32 ? (const void *)k_logmel<float, 8> : (const void *)k_logmel<int16_t, 8>)
+                                : (f32 ? (const void *)k_logmel<float, 4> : (const void *)k_logmel<int16_t, 4>);
     WW_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     long wgs = wgs_env > 0 ? wgs_env : ctx->logmel_wgs;
-    if (wgs <= 0) wgs = ww_occupancy_grid(fn, 256, smem, nitems, 1 << 20);
+    if (wgs <= 0) wgs = ww_occupancy_grid(fn, 64 * waves, smem, nitems, 1 << 20);
     dim3 grid((unsigned)(nitems < wgs ? nitems : wgs));
     hipStream_t st = (hipStream_t)stream;
     ww_prof_scope ps_(ctx, WW_K_LOGMEL, st);
-    if (wave_dtype == WW_WAVE_F32)
-        hipLaunchKernelGGL(k_logmel<float>, grid, dim3(256), smem, st, (const float *)wave, a, out, use_mask, mp,
-                           mask_idx, nblk, nitems);
-    else
-        hipLaunchKernelGGL(k_logmel<int16_t>, grid, dim3(256), smem, st, (const int16_t *)wave, a, out, use_mask, mp,
-                           mask_idx, nblk, nitems);
+#define WW_LOGMEL_GO(T_, W_) hipLaunchKernelGGL((k_logmel<T_, W_>), grid, dim3(64 * W_), smem, st, (const T_ *)wave, a, out, use_mask, mp, mask_idx, nblk, nitems)
+    if (waves == 8) { if (f32) WW_LOGMEL_GO(float, 8); else WW_LOGMEL_GO(int16_t, 8); }
+    else { if (f32) WW_LOGMEL_GO(float, 4); else WW_LOGMEL_GO(int16_t, 4); }
+#undef WW_LOGMEL_GO
     WW_LAUNCH_CHECK();
     return WW_OK;
 }
