@@ -4,6 +4,7 @@ The device work is not exercised here (no GPU): the Trainer drives the plain-tor
 its generic-module step, which must reproduce the reference Trainer's trace exactly."""
 import ctypes
 import json
+import os
 import re
 from pathlib import Path
 
@@ -441,3 +442,21 @@ def test_pending_batch_counts_do_not_survive_a_load_and_modules_pickle():
     clone = pickle.loads(pickle.dumps(bn))
     clone._pending_tracked = 1
     assert int(clone.state_dict()["num_batches_tracked"]) == 11
+
+
+@pytest.mark.timeout(300)
+def test_bench_spawner_starts_its_ranks_and_fails_loudly_without_a_gpu():
+    """``python bench.py --gpus 2`` with no launcher: the parent starts its own two ranks (torch.distributed.run, before anything
+    touches HIP) and relays rank 0's line.  Off an MI355X every rank must refuse loudly -- the hot path has no CPU fallback -- so
+    the parent exits non-zero with NOTHING on stdout (a consumer parsing one JSON line sees none) and the reason on stderr.
+    (The same path with two real ranks on the GPU: tests/test_data_parallel_gpu.py.)"""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the N-rank command path is covered by the -m gpu suite")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, env=env, timeout=280)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "needs an MI355X" in r.stderr

@@ -326,6 +326,54 @@ __global__ __launch_bounds__(256) void k_bn_act_apply_fin(const float *__restric
     }
 }
 
+// BatchNorm(+activation) backward apply pass that finishes the statistics pass's chunk partials itself (the backward twin of
+// k_bn_act_apply_fin): statistics + this = 2 launches instead of statistics, finish, apply.  Every workgroup re-reads the partial
+// columns of its channel group (<= 32 KB, L2-resident), so it is taken for SMALL layers only (ww_bn_act_bwd): there the finish
+// launch is a 4.8 us latency chain between two other short kernels; on a tall layer the re-read costs more than the launch.
+__global__ __launch_bounds__(256) void k_bnact_bwd_apply_fin(const float *__restrict__ x, const float *__restrict__ da,
+                                                             const float *__restrict__ part, int chunks, long M, int C, BnTile t,
+                                                             const float *__restrict__ ss, const float *__restrict__ mr, int act,
+                                                             float *__restrict__ dx, float *__restrict__ dgamma,
+                                                             float *__restrict__ dbeta) {
+    __shared__ double redd[256 * 4];
+    __shared__ double tot[128];
+    __shared__ __align__(16) float sums[128];
+    const int gc = blockIdx.x % t.G_c, c0 = gc * 4 * t.CG4, CG = 4 * t.CG4;
+    const long rc = blockIdx.x / t.G_c;
+    bn_group_totals(part, chunks, C, c0, t.CG4, tot, redd);
+    if (threadIdx.x < CG) {
+        const float s1 = (float)tot[threadIdx.x], s2 = (float)tot[CG + threadIdx.x];
+        sums[threadIdx.x] = s1; sums[CG + threadIdx.x] = s2;
+        if (rc == 0 && c0 + threadIdx.x < C) { dbeta[c0 + threadIdx.x] = s1; dgamma[c0 + threadIdx.x] = s2; }
+    }
+    __syncthreads();
+    const int cq = threadIdx.x % t.CG4, rl = threadIdx.x / t.CG4;
+    if (rl >= t.R || c0 + 4 * cq >= C) return;
+    const size_t col = (size_t)c0 + 4 * cq;
+    const float4 sc = *reinterpret_cast<const float4 *>(ss + col), sf = *reinterpret_cast<const float4 *>(ss + C + col);
+    const float4 mu = *reinterpret_cast<const float4 *>(mr + col), rs = *reinterpret_cast<const float4 *>(mr + C + col);
+    const float4 s1 = *reinterpret_cast<const float4 *>(sums + 4 * cq), s2 = *reinterpret_cast<const float4 *>(sums + CG + 4 * cq);
+    const float invM = 1.0f / (float)M;
+    const long r0 = rc * t.rows_per_block, r1 = min(M, r0 + t.rows_per_block);
+    for (long rb = r0 + rl; rb < r1; rb += 4L * t.R) {
+        float4 xv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t o = (size_t)min(rb + (long)u * t.R, r1 - 1) * C + col;
+            xv[u] = *reinterpret_cast<const float4 *>(x + o);
+            dv[u] = *reinterpret_cast<const float4 *>(da + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (rb + (long)u * t.R < r1)
+                *reinterpret_cast<float4 *>(dx + (size_t)(rb + (long)u * t.R) * C + col) =
+                    make_float4(bnact_bwd_one(xv[u].x, dv[u].x, sc.x, sf.x, mu.x, rs.x, s1.x, s2.x, invM, act, 1),
+                                bnact_bwd_one(xv[u].y, dv[u].y, sc.y, sf.y, mu.y, rs.y, s1.y, s2.y, invM, act, 1),
+                                bnact_bwd_one(xv[u].z, dv[u].z, sc.z, sf.z, mu.z, rs.z, s1.z, s2.z, invM, act, 1),
+                                bnact_bwd_one(xv[u].w, dv[u].w, sc.w, sf.w, mu.w, rs.w, s1.w, s2.w, invM, act, 1));
+    }
+}
+
 // ---- depthwise k x k, stride s, padding k/2.  thread = (output pixel, 4 channels); w (C,1,k,k) as in nn.Conv2d
 struct DwG { int B, H, W, C, k, s, Ho, Wo; };
 __global__ __launch_bounds__(256) void k_dwg_fwd(const float *__restrict__ x, const float *__restrict__ w, DwG g,
@@ -1105,6 +1153,19 @@ extern "C" int ww_bn_act_bwd(ww_ctx *ctx, const float *x, const float *da, long 
     hipLaunchKernelGGL(k_bnact_bwd_stats, dim3(chunks), dim3(C * R), (size_t)2 * R * C * sizeof(double), st, x, da, ss, mr, M, C, R,
                        act, (M + chunks - 1) / chunks, part);
     WW_LAUNCH_CHECK();
+    // the apply pass finishes the partials itself (2 launches instead of 3) up to WW_BN_BWD_FUSED_MAX_KB of activation tensor:
+    // MobileNetV3 B=256 step 2.414 / 2.398 / 2.393 / 2.385 / 2.388 ms at 0 / 1 / 4 / 16 / 64 MB (profiles/r03_p_*)
+    static const long fused_max = (long)ww_env_int("WW_BN_BWD_FUSED_MAX_KB", 16384) * 1024;
+    if (training && M * C * (long)sizeof(float) <= fused_max && vec4_ok(M * C, C, {x, da, dx, ss, mr, part})) {
+        const BnTile t = bn_tile(M, C, chunks);
+        if (t.CG4) {
+            const int blocks = (int)((M + t.rows_per_block - 1) / t.rows_per_block) * t.G_c;
+            hipLaunchKernelGGL(k_bnact_bwd_apply_fin, dim3(blocks), dim3(256), 0, st, x, da, part, chunks, M, C, t, ss, mr, act, dx,
+                               dgamma, dbeta);
+            WW_LAUNCH_CHECK();
+            return WW_OK;
+        }
+    }
     hipLaunchKernelGGL(k_bnact_bwd_finish, dim3((C + 63) / 64), dim3(1024), 0, st, part, chunks, C, sums, dgamma, dbeta);
     WW_LAUNCH_CHECK();
     if (vec4_ok(M * C, C, {x, da, dx, ss, mr, sums}))
