@@ -13,5 +13,6 @@ cat $O/step.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 tools/bench_models.py mobilenetv3 256 bf16 --graph > $O/step_under_rocprof.json 2>/dev/null
 cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 python tools/kernel_trace_by_grid.py $(ls $O/kt/*/*kernel_trace.csv | head -1) k_se k_dwg k_bn k_colstats k_gemm k_splitk k_colsum > $O/by_grid.txt
+python tools/launches_per_replay.py $(ls $O/kt/*/*kernel_trace.csv | head -1) | tee $O/launches_per_replay.txt
 rm -rf $O/kt
 python tools/kernel_stats_top.py $O/kernel_stats.csv 40

@@ -318,7 +318,7 @@ class Trainer:
         self._reduce_inline(buf)
         torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
 
-    # Overlapped all-reduce for bucketed autograd models (MobileNetV3: one 6.1 MB fp32 bucket).  The bucket is in parameters()
+    # Overlapped all-reduce for bucketed autograd models (MobileNetV3: one 5.8 MB fp32 bucket).  The bucket is in parameters()
     # order, so its TAIL holds the late layers, whose gradients the backward produces FIRST.  The tail (>= half of the bytes:
     # from the last inverted-residual blocks on) is all-reduced on the process group's stream as soon as its last gradient
     # has been accumulated, under the backward of the early layers; the head follows in-stream after the backward.  Each
@@ -338,8 +338,11 @@ class Trainer:
     def _overlap_arm(self):
         """Hooks on the tail's parameters (once): the LAST of them to receive its gradient starts the tail's all-reduce."""
         plist, views = self.model._fb_plist, self.model._fb_views
-        if self._ov is not None and self._ov["ptr"] == self.model.flat_param.data_ptr():
-            return self._ov
+        if self._ov is not None:
+            if self._ov["ptr"] == self.model.flat_param.data_ptr():
+                return self._ov
+            for h in self._ov["hooks"]:                            # the bucket was rebuilt (model.to(...)): new slots, new hooks
+                h.remove()
         total, acc, first = self.model.flat_grad.numel(), 0, len(plist)
         for i in range(len(plist) - 1, -1, -1):                    # smallest tail holding at least half of the elements
             acc += plist[i].numel()
