@@ -281,26 +281,28 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
             }
     }
     // padded-slot form of the band weights (k_logmel, n_fft 1024): two lanes share a band, each sums its half as a run of
-    // consecutive LDS slots of the power row -- no per-bin index arithmetic, adjacent slots pair into ds_read2
+    // consecutive LDS slots of the power row, read as aligned float4s, FOUR of them (16 slots) per trip with all eight loads of
+    // a trip in flight together: table entry = {first slot (a multiple of 4), trips, weight offset (a multiple of 4)}; weights are
+    // zero at the row's pad slots, before the half's first bin and after its last one
     std::vector<int32_t> ptab;
     std::vector<float> pw;
     for (int m = 0; m < M; ++m) {
         const int L = len[m], h0 = (L + 1) >> 1;
         for (int half = 0; half < 2; ++half) {
             const int j0 = half ? h0 : 0, j1 = half ? L : h0;
-            int slot0 = 0, steps = 0;
+            int slot0 = 0, trips = 0;
             const int woff = (int)pw.size();
             if (j1 > j0) {
                 const int b0 = start[m] + j0, b1 = start[m] + j1 - 1;
-                slot0 = b0 + (b0 >> 4);
+                slot0 = (b0 + (b0 >> 4)) & ~3;
                 const int slot1 = b1 + (b1 >> 4);
-                steps = (slot1 - slot0 + 1 + 3) / 4;
-                for (int p = slot0; p < slot0 + 4 * steps; ++p) {
+                trips = (slot1 - slot0 + 1 + 15) / 16;
+                for (int p = slot0; p < slot0 + 16 * trips; ++p) {
                     const int q = p / 17, r = p % 17, b = 16 * q + r;            // slot -> bin (r == 16: a pad slot)
                     pw.push_back((r != 16 && b >= b0 && b <= b1) ? w[off[m] + (b - start[m])] : 0.f);
                 }
             }
-            ptab.push_back(slot0); ptab.push_back(steps); ptab.push_back(woff);
+            ptab.push_back(slot0); ptab.push_back(trips); ptab.push_back(woff);
         }
     }
     ww_feat_tables *t = new ww_feat_tables();

@@ -93,6 +93,13 @@ __device__ __forceinline__ void twiddle16(float (&re)[16], float (&im)[16], cons
 // form shares the window / mel tables / span of 32 frames among twice the waves: 2 workgroups = 16 waves per CU (4 per SIMD)
 // where the 4-wave form's LDS allows 3 workgroups = 12 waves, and a 32-frame span re-reads 864 of 5984 samples instead of 864 of
 // 3424 (HBM-side traffic x1.2 instead of x1.38).
+#ifdef WW_LOGMEL_STAMPS
+// phase stamps (s_memtime) of one wave of one workgroup while it processes its third item: tools/logmel_stamps.py
+__device__ unsigned long long ww_logmel_stamps[32];
+#define WW_STAMP(i) do { if (stamp_on) ww_logmel_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WW_STAMP(i) do { } while (0)
+#endif
 template <typename WaveT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ out, int use_mask, ww_mask_params mp,
@@ -106,7 +113,7 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
     float *feat = lm + FRW * a.M;                                     // FR x F (== lm when !use_dct)
     int *msk = reinterpret_cast<int *>(feat + (a.use_dct ? FRW * a.F : 0));  // 2*WW_MAX_MASKS
     int *mtab = msk + 2 * WW_MAX_MASKS;                               // 6*M : per (band, half) first slot, 4-slot steps, weight offset
-    float *mw = reinterpret_cast<float *>(mtab + 6 * a.M);            // n_melp_w band weights in the power rows' slot layout
+    float *mw = reinterpret_cast<float *>(mtab + ((6 * a.M + 3) & ~3));   // n_melp_w band weights in the power rows' slot layout (16-B aligned)
     if (!a.use_dct) feat = lm;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -138,8 +145,21 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
         kbase[u] = 16 * kcA + kbA;
     }
     const bool special = lane == 63;                           // unit 127 (u = 1)
+    // The NEXT item's span is fetched into registers while the current item's tail (log pass, write-out) runs, and stored to
+    // LDS at the top of the next trip: the ~1.2 us HBM round trip of the staging was exposed once per item (10 % of an item by
+    // the s_memtime stamps, tools/logmel_stamps.py).  Interior, 16-byte-aligned fp32 spans of <= 4 float4 per thread only.
+    float4 pre[4];
+    bool pre_ok = false;
+    auto fast_span = [&](int bb, long base_) {
+        return sizeof(WaveT) == 4 && base_ >= 0 && base_ + a.span_len <= a.N && (((size_t)bb * a.N + (size_t)base_) & 3) == 0 &&
+               (reinterpret_cast<uintptr_t>(wave) & 15) == 0;
+    };
 
     for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
+#ifdef WW_LOGMEL_STAMPS
+        const bool stamp_on = blockIdx.x == 7 && tid == 0 && item == 7 + 2L * gridDim.x;
+#endif
+        WW_STAMP(0);
         const int b = (int)(item / nblk), blk = (int)(item - (long)b * nblk), t0 = blk * FRW;
         const WaveT *x = wave + (size_t)b * a.N;
         if (tid < K) {
@@ -157,9 +177,13 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
             bool fast = false;
             if constexpr (sizeof(WaveT) == 4) {
                 // interior span on a 16-byte boundary (hop 160, N 24000: every item but the first and last of a clip)
-                fast = base >= 0 && base + a.span_len <= a.N && (((size_t)b * a.N + (size_t)base) & 3) == 0 &&
-                       (reinterpret_cast<uintptr_t>(wave) & 15) == 0;
-                if (fast) {
+                fast = fast_span(b, base);
+                if (fast && pre_ok) {                                  // fetched during the previous item's tail
+                    const int n4 = a.span_len >> 2;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) reinterpret_cast<float4 *>(span)[min(tid + NT * u, n4 - 1)] = pre[u];
+                    for (int i = 4 * n4 + tid; i < a.span_len; i += NT) span[i] = x[base + i];
+                } else if (fast) {
                     // a thread's float4s of the span in batches of four unconditional (clamped) loads: as a plain copy loop
                     // every float4 was its own load -> wait -> LDS store round trip (3-4 dependent HBM latencies per item,
                     // and at one workgroup per CU beside a training step nothing else hides them)
@@ -199,6 +223,7 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
             }
         }
         __syncthreads();
+        WW_STAMP(1);
 
         for (int round = 0; round < 2; ++round) {
             const int fa = round * 2 * WAVES + 2 * wv, fb = fa + 1;  // local frame indices of this wave's pair
@@ -218,11 +243,14 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                     im[j] = w * sb[64 * j];
                 }
             }
+            WW_STAMP(2 + 8 * round);
             fft16(re, im);
+            WW_STAMP(3 + 8 * round);
             {
                 const Tw6 tw1 = load_tw6(a.twiddle, tb1);
                 twiddle16(re, im, tw1);
             }
+            WW_STAMP(4 + 8 * round);
             // exchange 1 (planar): real parts through the tile, then the imaginary parts
 #pragma unroll
             for (int k = 0; k < 16; ++k) p1[k * PROW] = re[F16_SLOT(k)];
@@ -237,12 +265,14 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
             for (int m = 0; m < 16; ++m) im[m] = p2[4 * m];
             wave_sync();
             // ---- pass 2: lane = kb*4 + q ; radix-16 over m (n1 = 4m + q), twiddle W64^(q*kc); written back in place
+            WW_STAMP(5 + 8 * round);
             fft16(re, im);
             {
                 const Tw6 tw2 = load_tw6(a.twiddle, tb2);        // (fetching both passes' factors at the top of the round: 128
                 twiddle16(re, im, tw2);                          //  VGPRs, 149 us alone either way, 1.260 vs 1.238 ms in the step)
             }
             // exchange 2 (planar) straight into the pass-3 butterflies' registers
+            WW_STAMP(6 + 8 * round);
             float4 ar[2], ai[2], br[2], bi[2];
 #pragma unroll
             for (int k = 0; k < 16; ++k) p2[4 * k] = re[F16_SLOT(k)];
@@ -263,6 +293,7 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
             }
             wave_sync();
             // ---- pass 3 fused with the separation of the two real spectra; |.|^2 of both frames into the tile's power rows
+            WW_STAMP(7 + 8 * round);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 fft4(ar[u].x, ai[u].x, ar[u].y, ai[u].y, ar[u].z, ai[u].z, ar[u].w, ai[u].w);
@@ -289,6 +320,7 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                 }
             }
             wave_sync();
+            WW_STAMP(8 + 8 * round);
             // ---- mel band sums: item = ((frame, mel), half); the two halves of a band sit in adjacent lanes.  A half is a run of
             // consecutive slots of the power row (weights stored in the same slot layout, zero at the row's pad slots, which
             // hold finite leftovers of the exchange): four slots per step, no per-bin index arithmetic
@@ -299,24 +331,58 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                 const int fr = pair >= a.M ? 1 : 0;
                 const int m = pair - fr * a.M;
                 const int *e = mtab + 3 * (2 * m + half);
-                const int steps = act ? e[1] : 0;
-                const float *wp = mw + e[2];
-                const float *pp = xb + fr * PB_LD + e[0];
-                float acc = 0.f;
-                for (int i = 0; i < steps; ++i) {
-                    acc = fmaf(wp[4 * i], pp[4 * i], acc);
-                    acc = fmaf(wp[4 * i + 1], pp[4 * i + 1], acc);
-                    acc = fmaf(wp[4 * i + 2], pp[4 * i + 2], acc);
-                    acc = fmaf(wp[4 * i + 3], pp[4 * i + 3], acc);
+#ifdef WW_LOGMEL_NOMEL
+                const int trips = 0;                 // experiment: what the band-sum loop costs (results are wrong)
+#else
+                const int trips = act ? e[1] : 0;
+#endif
+                const float4 *wp = reinterpret_cast<const float4 *>(mw + e[2]);
+                const float4 *pp = reinterpret_cast<const float4 *>(xb + fr * PB_LD + e[0]);
+                // a trip = 16 slots: its eight 16-byte LDS loads are issued together, then 16 FMAs on two partial sums.  (As a
+                // load -> fma chain of four slots per step the loop was one LDS round trip per step, ~27 per round: 43 % of
+                // the kernel -- 155 us with it, 88 without, `tools/logmel_stamps.py`.)  Slots past a half's end carry zero
+                // weights; the power values read there are finite leftovers of this clip's own tiles.
+                float acc = 0.f, acc2 = 0.f;
+                for (int i = 0; i < trips; ++i) {
+                    const float4 w0 = wp[4 * i], w1 = wp[4 * i + 1], w2 = wp[4 * i + 2], w3 = wp[4 * i + 3];
+                    const float4 q0 = pp[4 * i], q1 = pp[4 * i + 1], q2 = pp[4 * i + 2], q3 = pp[4 * i + 3];
+                    acc = fmaf(w0.x, q0.x, acc); acc2 = fmaf(w0.y, q0.y, acc2); acc = fmaf(w0.z, q0.z, acc); acc2 = fmaf(w0.w, q0.w, acc2);
+                    acc = fmaf(w1.x, q1.x, acc); acc2 = fmaf(w1.y, q1.y, acc2); acc = fmaf(w1.z, q1.z, acc); acc2 = fmaf(w1.w, q1.w, acc2);
+                    acc = fmaf(w2.x, q2.x, acc); acc2 = fmaf(w2.y, q2.y, acc2); acc = fmaf(w2.z, q2.z, acc); acc2 = fmaf(w2.w, q2.w, acc2);
+                    acc = fmaf(w3.x, q3.x, acc); acc2 = fmaf(w3.y, q3.y, acc2); acc = fmaf(w3.z, q3.z, acc); acc2 = fmaf(w3.w, q3.w, acc2);
                 }
+                acc += acc2;
                 acc += __shfl_xor(acc, 1);
                 if (act && half == 0) lm[(fa + fr) * a.M + m] = acc;
             }
             wave_sync();
+            WW_STAMP(9 + 8 * round);
         }
         __syncthreads();
+        WW_STAMP(18);
+        pre_ok = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);      // (ends the old values' live range before the rounds)
+        if constexpr (sizeof(WaveT) == 4) {
+            const long nitem = item + gridDim.x;
+            const int n4 = a.span_len >> 2;
+            if (nitem < nitems && n4 <= 4 * NT) {
+                const int nb = (int)(nitem / nblk);
+                const long nbase = (long)((int)(nitem - (long)nb * nblk) * FRW) * a.hop - WW_NFFT / 2;
+                if (fast_span(nb, nbase)) {
+                    const float4 *src = reinterpret_cast<const float4 *>(wave + (size_t)nb * a.N + nbase);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pre[u] = src[min(tid + NT * u, n4 - 1)];
+                    asm volatile("" : "+v"(pre[0].x), "+v"(pre[0].y), "+v"(pre[0].z), "+v"(pre[0].w), "+v"(pre[1].x), "+v"(pre[1].y),
+                                 "+v"(pre[1].z), "+v"(pre[1].w), "+v"(pre[2].x), "+v"(pre[2].y), "+v"(pre[2].z), "+v"(pre[2].w),
+                                 "+v"(pre[3].x), "+v"(pre[3].y), "+v"(pre[3].z), "+v"(pre[3].w));
+                    pre_ok = true;
+                }
+            }
+        }
         for (int it = tid; it < FRW * a.M; it += NT) lm[it] = logf(lm[it] + a.log_eps);
         __syncthreads();
+        WW_STAMP(19);
 
         if (a.use_dct) {
             for (int it = tid; it < FRW * a.F; it += NT) {
@@ -330,23 +396,44 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
             __syncthreads();
         }
 
-        // ---- masked, transposed write-out: out[b][0][f][t0 + i]
-        for (int it = tid; it < a.F * FRW; it += NT) {
-            const int f = it / FRW, i = it - f * FRW;
-            const int t = t0 + i;
-            if (t < a.T) {
-                float v = feat[i * a.F + f];
-                for (int k = 0; k < K; ++k) {
-                    const int s = msk[2 * k], w = msk[2 * k + 1];
-                    const int pos = k < mp.n_f ? f : t;
-                    if (pos >= s && pos < s + w) v = 0.f;
+        // ---- masked, transposed write-out: out[b][0][f][t0 + i].  A thread's frame index i is the same for all of its elements
+        // (FRW divides the workgroup size), so the masks are folded ONCE per item into a time flag and a 128-bit set of masked
+        // feature rows (2K LDS reads, one round trip); per element it is then one LDS read and a bit test (it was 2K LDS
+        // reads per element: 11 % of an item by the s_memtime stamps)
+        {
+            const int i = tid % FRW, t = t0 + i;
+            bool tmask = false;
+            unsigned long long fm0 = 0ull, fm1 = 0ull;
+            for (int k = 0; k < K; ++k) {
+                const int s_ = msk[2 * k], w_ = msk[2 * k + 1];
+                if (k < mp.n_f) {
+                    const int lo0 = max(s_, 0), hi0 = min(s_ + w_, 64), lo1 = max(s_, 64) - 64, hi1 = min(s_ + w_, 128) - 64;
+                    if (hi0 > lo0) fm0 |= (hi0 - lo0 >= 64 ? ~0ull : ((1ull << (hi0 - lo0)) - 1ull)) << lo0;
+                    if (hi1 > lo1) fm1 |= (hi1 - lo1 >= 64 ? ~0ull : ((1ull << (hi1 - lo1)) - 1ull)) << lo1;
+                } else {
+                    tmask = tmask || (t >= s_ && t < s_ + w_);
                 }
-                out[((size_t)b * a.F + f) * a.T + t] = v;
             }
+            if (t < a.T)
+                for (int f = tid / FRW; f < a.F; f += NT / FRW) {
+                    const bool fmask = ((f < 64 ? fm0 >> f : fm1 >> (f - 64)) & 1ull) != 0ull;
+                    const float v = (tmask || fmask) ? 0.f : feat[i * a.F + f];
+                    out[((size_t)b * a.F + f) * a.T + t] = v;
+                }
         }
+        WW_STAMP(20);
         __syncthreads();   // the next item restages span / masks / lm
+        WW_STAMP(21);
     }
 }
+
+#ifdef WW_LOGMEL_STAMPS
+}  // namespace
+extern "C" int ww_debug_logmel_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ww_logmel_stamps), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+namespace {
+#endif
 
 
 // ---- any other power-of-two n_fft (the reference's validator accepts 256 ... 4096, src/config/validator.py:129; 1024 is its
@@ -548,7 +635,7 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
         return WW_OK;
     }
     const size_t smem = ((size_t)waves * XB + WW_NFFT + ((a.span_len + 3) & ~3) + (size_t)FRW * a.M +
-                         (a.use_dct ? (size_t)FRW * a.F : 0) + 2 * WW_MAX_MASKS + (size_t)6 * a.M + a.n_melp_w) * sizeof(float);
+                         (a.use_dct ? (size_t)FRW * a.F : 0) + 2 * WW_MAX_MASKS + (size_t)((6 * a.M + 3) & ~3) + a.n_melp_w) * sizeof(float);
     // Persistent grid: ctx->logmel_wgs workgroups (ww_ctx_set_logmel_workgroups; WW_LOGMEL_WGS overrides it for tuning),
     // 0 = one full residency round of the device.
     const int nblk = (a.T + FRW - 1) / FRW;
