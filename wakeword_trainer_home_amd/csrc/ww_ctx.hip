@@ -299,7 +299,9 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
                 trips = (slot1 - slot0 + 1 + 15) / 16;
                 for (int p = slot0; p < slot0 + 16 * trips; ++p) {
                     const int q = p / 17, r = p % 17, b = 16 * q + r;            // slot -> bin (r == 16: a pad slot)
-                    pw.push_back((r != 16 && b >= b0 && b <= b1) ? w[off[m] + (b - start[m])] : 0.f);
+                    // (x 1/4: the kernel's power rows hold 4 |X|^2 -- the two real spectra come out of one complex FFT as sums /
+                    //  differences of X[k] and X[N-k] without their 1/2)
+                    pw.push_back((r != 16 && b >= b0 && b <= b1) ? 0.25f * w[off[m] + (b - start[m])] : 0.f);
                 }
             }
             ptab.push_back(slot0); ptab.push_back(trips); ptab.push_back(woff);

@@ -157,21 +157,11 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
 
     for (long item = blockIdx.x; item < nitems; item += gridDim.x) {
 #ifdef WW_LOGMEL_STAMPS
-        const bool stamp_on = blockIdx.x == 7 && tid == 0 && item == 7 + 2L * gridDim.x;
+        const bool stamp_on = blockIdx.x == 5 && tid == 0 && item == 5 + 2L * gridDim.x;      // (an interior block at 256 and 768 workgroups)
 #endif
         WW_STAMP(0);
         const int b = (int)(item / nblk), blk = (int)(item - (long)b * nblk), t0 = blk * FRW;
         const WaveT *x = wave + (size_t)b * a.N;
-        if (tid < K) {
-            int s, w;
-            ww_specaug_mask(mp, (uint32_t)(mp.sample_offset + (uint64_t)b), tid, a.F, a.T, s, w);
-            msk[2 * tid] = s;
-            msk[2 * tid + 1] = w;
-            if (mask_idx && blk == 0) {
-                mask_idx[((size_t)b * K + tid) * 2] = s;
-                mask_idx[((size_t)b * K + tid) * 2 + 1] = w;
-            }
-        }
         {
             const long base = (long)t0 * a.hop - WW_NFFT / 2;
             bool fast = false;
@@ -269,7 +259,9 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
             fft16(re, im);
             {
                 const Tw6 tw2 = load_tw6(a.twiddle, tb2);        // (fetching both passes' factors at the top of the round: 128
-                twiddle16(re, im, tw2);                          //  VGPRs, 149 us alone either way, 1.260 vs 1.238 ms in the step)
+                twiddle16(re, im, tw2);                          //  VGPRs, 149 us alone either way, 1.260 vs 1.238 ms in the step;
+                                                                 //  all 15 factors of a pass straight from the table instead of 6 +
+                                                                 //  nine complex products: 133 us alone against 116)
             }
             // exchange 2 (planar) straight into the pass-3 butterflies' registers
             WW_STAMP(6 + 8 * round);
@@ -303,8 +295,8 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                     const int pj = j + (j >> 4);
                     const float pr = xr_ + yr_, pi = xi_ - yi_;     // 2 * spectrum of frame a
                     const float qr = xi_ + yi_, qi = xr_ - yr_;     // 2 * spectrum of frame b (up to the sign of its imaginary part)
-                    xb[pj] = 0.25f * (pr * pr + pi * pi);
-                    xb[PB_LD + pj] = 0.25f * (qr * qr + qi * qi);
+                    xb[pj] = pr * pr + pi * pi;                     // 4 |X_a|^2: the 1/4 sits in the band weights (ww_ctx.hip)
+                    xb[PB_LD + pj] = qr * qr + qi * qi;
                 };
                 if (!(u == 1 && special)) {
                     emit(ar[u].x, ai[u].x, br[u].w, bi[u].w, kbase[u]);
@@ -360,6 +352,18 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
         }
         __syncthreads();
         WW_STAMP(18);
+        // the clip's SpecAugment masks (Philox, a handful of lanes): only the write-out needs them, so they are drawn here, beside
+        // the log pass, instead of in front of the staging barrier every wave waits at
+        if (tid < K) {
+            int s, w;
+            ww_specaug_mask(mp, (uint32_t)(mp.sample_offset + (uint64_t)b), tid, a.F, a.T, s, w);
+            msk[2 * tid] = s;
+            msk[2 * tid + 1] = w;
+            if (mask_idx && blk == 0) {
+                mask_idx[((size_t)b * K + tid) * 2] = s;
+                mask_idx[((size_t)b * K + tid) * 2 + 1] = w;
+            }
+        }
         pre_ok = false;
 #pragma unroll
         for (int u = 0; u < 4; ++u) pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);      // (ends the old values' live range before the rounds)
@@ -372,11 +376,8 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                 if (fast_span(nb, nbase)) {
                     const float4 *src = reinterpret_cast<const float4 *>(wave + (size_t)nb * a.N + nbase);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) pre[u] = src[min(tid + NT * u, n4 - 1)];
-                    asm volatile("" : "+v"(pre[0].x), "+v"(pre[0].y), "+v"(pre[0].z), "+v"(pre[0].w), "+v"(pre[1].x), "+v"(pre[1].y),
-                                 "+v"(pre[1].z), "+v"(pre[1].w), "+v"(pre[2].x), "+v"(pre[2].y), "+v"(pre[2].z), "+v"(pre[2].w),
-                                 "+v"(pre[3].x), "+v"(pre[3].y), "+v"(pre[3].z), "+v"(pre[3].w));
-                    pre_ok = true;
+                    for (int u = 0; u < 4; ++u) pre[u] = src[min(tid + NT * u, n4 - 1)];      // (no register pin here: an asm
+                    pre_ok = true;                                                              //  operand would wait for the loads)
                 }
             }
         }
