@@ -101,7 +101,7 @@ __device__ unsigned long long ww_logmel_stamps[32];
 #define WW_STAMP(i) do { } while (0)
 #endif
 template <typename WaveT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 8 ? 4 : 2, 4)))
 void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ out, int use_mask, ww_mask_params mp,
                      int32_t *__restrict__ mask_idx, int nblk, long nitems) {
     constexpr int NT = 64 * WAVES, FRW = 4 * WAVES;
@@ -148,6 +148,26 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
     // The NEXT item's span is fetched into registers while the current item's tail (log pass, write-out) runs, and stored to
     // LDS at the top of the next trip: the ~1.2 us HBM round trip of the staging was exposed once per item (10 % of an item by
     // the s_memtime stamps, tools/logmel_stamps.py).  Interior, 16-byte-aligned fp32 spans of <= 4 float4 per thread only.
+    // packed band-sum table entry of work item `it` = ((frame, band), half): power-row offset (11 bits) | trips (4) | weight
+    // offset in float4s (17); with WW_LOGMEL_NOMEL (an experiment build) no trips at all
+    auto mel_entry = [&](int it) {
+        const bool act = it < 4 * a.M;
+        const int pair = act ? it >> 1 : 0, half = it & 1;
+        const int fr = pair >= a.M ? 1 : 0;
+        const int *e = mtab + 3 * (2 * (pair - fr * a.M) + half);
+#ifdef WW_LOGMEL_NOMEL
+        const int trips = 0;
+#else
+        const int trips = act ? e[1] : 0;
+#endif
+        return (fr * PB_LD + e[0]) | (trips << 11) | ((e[2] >> 2) << 15);
+    };
+    __syncthreads();                                           // the tables are in LDS
+    // (the 8-wave form has 128 registers per lane and none to spare: it keeps reading the table)
+    constexpr int NENT = WAVES == 8 ? 0 : 4;
+    int ent[NENT ? NENT : 1];
+#pragma unroll
+    for (int p = 0; p < NENT; ++p) ent[p] = mel_entry(64 * p + lane);
     float4 pre[4];
     bool pre_ok = false;
     auto fast_span = [&](int bb, long base_) {
@@ -316,20 +336,13 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
             // ---- mel band sums: item = ((frame, mel), half); the two halves of a band sit in adjacent lanes.  A half is a run of
             // consecutive slots of the power row (weights stored in the same slot layout, zero at the row's pad slots, which
             // hold finite leftovers of the exchange): four slots per step, no per-bin index arithmetic
-            for (int it0 = 0; it0 < 4 * a.M; it0 += 64) {
-                const int it = it0 + lane;
+            auto band_sum = [&](int it, int rowoff, int trips, int woff4) {
                 const bool act = it < 4 * a.M;
                 const int pair = act ? it >> 1 : 0, half = it & 1;
                 const int fr = pair >= a.M ? 1 : 0;
                 const int m = pair - fr * a.M;
-                const int *e = mtab + 3 * (2 * m + half);
-#ifdef WW_LOGMEL_NOMEL
-                const int trips = 0;                 // experiment: what the band-sum loop costs (results are wrong)
-#else
-                const int trips = act ? e[1] : 0;
-#endif
-                const float4 *wp = reinterpret_cast<const float4 *>(mw + e[2]);
-                const float4 *pp = reinterpret_cast<const float4 *>(xb + fr * PB_LD + e[0]);
+                const float4 *wp = reinterpret_cast<const float4 *>(mw) + woff4;
+                const float4 *pp = reinterpret_cast<const float4 *>(xb + rowoff);
                 // a trip = 16 slots: its eight 16-byte LDS loads are issued together, then 16 FMAs on two partial sums.  (As a
                 // load -> fma chain of four slots per step the loop was one LDS round trip per step, ~27 per round: 43 % of
                 // the kernel -- 155 us with it, 88 without, `tools/logmel_stamps.py`.)  Slots past a half's end carry zero
@@ -346,6 +359,15 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                 acc += acc2;
                 acc += __shfl_xor(acc, 1);
                 if (act && half == 0) lm[(fa + fr) * a.M + m] = acc;
+            };
+            // the first four 64-lane passes (all of them up to 64 mel bands) take their table entry from a register filled once
+            // per workgroup: read from LDS it was one more dependent round trip per pass, 3 of a round's 11
+#pragma unroll
+            for (int p = 0; p < NENT; ++p)
+                if (64 * p < 4 * a.M) band_sum(64 * p + lane, ent[p] & 2047, (ent[p] >> 11) & 15, (int)((unsigned)ent[p] >> 15));
+            for (int it0 = 64 * NENT; it0 < 4 * a.M; it0 += 64) {
+                const int e_ = mel_entry(it0 + lane);
+                band_sum(it0 + lane, e_ & 2047, (e_ >> 11) & 15, (int)((unsigned)e_ >> 15));
             }
             wave_sync();
             WW_STAMP(9 + 8 * round);
