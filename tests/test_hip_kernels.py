@@ -111,6 +111,11 @@ def _assert_logmel_close(out, ref, x, tol=1e-3, **kw):
     (2, 40000, dict()),
     (5, 600, dict()),
     (3, 24000, dict(f_min=50.0, f_max=7600.0)),
+    # band counts that are not a multiple of the MFMA band sums' 4-band blocks / one block only / three passes' worth
+    (2, 24000, dict(n_mels=13)),
+    (2, 8000, dict(n_mels=3)),
+    (2, 24000, dict(n_mels=80, f_min=20.0)),
+    (2, 24000, dict(n_mels=23, f_max=3800.0)),
 ])
 def test_logmel_matches_oracle(nat, B, N, kw):
     from oracle import features as OF

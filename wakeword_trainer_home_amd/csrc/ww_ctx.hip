@@ -97,8 +97,8 @@ static void free_tables(ww_feat_tables *t) {
         (void)hipFree(t->mel_len);
         (void)hipFree(t->mel_off);
         (void)hipFree(t->mel_w);
-        if (t->melp_tab) (void)hipFree(t->melp_tab);
-        if (t->melp_w) (void)hipFree(t->melp_w);
+        if (t->melq_tab) (void)hipFree(t->melq_tab);
+        if (t->melq_w) (void)hipFree(t->melq_w);
         if (t->dct) (void)hipFree(t->dct);
         delete t;
         t = n;
@@ -280,43 +280,91 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
                 dct[(size_t)c * M + m] = (float)v;
             }
     }
-    // padded-slot form of the band weights (k_logmel, n_fft 1024): two lanes share a band, each sums its half as a run of
-    // consecutive LDS slots of the power row, read as aligned float4s, FOUR of them (16 slots) per trip with all eight loads of
-    // a trip in flight together: table entry = {first slot (a multiple of 4), trips, weight offset (a multiple of 4)}; weights are
-    // zero at the row's pad slots, before the half's first bin and after its last one
-    std::vector<int32_t> ptab;
-    std::vector<float> pw;
-    for (int m = 0; m < M; ++m) {
-        const int L = len[m], h0 = (L + 1) >> 1;
-        for (int half = 0; half < 2; ++half) {
-            const int j0 = half ? h0 : 0, j1 = half ? L : h0;
-            int slot0 = 0, trips = 0;
-            const int woff = (int)pw.size();
-            if (j1 > j0) {
-                const int b0 = start[m] + j0, b1 = start[m] + j1 - 1;
-                slot0 = (b0 + (b0 >> 4)) & ~3;
-                const int slot1 = b1 + (b1 >> 4);
-                trips = (slot1 - slot0 + 1 + 15) / 16;
-                for (int p = slot0; p < slot0 + 16 * trips; ++p) {
-                    const int q = p / 17, r = p % 17, b = 16 * q + r;            // slot -> bin (r == 16: a pad slot)
-                    // (x 1/4: the kernel's power rows hold 4 |X|^2 -- the two real spectra come out of one complex FFT as sums /
-                    //  differences of X[k] and X[N-k] without their 1/2)
-                    pw.push_back((r != 16 && b >= b0 && b <= b1) ? 0.25f * w[off[m] + (b - start[m])] : 0.f);
-                }
+    // MFMA form of the band sums (k_logmel, n_fft 1024): v_mfma_f32_4x4x1 runs 16 independent 4x4 outer products per
+    // instruction -- block = 4 consecutive bands ("quad") x the wave's frames, one spectrum bin per step.  A UNIT is a run of
+    // bins of one quad (in groups of 8 bins) handled by one block of one pass; a pass costs its longest unit's steps, so the
+    // quads' runs are cut into 16 * P near-equal units (a piece more to whichever quad has the longest pieces) and the units
+    // dealt to the passes by length; P = the pass count with the fewest steps in total (40 bands: one pass = 64 steps, two =
+    // 24 + 24).  Per (pass, step, lane = 4*block + row) one weight (x 1/4: the kernel's power rows hold 4 |X|^2 -- the two
+    // real spectra come out of one complex FFT as sums / differences of X[k] and X[N-k] without their 1/2); a band's sum is
+    // the sum of its quad's unit partials in bin order.  Table (ints): [0] passes P, [1] quads NQ, [2+2p] steps of pass p,
+    // [3+2p] its weights' offset, [10+32p+2b] first bin (a multiple of 8) of block b, [11+32p+2b] its unit number,
+    // [138+q] first unit of quad q (NQ+1 entries).
+    std::vector<int32_t> qtab(WW_MELQ_TAB, 0);
+    std::vector<float> qw;
+    if (n_fft == WW_NFFT) {
+        struct Unit { int quad, g0, g1; };                           // bins [8*g0, 8*g1)
+        const int NQ = (M + 3) / 4, Pmin = (NQ + 15) / 16;
+        std::vector<Unit> quads;
+        for (int q = 0; q < NQ; ++q) {
+            int s = n_bins, e = 0;
+            for (int m = 4 * q; m < std::min(M, 4 * q + 4); ++m)
+                if (len[m] > 0) { s = std::min(s, start[m]); e = std::max(e, start[m] + len[m]); }
+            if (e <= s) { s = 0; e = 0; }
+            quads.push_back(Unit{q, s / 8, (e + 7) / 8});
+        }
+        std::vector<Unit> units;
+        std::vector<int> order;
+        int best = -1;
+        for (int P = Pmin; P <= WW_MELQ_MAX_PASSES; ++P) {
+            // (at most 8 pieces of a quad hold bins -- the kernel sums a band's partials as 8 loads in flight; any more are empty)
+            std::vector<int> pieces(NQ, 1);
+            auto longest = [&](int q) { return pieces[q] >= 8 ? 0 : (quads[q].g1 - quads[q].g0 + pieces[q] - 1) / pieces[q]; };
+            int fill = 0;
+            for (int n = NQ; n < 16 * P; ++n) {
+                int big = 0;
+                for (int q = 1; q < NQ; ++q)
+                    if (longest(q) > longest(big)) big = q;
+                if (pieces[big] >= 8) ++fill; else ++pieces[big];
             }
-            ptab.push_back(slot0); ptab.push_back(trips); ptab.push_back(woff);
+            std::vector<Unit> us;
+            for (int q = 0; q < NQ; ++q) {
+                const int g = quads[q].g1 - quads[q].g0;
+                for (int i = 0; i < pieces[q]; ++i) us.push_back(Unit{q, quads[q].g0 + g * i / pieces[q], quads[q].g0 + g * (i + 1) / pieces[q]});
+                if (q == NQ - 1)
+                    for (int i = 0; i < fill; ++i) us.push_back(Unit{q, quads[q].g1, quads[q].g1});
+            }
+            std::vector<int> ord(us.size());
+            for (size_t i = 0; i < ord.size(); ++i) ord[i] = (int)i;
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return us[x].g1 - us[x].g0 > us[y].g1 - us[y].g0; });
+            int total = 0;
+            for (int p = 0; p < P; ++p) total += 8 * (us[ord[16 * p]].g1 - us[ord[16 * p]].g0);
+            if (best < 0 || total < best) { best = total; units = us; order = ord; }
+        }
+        const int P = (int)units.size() / 16;
+        qtab[0] = P; qtab[1] = NQ;
+        for (int p = 0; p < P; ++p) {
+            const int steps = 8 * (units[order[16 * p]].g1 - units[order[16 * p]].g0);
+            qtab[2 + 2 * p] = steps;
+            qtab[3 + 2 * p] = (int32_t)qw.size();
+            for (int b = 0; b < 16; ++b) {
+                qtab[10 + 32 * p + 2 * b] = 8 * units[order[16 * p + b]].g0;
+                qtab[11 + 32 * p + 2 * b] = order[16 * p + b];
+            }
+            for (int t = 0; t < steps; ++t)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const Unit &u = units[order[16 * p + (lane >> 2)]];
+                    const int m = 4 * u.quad + (lane & 3), j = 8 * u.g0 + t;
+                    const bool in = m < M && j < 8 * u.g1 && j >= start[m] && j < start[m] + len[m];
+                    qw.push_back(in ? 0.25f * w[off[m] + (j - start[m])] : 0.f);
+                }
+        }
+        for (int q = 0, i = 0; q <= NQ; ++q) {
+            while (i < (int)units.size() && units[i].quad < q) ++i;
+            qtab[138 + q] = i;
         }
     }
     ww_feat_tables *t = new ww_feat_tables();
     memset(t, 0, sizeof(*t));
     t->cfg = *cfg;
-    t->n_melp_w = (int32_t)pw.size();
+    t->n_melq_w = (int32_t)qw.size();
+    t->melq_passes = qtab[0];
     t->max_len = max_len;
     t->n_mel_w = (int32_t)w.size();
     int rc;
     if ((rc = upload(&t->window, win)) || (rc = upload(&t->twiddle, tw)) || (rc = upload(&t->mel_start, start)) ||
         (rc = upload(&t->mel_len, len)) || (rc = upload(&t->mel_off, off)) || (rc = upload(&t->mel_w, w)) ||
-        (rc = upload(&t->melp_tab, ptab)) || (rc = upload(&t->melp_w, pw))) {
+        (rc = upload(&t->melq_tab, qtab)) || (rc = upload(&t->melq_w, qw))) {
         free_tables(t);
         return rc;
     }

@@ -10,15 +10,16 @@
 //           rewrites exactly the 16 slots it read, so one 4.4 KB tile per wavefront suffices)
 //   pass 3  radix-4 butterflies X[16kc + 256kd + kb], run in PAIRS that produce X[k] and X[N-k] in the same lane: the two
 //           real spectra are separated in registers and |.|^2 goes straight to the power buffers (no return to LDS)
-// Every mel band is then summed by two adjacent lanes (half a band each, weights staged in LDS, combined with one
-// shuffle), and the 16 x F tile is transposed through LDS so the (B,1,F,T) output is written in 64-byte runs along T.
+// The mel band sums then run on the matrix pipe (v_mfma_f32_4x4x1: 16 blocks of 4 bands x the pair's frames, one bin per
+// step), and the 16 x F tile is transposed through LDS so the (B,1,F,T) output is written in 64-byte runs along T.
 // Index algebra verified against numpy (tests/test_frontend_index_algebra.py).
 #include "ww_internal.h"
 
 namespace {
 
 // (frames per item: 4 per wavefront of the workgroup, see k_logmel)
-constexpr int PB_LD = 548;                   // floats per power spectrum: bin j sits at j + (j >> 4) (bank spreading)
+constexpr int PB_LD = 552;                   // floats per power spectrum: bin j sits at j + (j >> 4) (bank spreading); the band sums
+                                             // read whole groups of 8 bins, the last one [512, 520) -> slots 544 ... 551
 
 #include "ww_fft.h"
 
@@ -36,9 +37,10 @@ struct FeatArgs {
     const float *dct;
     int span_len;
     int n_mel_w;
-    const int32_t *melp_tab;     // k_logmel: padded-slot band table / weights (ww_feat_tables)
-    const float *melp_w;
-    int n_melp_w;
+    const int32_t *melq_tab;     // k_logmel: band sums in v_mfma_f32_4x4x1 form (ww_feat_tables)
+    const float *melq_w;
+    int n_melq_w;
+    int melq_in_lds;             // the weights are staged in LDS (else read from the L1-resident table: the 8-wave form when LDS is short)
 };
 
 // order a wave's own LDS traffic (cross-lane hand-off inside one wavefront): LDS processes one wave's operations in
@@ -112,8 +114,8 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
     float *lm = span + ((a.span_len + 3) & ~3);                       // FR x M (raw mel sums, then their logs)
     float *feat = lm + FRW * a.M;                                     // FR x F (== lm when !use_dct)
     int *msk = reinterpret_cast<int *>(feat + (a.use_dct ? FRW * a.F : 0));  // 2*WW_MAX_MASKS
-    int *mtab = msk + 2 * WW_MAX_MASKS;                               // 6*M : per (band, half) first slot, 4-slot steps, weight offset
-    float *mw = reinterpret_cast<float *>(mtab + ((6 * a.M + 3) & ~3));   // n_melp_w band weights in the power rows' slot layout (16-B aligned)
+    int *mtab = msk + 2 * WW_MAX_MASKS;                               // WW_MELQ_TAB ints (ww_get_feat_tables)
+    float *mw = reinterpret_cast<float *>(mtab + WW_MELQ_TAB);        // n_melq_w band weights, one per (pass, step, lane)
     if (!a.use_dct) feat = lm;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -121,8 +123,9 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
     for (int i = tid; i < WW_NFFT / 4; i += NT) reinterpret_cast<float4 *>(wl)[i] = reinterpret_cast<const float4 *>(a.window)[i];
     // (the tiles' pad slots are never written -- the band sums multiply them by zero weights, so they must not hold NaN patterns)
     for (int i = tid; i < WAVES * XB; i += NT) xball[i] = 0.f;
-    for (int i = tid; i < 6 * a.M; i += NT) mtab[i] = a.melp_tab[i];
-    for (int i = tid; i < a.n_melp_w; i += NT) mw[i] = a.melp_w[i];
+    for (int i = tid; i < WW_MELQ_TAB; i += NT) mtab[i] = a.melq_tab[i];
+    if (a.melq_in_lds)
+        for (int i = tid; i < a.n_melq_w; i += NT) mw[i] = a.melq_w[i];
     const int K = use_mask ? (mp.n_f + mp.n_t) : 0;
 
     float *xb = xball + wv * XB;
@@ -148,26 +151,9 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
     // The NEXT item's span is fetched into registers while the current item's tail (log pass, write-out) runs, and stored to
     // LDS at the top of the next trip: the ~1.2 us HBM round trip of the staging was exposed once per item (10 % of an item by
     // the s_memtime stamps, tools/logmel_stamps.py).  Interior, 16-byte-aligned fp32 spans of <= 4 float4 per thread only.
-    // packed band-sum table entry of work item `it` = ((frame, band), half): power-row offset (11 bits) | trips (4) | weight
-    // offset in float4s (17); with WW_LOGMEL_NOMEL (an experiment build) no trips at all
-    auto mel_entry = [&](int it) {
-        const bool act = it < 4 * a.M;
-        const int pair = act ? it >> 1 : 0, half = it & 1;
-        const int fr = pair >= a.M ? 1 : 0;
-        const int *e = mtab + 3 * (2 * (pair - fr * a.M) + half);
-#ifdef WW_LOGMEL_NOMEL
-        const int trips = 0;
-#else
-        const int trips = act ? e[1] : 0;
-#endif
-        return (fr * PB_LD + e[0]) | (trips << 11) | ((e[2] >> 2) << 15);
-    };
     __syncthreads();                                           // the tables are in LDS
-    // (the 8-wave form has 128 registers per lane and none to spare: it keeps reading the table)
-    constexpr int NENT = WAVES == 8 ? 0 : 4;
-    int ent[NENT ? NENT : 1];
-#pragma unroll
-    for (int p = 0; p < NENT; ++p) ent[p] = mel_entry(64 * p + lane);
+    const int npass = __builtin_amdgcn_readfirstlane(mtab[0]), nunit = 16 * npass;
+    const float *const wtab = (a.melq_in_lds ? mw : a.melq_w) + lane;
     float4 pre[4];
     bool pre_ok = false;
     auto fast_span = [&](int bb, long base_) {
@@ -333,42 +319,66 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
             }
             wave_sync();
             WW_STAMP(8 + 8 * round);
-            // ---- mel band sums: item = ((frame, mel), half); the two halves of a band sit in adjacent lanes.  A half is a run of
-            // consecutive slots of the power row (weights stored in the same slot layout, zero at the row's pad slots, which
-            // hold finite leftovers of the exchange): four slots per step, no per-bin index arithmetic
-            auto band_sum = [&](int it, int rowoff, int trips, int woff4) {
-                const bool act = it < 4 * a.M;
-                const int pair = act ? it >> 1 : 0, half = it & 1;
-                const int fr = pair >= a.M ? 1 : 0;
-                const int m = pair - fr * a.M;
-                const float4 *wp = reinterpret_cast<const float4 *>(mw) + woff4;
-                const float4 *pp = reinterpret_cast<const float4 *>(xb + rowoff);
-                // a trip = 16 slots: its eight 16-byte LDS loads are issued together, then 16 FMAs on two partial sums.  (As a
-                // load -> fma chain of four slots per step the loop was one LDS round trip per step, ~27 per round: 43 % of
-                // the kernel -- 155 us with it, 88 without, `tools/logmel_stamps.py`.)  Slots past a half's end carry zero
-                // weights; the power values read there are finite leftovers of this clip's own tiles.
-                float acc = 0.f, acc2 = 0.f;
-                for (int i = 0; i < trips; ++i) {
-                    const float4 w0 = wp[4 * i], w1 = wp[4 * i + 1], w2 = wp[4 * i + 2], w3 = wp[4 * i + 3];
-                    const float4 q0 = pp[4 * i], q1 = pp[4 * i + 1], q2 = pp[4 * i + 2], q3 = pp[4 * i + 3];
-                    acc = fmaf(w0.x, q0.x, acc); acc2 = fmaf(w0.y, q0.y, acc2); acc = fmaf(w0.z, q0.z, acc); acc2 = fmaf(w0.w, q0.w, acc2);
-                    acc = fmaf(w1.x, q1.x, acc); acc2 = fmaf(w1.y, q1.y, acc2); acc = fmaf(w1.z, q1.z, acc); acc2 = fmaf(w1.w, q1.w, acc2);
-                    acc = fmaf(w2.x, q2.x, acc); acc2 = fmaf(w2.y, q2.y, acc2); acc = fmaf(w2.z, q2.z, acc); acc2 = fmaf(w2.w, q2.w, acc2);
-                    acc = fmaf(w3.x, q3.x, acc); acc2 = fmaf(w3.y, q3.y, acc2); acc = fmaf(w3.z, q3.z, acc); acc2 = fmaf(w3.w, q3.w, acc2);
-                }
-                acc += acc2;
-                acc += __shfl_xor(acc, 1);
-                if (act && half == 0) lm[(fa + fr) * a.M + m] = acc;
-            };
-            // the first four 64-lane passes (all of them up to 64 mel bands) take their table entry from a register filled once
-            // per workgroup: read from LDS it was one more dependent round trip per pass, 3 of a round's 11
+            // ---- mel band sums on the matrix pipe: v_mfma_f32_4x4x1 = 16 independent 4x4 outer products, block = (4 consecutive
+            // bands) x (this pair's frames: columns 2, 3 repeat 0, 1), one spectrum bin per step -- per step one weight (LDS, a
+            // constant offset) and one power value (LDS, consecutive slots inside a group of 8 bins) per lane.  As VALU work
+            // (two lanes per band, runs of 16 slots) this phase was 27 trips x (8 x 16-byte LDS loads + 16 FMAs) per round, a
+            // third of the kernel (tools/logmel_stamps.py); operand layout checked on the device (tools/probes/mfma4x4x1.hip).
+#ifndef WW_LOGMEL_NOMEL
+            typedef float f4_ __attribute__((ext_vector_type(4)));
+            f4_ acc[WW_MELQ_MAX_PASSES];
+            int unit_[WW_MELQ_MAX_PASSES];
 #pragma unroll
-            for (int p = 0; p < NENT; ++p)
-                if (64 * p < 4 * a.M) band_sum(64 * p + lane, ent[p] & 2047, (ent[p] >> 11) & 15, (int)((unsigned)ent[p] >> 15));
-            for (int it0 = 64 * NENT; it0 < 4 * a.M; it0 += 64) {
-                const int e_ = mel_entry(it0 + lane);
-                band_sum(it0 + lane, e_ & 2047, (e_ >> 11) & 15, (int)((unsigned)e_ >> 15));
+            for (int p = 0; p < WW_MELQ_MAX_PASSES; ++p) {
+                acc[p] = f4_{0.f, 0.f, 0.f, 0.f};
+                unit_[p] = 0;
+                if (p < npass) {
+                    const int steps = __builtin_amdgcn_readfirstlane(mtab[2 + 2 * p]);
+                    const float *wq = wtab + __builtin_amdgcn_readfirstlane(mtab[3 + 2 * p]);
+                    const int2 blk_ = *reinterpret_cast<const int2 *>(mtab + 10 + 32 * p + 2 * (lane >> 2));   // {first bin, unit}
+                    unit_[p] = blk_.y;
+                    const float *row = xb + (lane & 1) * PB_LD;
+                    // operands of a group of 8 steps; the next group's are fetched before this group's products are issued
+                    // (a short unit's idle steps: zero weights, any finite power value)
+                    float wa[8], pb[8];
+                    auto fetch = [&](int t, float (&w_)[8], float (&p_)[8]) {
+                        const int j = min(blk_.x + t, 512);
+                        const float *pp = row + j + (j >> 4);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { w_[i] = wq[64 * (t + i)]; p_[i] = pp[i]; }
+                    };
+                    fetch(0, wa, pb);
+                    for (int t = 0; t < steps; t += 8) {
+                        float wn[8], pn[8];
+                        fetch(min(t + 8, steps - 8), wn, pn);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) acc[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[i], pb[i], acc[p], 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { wa[i] = wn[i]; pb[i] = pn[i]; }
+                    }
+                }
             }
+            // the power rows are spent: the unit partials go through the head of the tile, [frame][unit][4 bands]; a band's sum =
+            // its quad's partials in bin order (at most 8 that are not empty, ww_get_feat_tables), fetched together
+            wave_sync();
+#pragma unroll
+            for (int p = 0; p < WW_MELQ_MAX_PASSES; ++p)
+                if (p < npass && (lane & 3) < 2)
+                    *reinterpret_cast<float4 *>(xb + ((lane & 3) * nunit + unit_[p]) * 4) = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+            wave_sync();
+            for (int it = lane; it < 2 * a.M; it += 64) {
+                const int fr = it >= a.M ? 1 : 0, m = it - fr * a.M;
+                const int2 uu = make_int2(mtab[138 + (m >> 2)], mtab[139 + (m >> 2)]);
+                const float *src = xb + (fr * nunit + uu.x) * 4 + (m & 3);
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = src[uu.x + k < uu.y ? 4 * k : 0];
+                float sum = v[0];                                      // (every quad has at least one unit)
+#pragma unroll
+                for (int k = 1; k < 8; ++k) sum += uu.x + k < uu.y ? v[k] : 0.f;
+                lm[(fa + fr) * a.M + m] = sum;
+            }
+#endif
             wave_sync();
             WW_STAMP(9 + 8 * round);
         }
@@ -632,7 +642,7 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
     const int FRW = 4 * waves;
     a.span_len = (FRW - 1) * cfg->hop + WW_NFFT;
     a.n_mel_w = tb->n_mel_w;
-    a.melp_tab = tb->melp_tab; a.melp_w = tb->melp_w; a.n_melp_w = tb->n_melp_w;
+    a.melq_tab = tb->melq_tab; a.melq_w = tb->melq_w; a.n_melq_w = tb->n_melq_w;
     ww_mask_params mp = {};
     int use_mask = 0;
     if (sa) {
@@ -657,8 +667,12 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
         WW_LAUNCH_CHECK();
         return WW_OK;
     }
-    const size_t smem = ((size_t)waves * XB + WW_NFFT + ((a.span_len + 3) & ~3) + (size_t)FRW * a.M +
-                         (a.use_dct ? (size_t)FRW * a.F : 0) + 2 * WW_MAX_MASKS + (size_t)((6 * a.M + 3) & ~3) + a.n_melp_w) * sizeof(float);
+    // the band weights go to LDS unless that would cost the 8-wave form its second workgroup per CU (then: the L1-resident table)
+    const size_t smem_base = ((size_t)waves * XB + WW_NFFT + ((a.span_len + 3) & ~3) + (size_t)FRW * a.M +
+                              (a.use_dct ? (size_t)FRW * a.F : 0) + 2 * WW_MAX_MASKS + WW_MELQ_TAB) * sizeof(float);
+    const size_t smem_w = (size_t)((a.n_melq_w + 3) & ~3) * sizeof(float);
+    a.melq_in_lds = waves == 4 || smem_base + smem_w <= 80 * 1024;
+    const size_t smem = smem_base + (a.melq_in_lds ? smem_w : 0);
     // Persistent grid: ctx->logmel_wgs workgroups (ww_ctx_set_logmel_workgroups; WW_LOGMEL_WGS overrides it for tuning),
     // 0 = one full residency round of the device.
     const int nblk = (a.T + FRW - 1) / FRW;

@@ -9,6 +9,8 @@
 #define WW_NFFT 1024
 #define WW_NBINS 513
 #define WW_MAX_MELS 128
+#define WW_MELQ_MAX_PASSES 4
+#define WW_MELQ_TAB 172          // ints in ww_feat_tables::melq_tab (up to 4 passes of 16 blocks, 32 quads = 128 mel bands)
 #define WW_MAX_MASKS 16
 #define WW_FRAMES_PER_BLOCK 16
 #define WW_MAX_HOP 512
@@ -56,11 +58,13 @@ struct ww_feat_tables {
     float *dct;            // (n_mfcc, n_mels) or null
     int32_t max_len;
     int32_t n_mel_w;       // number of floats in mel_w
-    // the same band weights laid out for k_logmel's power rows (bin j sits at slot j + (j >> 4)): per (band, half) the first
-    // slot, the number of 4-slot steps and the offset of its weights in melp_w (zero at pad slots and past the half's end)
-    int32_t *melp_tab;     // (2 * n_mels) x {slot0, steps, offset}
-    float *melp_w;
-    int32_t n_melp_w;
+    // the band weights in the form k_logmel's v_mfma_f32_4x4x1 band sums read them (ww_get_feat_tables): melq_tab = WW_MELQ_TAB
+    // ints (passes, quads, steps / weight offset per pass, first bin / unit per block, first unit per quad), melq_w = per
+    // (pass, step, lane) one weight
+    int32_t *melq_tab;
+    float *melq_w;
+    int32_t n_melq_w;
+    int32_t melq_passes;   // = melq_tab[0] (host copy: sizes the kernel's partial-sum scratch)
     ww_feat_tables *next;
 };
 
