@@ -75,7 +75,7 @@ template <int NACC> __global__ void kfma2(float a, float b, float *out, unsigned
 }
 int main() {
     float *o; unsigned long long *t, h;
-    (void)hipMalloc(&o, 256); (void)hipMalloc(&t, 8);
+    (void)hipMalloc(&o, 4096); (void)hipMalloc(&t, 8);
 #define RUN(name, K) for (int r = 0; r < 2; ++r) { hipLaunchKernelGGL(K, dim3(1), dim3(64), 0, 0, 1.f, 2.f, o, t); (void)hipMemcpy(&h, t, 8, hipMemcpyDeviceToHost); } \
     printf("%-34s %7.1f ticks per instruction\n", name, (double)h / N);
     RUN("v_fma_f32 chain", (kfma<1>)); RUN("v_fma_f32 x4 accumulators", (kfma<4>));
@@ -83,5 +83,10 @@ int main() {
     RUN("v_pk_fma_f32 chain", (kpk<1>)); RUN("v_pk_fma_f32 x8 accumulators", (kpk<8>));
     RUN("mfma_f32_4x4x1 chain", (k4x4<1>)); RUN("mfma_f32_4x4x1 x4 accumulators", (k4x4<4>));
     RUN("mfma_f32_16x16x4 chain", (k16<1>)); RUN("mfma_f32_16x16x4 x4 accumulators", (k16<4>));
+    // the same with 16 waves on the CU (4 per SIMD): SIMD throughput instead of one wave's issue interval
+#define RUN16(name, K) for (int r = 0; r < 2; ++r) { hipLaunchKernelGGL(K, dim3(1), dim3(1024), 0, 0, 1.f, 2.f, o, t); (void)hipMemcpy(&h, t, 8, hipMemcpyDeviceToHost); } \
+    printf("%-34s %7.1f ticks per instruction per wave (4 waves per SIMD)\n", name, (double)h / N);
+    RUN16("v_fma_f32 (asm) x8, 16 waves", (kfma2<8>)); RUN16("v_pk_fma_f32 x8, 16 waves", (kpk<8>));
+    RUN16("mfma_f32_4x4x1 x4, 16 waves", (k4x4<4>));
     return 0;
 }

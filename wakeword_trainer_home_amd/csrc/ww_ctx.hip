@@ -358,7 +358,6 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
     memset(t, 0, sizeof(*t));
     t->cfg = *cfg;
     t->n_melq_w = (int32_t)qw.size();
-    t->melq_passes = qtab[0];
     t->max_len = max_len;
     t->n_mel_w = (int32_t)w.size();
     int rc;

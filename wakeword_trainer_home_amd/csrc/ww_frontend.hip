@@ -40,7 +40,6 @@ struct FeatArgs {
     const int32_t *melq_tab;     // k_logmel: band sums in v_mfma_f32_4x4x1 form (ww_feat_tables)
     const float *melq_w;
     int n_melq_w;
-    int melq_in_lds;             // the weights are staged in LDS (else read from the L1-resident table: the 8-wave form when LDS is short)
 };
 
 // order a wave's own LDS traffic (cross-lane hand-off inside one wavefront): LDS processes one wave's operations in
@@ -124,8 +123,7 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
     // (the tiles' pad slots are never written -- the band sums multiply them by zero weights, so they must not hold NaN patterns)
     for (int i = tid; i < WAVES * XB; i += NT) xball[i] = 0.f;
     for (int i = tid; i < WW_MELQ_TAB; i += NT) mtab[i] = a.melq_tab[i];
-    if (a.melq_in_lds)
-        for (int i = tid; i < a.n_melq_w; i += NT) mw[i] = a.melq_w[i];
+    for (int i = tid; i < a.n_melq_w; i += NT) mw[i] = a.melq_w[i];
     const int K = use_mask ? (mp.n_f + mp.n_t) : 0;
 
     float *xb = xball + wv * XB;
@@ -153,7 +151,6 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
     // the s_memtime stamps, tools/logmel_stamps.py).  Interior, 16-byte-aligned fp32 spans of <= 4 float4 per thread only.
     __syncthreads();                                           // the tables are in LDS
     const int npass = __builtin_amdgcn_readfirstlane(mtab[0]), nunit = 16 * npass;
-    const float *const wtab = (a.melq_in_lds ? mw : a.melq_w) + lane;
     float4 pre[4];
     bool pre_ok = false;
     auto fast_span = [&](int bb, long base_) {
@@ -267,7 +264,11 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                 const Tw6 tw2 = load_tw6(a.twiddle, tb2);        // (fetching both passes' factors at the top of the round: 128
                 twiddle16(re, im, tw2);                          //  VGPRs, 149 us alone either way, 1.260 vs 1.238 ms in the step;
                                                                  //  all 15 factors of a pass straight from the table instead of 6 +
-                                                                 //  nine complex products: 133 us alone against 116)
+                                                                 //  nine complex products: 133 us alone against 116.  The two
+                                                                 //  radix-16 passes on (re, im) register pairs with v_pk_add/mul/
+                                                                 //  fma_f32 -- 270 fewer VALU instructions per round of ~1300, but
+                                                                 //  pair alignment and dependent mul -> fma pairs: 121 us alone
+                                                                 //  against 116, the step equal: profiles/EXPERIMENTS.md)
             }
             // exchange 2 (planar) straight into the pass-3 butterflies' registers
             WW_STAMP(6 + 8 * round);
@@ -334,7 +335,7 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                 unit_[p] = 0;
                 if (p < npass) {
                     const int steps = __builtin_amdgcn_readfirstlane(mtab[2 + 2 * p]);
-                    const float *wq = wtab + __builtin_amdgcn_readfirstlane(mtab[3 + 2 * p]);
+                    const float *wq = mw + __builtin_amdgcn_readfirstlane(mtab[3 + 2 * p]) + lane;
                     const int2 blk_ = *reinterpret_cast<const int2 *>(mtab + 10 + 32 * p + 2 * (lane >> 2));   // {first bin, unit}
                     unit_[p] = blk_.y;
                     const float *row = xb + (lane & 1) * PB_LD;
@@ -348,13 +349,16 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
                         for (int i = 0; i < 8; ++i) { w_[i] = wq[64 * (t + i)]; p_[i] = pp[i]; }
                     };
                     fetch(0, wa, pb);
-                    for (int t = 0; t < steps; t += 8) {
+                    for (int t = 0; t < steps; t += 16) {                // (two groups per trip: the buffers swap roles, no copies)
                         float wn[8], pn[8];
                         fetch(min(t + 8, steps - 8), wn, pn);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) acc[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(wa[i], pb[i], acc[p], 0, 0, 0);
+                        fetch(min(t + 16, steps - 8), wa, pb);
+                        if (t + 8 < steps) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) { wa[i] = wn[i]; pb[i] = pn[i]; }
+                            for (int i = 0; i < 8; ++i) acc[p] = __builtin_amdgcn_mfma_f32_4x4x1f32(wn[i], pn[i], acc[p], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -667,12 +671,11 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
         WW_LAUNCH_CHECK();
         return WW_OK;
     }
-    // the band weights go to LDS unless that would cost the 8-wave form its second workgroup per CU (then: the L1-resident table)
-    const size_t smem_base = ((size_t)waves * XB + WW_NFFT + ((a.span_len + 3) & ~3) + (size_t)FRW * a.M +
-                              (a.use_dct ? (size_t)FRW * a.F : 0) + 2 * WW_MAX_MASKS + WW_MELQ_TAB) * sizeof(float);
-    const size_t smem_w = (size_t)((a.n_melq_w + 3) & ~3) * sizeof(float);
-    a.melq_in_lds = waves == 4 || smem_base + smem_w <= 80 * 1024;
-    const size_t smem = smem_base + (a.melq_in_lds ? smem_w : 0);
+    // (8-wave form, 40 bands: 81 584 bytes -- two workgroups per CU fit the 160 KB with 336 bytes to spare; the band weights are
+    //  12 KB of it.  Reading them from the L1-resident table instead (to keep the second workgroup with more bands) was built:
+    //  a pointer chosen at run time is a generic pointer = flat loads, two typed paths cost the 8-wave form its last registers)
+    const size_t smem = ((size_t)waves * XB + WW_NFFT + ((a.span_len + 3) & ~3) + (size_t)FRW * a.M +
+                         (a.use_dct ? (size_t)FRW * a.F : 0) + 2 * WW_MAX_MASKS + WW_MELQ_TAB + (size_t)((a.n_melq_w + 3) & ~3)) * sizeof(float);
     // Persistent grid: ctx->logmel_wgs workgroups (ww_ctx_set_logmel_workgroups; WW_LOGMEL_WGS overrides it for tuning),
     // 0 = one full residency round of the device.
     const int nblk = (a.T + FRW - 1) / FRW;

@@ -64,7 +64,6 @@ struct ww_feat_tables {
     int32_t *melq_tab;
     float *melq_w;
     int32_t n_melq_w;
-    int32_t melq_passes;   // = melq_tab[0] (host copy: sizes the kernel's partial-sum scratch)
     ww_feat_tables *next;
 };
 
