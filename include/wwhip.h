@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define WW_ABI_VERSION 13
+#define WW_ABI_VERSION 14
 
 #define WW_OK 0
 #define WW_E_INVALID (-1)     /* bad argument (shape, null pointer, unsupported size) */
@@ -105,6 +105,20 @@ typedef struct {
 #define WW_WAVE_I16 1
 
 int ww_feat_num_frames(int n_samples, int hop);
+
+/* Host only (no GPU, no context): the HTK mel filterbank ww_logmel_fwd uses for cfg, as the kernels read it.  Replaces what
+ * the reference gets from torchaudio's MelSpectrogram inside FeatureExtractor (src/data/feature_extraction.py is absent from
+ * the snapshot; called from src/training/trainer.py:165-170 through the data pipeline).
+ *   start, len (n_mels ints each): first spectrum bin / number of bins of each triangular band
+ *   w (w_cap floats, nullable): the bands' weights back to back, *n_w of them
+ *   melq_tab (WW_MELQ_TAB ints, nullable), melq_w (melq_cap floats, nullable), *n_melq_w (nullable): for n_fft 1024, the
+ *   same weights in the form the v_mfma_f32_4x4x1 band sums of the STFT kernel read: [0] passes P, [1] 4-band quads NQ,
+ *   [2+2p] steps of pass p, [3+2p] offset of its weights, [10+32p+2b] first bin of block b, [11+32p+2b] its unit number,
+ *   [138+q] first unit of quad q; weight of (pass p, step t, lane) at melq_w[offset_p + 64 t + lane] = 1/4 of the weight of
+ *   band 4*quad + lane%4 at bin first_bin(block lane/4) + t.                                                              */
+#define WW_MELQ_TAB 172
+int ww_feat_mel_tables(const ww_feat_cfg *cfg, int32_t *start, int32_t *len, float *w, int w_cap, int32_t *n_w,
+                       int32_t *melq_tab, float *melq_w, int melq_cap, int32_t *n_melq_w);
 
 /* wave (B,N) f32|i16  ->  out (B,1,n_feat,T) f32, optionally SpecAugment-masked in the
  * same pass.  mask_idx (nullable): int32 (B, n_f+n_t, 2) rows (start,width).           */

@@ -313,6 +313,69 @@ def test_library_exports_the_whole_c_abi():
         assert _native.prob_threshold(float(np.float32(p))) == prob_threshold(p)
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(n_mels=64), dict(n_mels=128), dict(n_mels=13), dict(n_mels=3), dict(n_mels=80, f_min=20.0),
+                                dict(n_mels=23, f_max=3800.0), dict(n_mels=1), dict(n_mels=40, sample_rate=8000),
+                                dict(n_mels=40, n_fft=512)])
+def test_mel_tables_match_the_oracle_filterbank_in_both_forms(kw):
+    """Host side of the log-mel kernel (no GPU): the compact HTK bands equal the oracle's filterbank, and the matrix-pipe form of
+    the n_fft-1024 kernel (16 blocks of 4 bands per v_mfma_f32_4x4x1, units of bins balanced over the passes) holds every
+    non-zero weight exactly once, a quarter of its value, where the kernel's addressing can reach it."""
+    from oracle import features as OF
+    from wakeword_trainer_home_amd import _native as nat
+    cfg = nat.make_feat_cfg(**kw)
+    t = nat.mel_tables(cfg)
+    M, n_bins = cfg.n_mels, cfg.n_fft // 2 + 1
+    fb = OF.mel_filterbank(n_bins, M, cfg.sample_rate, cfg.f_min, cfg.f_max if cfg.f_max > 0 else None)   # (bins, M) float64
+    got = np.zeros((n_bins, M), np.float32)
+    off = 0
+    for m in range(M):
+        s_, l_ = int(t["start"][m]), int(t["len"][m])
+        got[s_:s_ + l_, m] = t["w"][off:off + l_]
+        off += l_
+    assert off == t["w"].size
+    assert np.array_equal(got, fb.astype(np.float32)), np.abs(got - fb).max()
+    tab, qw = t["melq_tab"], t["melq_w"]
+    if cfg.n_fft != 1024:
+        assert qw.size == 0 and not tab.any()
+        return
+    P, NQ = int(tab[0]), int(tab[1])
+    assert NQ == (M + 3) // 4 and (NQ + 15) // 16 <= P <= 4
+    first = tab[138:138 + NQ + 1]
+    assert first[0] == 0 and first[-1] == 16 * P and np.all(np.diff(first) >= 1)         # every quad owns at least one unit
+    quad_of = np.repeat(np.arange(NQ), np.diff(first))
+    rec = np.zeros((n_bins + 1024, 4 * NQ), np.float64)
+    seen, end = set(), 0
+    for p in range(P):
+        steps, woff = int(tab[2 + 2 * p]), int(tab[3 + 2 * p])
+        assert steps % 8 == 0 and woff == end
+        end = woff + 64 * steps
+        blk = qw[woff:end].reshape(steps, 16, 4)                                          # (step, block, band in the quad)
+        for b in range(16):
+            j0, u = int(tab[10 + 32 * p + 2 * b]), int(tab[11 + 32 * p + 2 * b])
+            assert j0 % 8 == 0 and 0 <= u < 16 * P and u not in seen
+            seen.add(u)
+            live = np.flatnonzero(np.abs(blk[:, b, :]).sum(axis=1))
+            if live.size:                                                                 # the kernel clamps a group's first bin to 512
+                assert j0 + int(live[-1]) <= 512 and (j0 + 8 * (int(live[-1]) // 8)) <= 512
+                q = int(quad_of[u])
+                rec[j0:j0 + steps, 4 * q:4 * q + 4] += blk[:, b, :]
+    assert end == qw.size and len(seen) == 16 * P
+    assert np.array_equal((4.0 * rec[:n_bins, :M]).astype(np.float32), got) and not rec[n_bins:].any() and not rec[:, M:].any()
+    # units of a quad that hold bins: at most 8 (the kernel fetches a band's partials as eight loads), in bin order, ahead of the
+    # empty ones
+    for q in range(NQ):
+        us = list(range(int(first[q]), int(first[q + 1])))
+        bins = []
+        for u in us:
+            p, b = next((p, b) for p in range(P) for b in range(16) if int(tab[11 + 32 * p + 2 * b]) == u)
+            steps, woff = int(tab[2 + 2 * p]), int(tab[3 + 2 * p])
+            w_u = qw[woff:woff + 64 * steps].reshape(steps, 16, 4)[:, b, :]
+            live = np.flatnonzero(np.abs(w_u).sum(axis=1))
+            bins.append((int(tab[10 + 32 * p + 2 * b]) + int(live[0])) if live.size else None)
+        filled = [x for x in bins if x is not None]
+        assert len(filled) <= 8 and bins[:len(filled)] == filled and filled == sorted(filled), (q, bins)
+
+
 def test_flat_buckets_mixin_on_cpu():
     """models/flat_buckets.py (device-agnostic host logic): parameters become views of one flat tensor in parameters()
     order, state_dict round-trips through the views, gather_grads copies every gradient and refuses a missing one (torch.optim

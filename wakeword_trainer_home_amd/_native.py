@@ -15,7 +15,7 @@ _LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libwwhip.so"
 _lib = None
 _ctx = {}
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 BWD_ALL, BWD_LATE, BWD_EARLY = 0, 1, 2
 ACT_F32, ACT_BF16, ACT_F16 = 0, 1, 2
 LOSS_CE, LOSS_FOCAL = 0, 1
@@ -115,6 +115,7 @@ _SIGS = {
     "ww_ctx_set_logmel_workgroups": (C.c_int, [_vp, C.c_int]),
     "ww_step_ctl_advance": (C.c_int, [_vp, _vp]),
     "ww_feat_num_frames": (C.c_int, [_i, _i]),
+    "ww_feat_mel_tables": (C.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "ww_logmel_fwd": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(FeatCfg), _vp, C.POINTER(SpecAugCfg), _u64, _u64, _u64,
                                 _vp, _vp]),
     "ww_specaug_apply": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(SpecAugCfg), _u64, _u64, _u64, _vp, _vp]),
@@ -317,6 +318,25 @@ def _guard(dev):
 
 def num_frames(n, hop):
     return load().ww_feat_num_frames(n, hop)
+
+
+MELQ_TAB = 172
+
+
+def mel_tables(cfg):
+    """Host only: the mel filterbank of ``cfg`` as the kernels read it -> dict(start, len (n_mels,) int32; w compact band weights;
+    melq_tab (MELQ_TAB,) int32 and melq_w: the matrix-pipe form of the n_fft-1024 kernel, see include/wwhip.h)."""
+    import numpy as np
+    M = int(cfg.n_mels)
+    start, length = np.zeros(M, np.int32), np.zeros(M, np.int32)
+    n_w, n_q = C.c_int32(0), C.c_int32(0)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    _check(load().ww_feat_mel_tables(C.byref(cfg), ptr(start), ptr(length), None, 0, C.byref(n_w), None, None, 0, C.byref(n_q)),
+           "ww_feat_mel_tables")
+    w, qtab, qw = np.zeros(max(n_w.value, 1), np.float32), np.zeros(MELQ_TAB, np.int32), np.zeros(max(n_q.value, 1), np.float32)
+    _check(load().ww_feat_mel_tables(C.byref(cfg), ptr(start), ptr(length), ptr(w), w.size, C.byref(n_w), ptr(qtab), ptr(qw),
+                                     qw.size, C.byref(n_q)), "ww_feat_mel_tables")
+    return dict(start=start, len=length, w=w[:n_w.value], melq_tab=qtab, melq_w=qw[:n_q.value])
 
 
 def prob_threshold(p):

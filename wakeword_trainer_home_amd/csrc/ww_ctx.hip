@@ -219,32 +219,31 @@ static int upload(T **dptr, const std::vector<T> &h) {
     return WW_OK;
 }
 
-// Tables follow DESIGN.md "Feature spec" / oracle/features.py exactly (double on the host).
-int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out) {
-    for (ww_feat_tables *t = ctx->tables; t; t = t->next) {
-        if (memcmp(&t->cfg, cfg, sizeof(ww_feat_cfg)) == 0) {
-            *out = t;
-            return WW_OK;
-        }
-    }
+// The mel filterbank of a feature configuration in the two forms the kernels read (host only; DESIGN.md "Feature spec" /
+// oracle/features.py, double arithmetic): compact bands (first bin, length, offset into w) and, for n_fft 1024, the
+// matrix-pipe form of k_logmel.
+struct MelTables {
+    std::vector<int32_t> start, len, off, qtab;
+    std::vector<float> w, qw;
+    int max_len = 0;
+};
+static void build_mel_tables(const ww_feat_cfg *cfg, MelTables &mt) {
     const int n_fft = cfg->n_fft, n_bins = n_fft / 2 + 1, M = cfg->n_mels;
     const double sr = cfg->sample_rate;
     const double f_min = cfg->f_min, f_max = cfg->f_max > 0.f ? cfg->f_max : sr / 2.0;
-    std::vector<float> win(n_fft);
-    std::vector<float2> tw(n_fft);
-    for (int i = 0; i < n_fft; ++i) {
-        win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / n_fft));
-        tw[i] = make_float2((float)cos(2.0 * M_PI * i / n_fft), (float)(-sin(2.0 * M_PI * i / n_fft)));
-    }
+    std::vector<int32_t> &qtab = mt.qtab;
+    std::vector<float> &w = mt.w, &qw = mt.qw;
+    int &max_len = mt.max_len;
     std::vector<double> f_pts(M + 2);
     const double m_lo = hz_to_mel(f_min), m_hi = hz_to_mel(f_max);
     for (int i = 0; i < M + 2; ++i) {
         double m = (i == M + 1) ? m_hi : m_lo + i * ((m_hi - m_lo) / (M + 1));
         f_pts[i] = mel_to_hz(m);
     }
-    std::vector<int32_t> start(M), len(M), off(M);
-    std::vector<float> w;
-    int max_len = 0;
+    std::vector<int32_t> &start = mt.start, &len = mt.len, &off = mt.off;
+    start.assign(M, 0); len.assign(M, 0); off.assign(M, 0);
+    w.clear();
+    max_len = 0;
     for (int m = 0; m < M; ++m) {
         int s = -1, e = -1;
         std::vector<float> band;
@@ -270,16 +269,6 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
         }
         if (len[m] > max_len) max_len = len[m];
     }
-    std::vector<float> dct;
-    if (cfg->n_mfcc > 0) {
-        dct.resize((size_t)cfg->n_mfcc * M);
-        for (int c = 0; c < cfg->n_mfcc; ++c)
-            for (int m = 0; m < M; ++m) {
-                double v = cos(M_PI / M * (m + 0.5) * c) * sqrt(2.0 / M);
-                if (c == 0) v *= 1.0 / sqrt(2.0);
-                dct[(size_t)c * M + m] = (float)v;
-            }
-    }
     // MFMA form of the band sums (k_logmel, n_fft 1024): v_mfma_f32_4x4x1 runs 16 independent 4x4 outer products per
     // instruction -- block = 4 consecutive bands ("quad") x the wave's frames, one spectrum bin per step.  A UNIT is a run of
     // bins of one quad (in groups of 8 bins) handled by one block of one pass; a pass costs its longest unit's steps, so the
@@ -290,8 +279,8 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
     // the sum of its quad's unit partials in bin order.  Table (ints): [0] passes P, [1] quads NQ, [2+2p] steps of pass p,
     // [3+2p] its weights' offset, [10+32p+2b] first bin (a multiple of 8) of block b, [11+32p+2b] its unit number,
     // [138+q] first unit of quad q (NQ+1 entries).
-    std::vector<int32_t> qtab(WW_MELQ_TAB, 0);
-    std::vector<float> qw;
+    qtab.assign(WW_MELQ_TAB, 0);
+    qw.clear();
     if (n_fft == WW_NFFT) {
         struct Unit { int quad, g0, g1; };                           // bins [8*g0, 8*g1)
         const int NQ = (M + 3) / 4, Pmin = (NQ + 15) / 16;
@@ -353,6 +342,61 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
             while (i < (int)units.size() && units[i].quad < q) ++i;
             qtab[138 + q] = i;
         }
+    }
+}
+
+extern "C" int ww_feat_mel_tables(const ww_feat_cfg *cfg, int32_t *start, int32_t *len, float *w, int w_cap, int32_t *n_w,
+                                  int32_t *melq_tab, float *melq_w, int melq_cap, int32_t *n_melq_w) {
+    WW_REQUIRE(cfg && start && len && n_w, WW_E_INVALID, "ww_feat_mel_tables: null argument");
+    WW_REQUIRE(cfg->n_fft >= 64 && cfg->n_fft <= 4096 && (cfg->n_fft & (cfg->n_fft - 1)) == 0 && cfg->n_mels >= 1 &&
+               cfg->n_mels <= WW_MAX_MELS && cfg->sample_rate > 0, WW_E_INVALID, "ww_feat_mel_tables: bad configuration");
+    MelTables mt;
+    build_mel_tables(cfg, mt);
+    memcpy(start, mt.start.data(), mt.start.size() * sizeof(int32_t));
+    memcpy(len, mt.len.data(), mt.len.size() * sizeof(int32_t));
+    *n_w = (int32_t)mt.w.size();
+    if (w) {
+        WW_REQUIRE(w_cap >= (int)mt.w.size(), WW_E_INVALID, "ww_feat_mel_tables: w holds %d floats, %d needed", w_cap, (int)mt.w.size());
+        memcpy(w, mt.w.data(), mt.w.size() * sizeof(float));
+    }
+    if (n_melq_w) *n_melq_w = (int32_t)mt.qw.size();
+    if (melq_tab) memcpy(melq_tab, mt.qtab.data(), WW_MELQ_TAB * sizeof(int32_t));
+    if (melq_w) {
+        WW_REQUIRE(melq_cap >= (int)mt.qw.size(), WW_E_INVALID, "ww_feat_mel_tables: melq_w holds %d floats, %d needed", melq_cap, (int)mt.qw.size());
+        memcpy(melq_w, mt.qw.data(), mt.qw.size() * sizeof(float));
+    }
+    return WW_OK;
+}
+
+// Tables follow DESIGN.md "Feature spec" / oracle/features.py exactly (double on the host).
+int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out) {
+    for (ww_feat_tables *t = ctx->tables; t; t = t->next) {
+        if (memcmp(&t->cfg, cfg, sizeof(ww_feat_cfg)) == 0) {
+            *out = t;
+            return WW_OK;
+        }
+    }
+    const int n_fft = cfg->n_fft, M = cfg->n_mels;
+    std::vector<float> win(n_fft);
+    std::vector<float2> tw(n_fft);
+    for (int i = 0; i < n_fft; ++i) {
+        win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / n_fft));
+        tw[i] = make_float2((float)cos(2.0 * M_PI * i / n_fft), (float)(-sin(2.0 * M_PI * i / n_fft)));
+    }
+    MelTables mt;
+    build_mel_tables(cfg, mt);
+    const std::vector<int32_t> &start = mt.start, &len = mt.len, &off = mt.off, &qtab = mt.qtab;
+    const std::vector<float> &w = mt.w, &qw = mt.qw;
+    const int max_len = mt.max_len;
+    std::vector<float> dct;
+    if (cfg->n_mfcc > 0) {
+        dct.resize((size_t)cfg->n_mfcc * M);
+        for (int c = 0; c < cfg->n_mfcc; ++c)
+            for (int m = 0; m < M; ++m) {
+                double v = cos(M_PI / M * (m + 0.5) * c) * sqrt(2.0 / M);
+                if (c == 0) v *= 1.0 / sqrt(2.0);
+                dct[(size_t)c * M + m] = (float)v;
+            }
     }
     ww_feat_tables *t = new ww_feat_tables();
     memset(t, 0, sizeof(*t));

@@ -9,8 +9,7 @@
 #define WW_NFFT 1024
 #define WW_NBINS 513
 #define WW_MAX_MELS 128
-#define WW_MELQ_MAX_PASSES 4
-#define WW_MELQ_TAB 172          // ints in ww_feat_tables::melq_tab (up to 4 passes of 16 blocks, 32 quads = 128 mel bands)
+#define WW_MELQ_MAX_PASSES 4     // WW_MELQ_TAB (wwhip.h) ints: up to 4 passes of 16 blocks, 32 quads = 128 mel bands
 #define WW_MAX_MASKS 16
 #define WW_FRAMES_PER_BLOCK 16
 #define WW_MAX_HOP 512
