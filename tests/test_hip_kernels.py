@@ -129,10 +129,12 @@ def test_logmel_matches_oracle(nat, B, N, kw):
 
 
 @pytest.mark.parametrize("n_fft,hop,n_mels,N", [(256, 64, 40, 8000), (512, 160, 40, 24000), (2048, 512, 64, 24000),
-                                                (4096, 160, 40, 24000), (512, 128, 128, 5000)])
+                                                (4096, 160, 40, 24000), (512, 128, 128, 5000), (64, 32, 13, 3000),
+                                                (128, 160, 23, 24000), (256, 160, 40, 200), (512, 160, 80, 300)])
 def test_logmel_other_fft_sizes_match_oracle(nat, n_fft, hop, n_mels, N):
-    """n_fft other than the reference default 1024 (its validator accepts 256 ... 4096, src/config/validator.py:129): the
-    general radix-2 kernel, same spec and bound; also int16 input, MFCC and the fused SpecAugment on that path."""
+    """n_fft other than the reference default 1024 (its validator accepts 256 ... 4096, src/config/validator.py:129): below 1024
+    the 1024-point kernel on zero-extended frames (clips shorter than its 512-sample reach included), above it the general
+    radix-2 kernel; same spec and bound; also int16 input, MFCC and the fused SpecAugment on those paths."""
     from oracle import features as OF
     from oracle.specaugment import specaug_indices, specaug_apply
     x = _waves(4, N, seed=n_fft)

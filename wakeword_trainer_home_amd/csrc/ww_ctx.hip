@@ -100,6 +100,7 @@ static void free_tables(ww_feat_tables *t) {
         if (t->melq_tab) (void)hipFree(t->melq_tab);
         if (t->melq_w) (void)hipFree(t->melq_w);
         if (t->dct) (void)hipFree(t->dct);
+        if (t->dct_t) (void)hipFree(t->dct_t);
         delete t;
         t = n;
     }
@@ -281,14 +282,18 @@ static void build_mel_tables(const ww_feat_cfg *cfg, MelTables &mt) {
     // [138+q] first unit of quad q (NQ+1 entries).
     qtab.assign(WW_MELQ_TAB, 0);
     qw.clear();
-    if (n_fft == WW_NFFT) {
-        struct Unit { int quad, g0, g1; };                           // bins [8*g0, 8*g1)
+    // Shorter transforms run on the same kernel: a frame of n_fft = 1024 / r samples under its own window, zero-extended to 1024
+    // samples, has the n_fft-point spectrum at every r-th bin of its 1024-point one (up to a phase), so bin k's weight sits at
+    // bin r k of this table and the bins between weigh nothing.
+    if (n_fft <= WW_NFFT) {
+        const int r = WW_NFFT / n_fft;
+        struct Unit { int quad, g0, g1; };                           // bins [8*g0, 8*g1) of the 1024-point spectrum
         const int NQ = (M + 3) / 4, Pmin = (NQ + 15) / 16;
         std::vector<Unit> quads;
         for (int q = 0; q < NQ; ++q) {
-            int s = n_bins, e = 0;
+            int s = WW_NFFT / 2 + 1, e = 0;
             for (int m = 4 * q; m < std::min(M, 4 * q + 4); ++m)
-                if (len[m] > 0) { s = std::min(s, start[m]); e = std::max(e, start[m] + len[m]); }
+                if (len[m] > 0) { s = std::min(s, r * start[m]); e = std::max(e, r * (start[m] + len[m] - 1) + 1); }
             if (e <= s) { s = 0; e = 0; }
             quads.push_back(Unit{q, s / 8, (e + 7) / 8});
         }
@@ -334,8 +339,9 @@ static void build_mel_tables(const ww_feat_cfg *cfg, MelTables &mt) {
                 for (int lane = 0; lane < 64; ++lane) {
                     const Unit &u = units[order[16 * p + (lane >> 2)]];
                     const int m = 4 * u.quad + (lane & 3), j = 8 * u.g0 + t;
-                    const bool in = m < M && j < 8 * u.g1 && j >= start[m] && j < start[m] + len[m];
-                    qw.push_back(in ? 0.25f * w[off[m] + (j - start[m])] : 0.f);
+                    const int k = j / r;
+                    const bool in = m < M && j < 8 * u.g1 && j % r == 0 && k >= start[m] && k < start[m] + len[m];
+                    qw.push_back(in ? 0.25f * w[off[m] + (k - start[m])] : 0.f);
                 }
         }
         for (int q = 0, i = 0; q <= NQ; ++q) {
@@ -377,12 +383,14 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
         }
     }
     const int n_fft = cfg->n_fft, M = cfg->n_mels;
-    std::vector<float> win(n_fft);
-    std::vector<float2> tw(n_fft);
-    for (int i = 0; i < n_fft; ++i) {
-        win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / n_fft));
-        tw[i] = make_float2((float)cos(2.0 * M_PI * i / n_fft), (float)(-sin(2.0 * M_PI * i / n_fft)));
-    }
+    // transforms up to 1024 points run on k_logmel: the frame's own periodic Hann in the middle of a 1024-sample window of
+    // zeros (the frame then starts n_fft/2 before t * hop, as torch.stft(center=True) has it), the 1024-point twiddles
+    const int n_tab = n_fft < WW_NFFT ? WW_NFFT : n_fft, lead = (n_tab - n_fft) / 2;
+    std::vector<float> win(n_tab, 0.f);
+    std::vector<float2> tw(n_tab);
+    for (int i = 0; i < n_fft; ++i) win[lead + i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / n_fft));
+    for (int i = 0; i < n_tab; ++i)
+        tw[i] = make_float2((float)cos(2.0 * M_PI * i / n_tab), (float)(-sin(2.0 * M_PI * i / n_tab)));
     MelTables mt;
     build_mel_tables(cfg, mt);
     const std::vector<int32_t> &start = mt.start, &len = mt.len, &off = mt.off, &qtab = mt.qtab;
@@ -411,7 +419,10 @@ int ww_get_feat_tables(ww_ctx *ctx, const ww_feat_cfg *cfg, ww_feat_tables **out
         free_tables(t);
         return rc;
     }
-    if (cfg->n_mfcc > 0 && (rc = upload(&t->dct, dct))) {
+    std::vector<float> dct_t(dct.size());
+    for (int c = 0; c < cfg->n_mfcc; ++c)
+        for (int m = 0; m < M; ++m) dct_t[(size_t)m * cfg->n_mfcc + c] = dct[(size_t)c * M + m];
+    if (cfg->n_mfcc > 0 && ((rc = upload(&t->dct, dct)) || (rc = upload(&t->dct_t, dct_t)))) {
         free_tables(t);
         return rc;
     }

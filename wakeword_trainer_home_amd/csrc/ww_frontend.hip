@@ -35,6 +35,7 @@ struct FeatArgs {
     const int32_t *mel_start, *mel_len, *mel_off;
     const float *mel_w;
     const float *dct;
+    const float *dct_t;          // (M, F): k_logmel
     int span_len;
     int n_mel_w;
     const int32_t *melq_tab;     // k_logmel: band sums in v_mfma_f32_4x4x1 form (ww_feat_tables)
@@ -111,8 +112,8 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
     float *wl = xball + WAVES * XB;                                       // the 1024 window samples
     float *span = wl + WW_NFFT;                                       // span_len (16-byte aligned: vector staging)
     float *lm = span + ((a.span_len + 3) & ~3);                       // FR x M (raw mel sums, then their logs)
-    float *feat = lm + FRW * a.M;                                     // FR x F (== lm when !use_dct)
-    int *msk = reinterpret_cast<int *>(feat + (a.use_dct ? FRW * a.F : 0));  // 2*WW_MAX_MASKS
+    float *feat = xball;                                              // FR x F cepstra: in the tiles, spent once the rounds are over (== lm when !use_dct)
+    int *msk = reinterpret_cast<int *>(lm + FRW * a.M);               // 2*WW_MAX_MASKS
     int *mtab = msk + 2 * WW_MAX_MASKS;                               // WW_MELQ_TAB ints (ww_get_feat_tables)
     float *mw = reinterpret_cast<float *>(mtab + WW_MELQ_TAB);        // n_melq_w band weights, one per (pass, step, lane)
     if (!a.use_dct) feat = lm;
@@ -422,12 +423,23 @@ void k_logmel(const WaveT *__restrict__ wave, FeatArgs a, float *__restrict__ ou
         WW_STAMP(19);
 
         if (a.use_dct) {
+            // (FRW * F <= WAVES * XB: F <= M <= 128.)  Neighbouring lanes = neighbouring coefficients of one frame: the
+            // transposed table makes their loads one line, eight in flight per lane; with (F, M) rows each lane walked its own
+            // row, a dependent L1 round trip per term -- MFCC-13 193 us against the log-mel's 110
             for (int it = tid; it < FRW * a.F; it += NT) {
                 const int fr = it / a.F, c = it - fr * a.F;
-                const float *d = a.dct + (size_t)c * a.M;
+                const float *d = a.dct_t + c;
                 const float *l = lm + fr * a.M;
                 float acc = 0.f;
-                for (int m = 0; m < a.M; ++m) acc = fmaf(d[m], l[m], acc);
+                int m = 0;
+                for (; m + 8 <= a.M; m += 8) {
+                    float dv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dv[i] = d[(size_t)(m + i) * a.F];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc = fmaf(dv[i], l[m + i], acc);
+                }
+                for (; m < a.M; ++m) acc = fmaf(d[(size_t)m * a.F], l[m], acc);
                 feat[it] = acc;
             }
             __syncthreads();
@@ -639,6 +651,7 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
     a.window = tb->window; a.twiddle = tb->twiddle;
     a.mel_start = tb->mel_start; a.mel_len = tb->mel_len; a.mel_off = tb->mel_off; a.mel_w = tb->mel_w;
     a.dct = tb->dct;
+    a.dct_t = tb->dct_t;
     // workgroup form: 8 waves / 32-frame items when the kernel has the device to itself, 4 waves / 16 frames when it runs
     // beside a training step with a caller-chosen number of workgroups (half the per-CU footprint); WW_LOGMEL_WAVES overrides
     static const int waves_env = ww_env_int("WW_LOGMEL_WAVES", 0);
@@ -653,7 +666,10 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
         if ((rc = resolve_mask(ctx, sa, seed, step, sample_offset, &mp))) return rc;
         use_mask = (mp.n_f + mp.n_t) > 0;
     }
-    if (cfg->n_fft != WW_NFFT) {                       // the general radix-2 kernel: one workgroup per (clip, frame)
+    // n_fft <= 1024 runs on k_logmel (shorter frames zero-extended inside the 1024-sample window: their spectrum is every
+    // (1024 / n_fft)-th bin of the 1024-point one, and the band weights sit there, ww_get_feat_tables); longer ones on the
+    // general radix-2 kernel, one workgroup per (clip, frame)
+    if (cfg->n_fft > WW_NFFT) {
         int log2n = 0;
         while ((1 << log2n) < cfg->n_fft) ++log2n;
         const size_t smem_any = (size_t)cfg->n_fft * sizeof(float2) + (size_t)(cfg->n_fft / 2 + 4) * sizeof(float) +
@@ -675,7 +691,7 @@ extern "C" int ww_logmel_fwd(ww_ctx *ctx, const void *wave, int wave_dtype, int 
     //  12 KB of it.  Reading them from the L1-resident table instead (to keep the second workgroup with more bands) was built:
     //  a pointer chosen at run time is a generic pointer = flat loads, two typed paths cost the 8-wave form its last registers)
     const size_t smem = ((size_t)waves * XB + WW_NFFT + ((a.span_len + 3) & ~3) + (size_t)FRW * a.M +
-                         (a.use_dct ? (size_t)FRW * a.F : 0) + 2 * WW_MAX_MASKS + WW_MELQ_TAB + (size_t)((a.n_melq_w + 3) & ~3)) * sizeof(float);
+                         2 * WW_MAX_MASKS + WW_MELQ_TAB + (size_t)((a.n_melq_w + 3) & ~3)) * sizeof(float);
     // Persistent grid: ctx->logmel_wgs workgroups (ww_ctx_set_logmel_workgroups; WW_LOGMEL_WGS overrides it for tuning),
     // 0 = one full residency round of the device.
     const int nblk = (a.T + FRW - 1) / FRW;

@@ -55,6 +55,7 @@ struct ww_feat_tables {
     int32_t *mel_off;      // (n_mels) offset of the band's weights in mel_w
     float *mel_w;          // compact band weights
     float *dct;            // (n_mfcc, n_mels) or null
+    float *dct_t;          // its transpose (n_mels, n_mfcc): k_logmel's lanes take neighbouring coefficients -- neighbouring addresses
     int32_t max_len;
     int32_t n_mel_w;       // number of floats in mel_w
     // the band weights in the form k_logmel's v_mfma_f32_4x4x1 band sums read them (ww_get_feat_tables): melq_tab = WW_MELQ_TAB
