@@ -485,8 +485,8 @@ namespace {
 #endif
 
 
-// ---- any other power-of-two n_fft (the reference's validator accepts 256 ... 4096, src/config/validator.py:129; 1024 is its
-// default and the size k_logmel is built for).  Plain and general rather than fast: one workgroup per (clip, frame), the
+// ---- n_fft above 1024 (the reference's validator accepts 256 ... 4096, src/config/validator.py:129; 1024 is its default and
+// the size k_logmel is built for; shorter transforms run there too).  Plain and general rather than fast: one workgroup per (clip, frame), the
 // windowed frame bit-reversed into LDS as a complex sequence, log2(n_fft) radix-2 stages with the table twiddles, then the
 // same power -> mel -> log (-> DCT) -> SpecAugment law as k_logmel.
 template <typename WaveT>
