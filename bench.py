@@ -260,15 +260,23 @@ def main():
         wave, y = pool[i % len(pool)]
         staged[i] = trainer._prepare_native(wave, y, i)
 
+    gate = os.environ.get("WW_INPUT_GATE", "")           # experiment: fwd | bwd | mid (profiles/EXPERIMENTS.md), default none
+    if gate:
+        model.input_gate, model.gate_event = gate, torch.cuda.Event()
+
     def step(i, lookahead=True):
         if i not in staged:
             prepare(i)
         prep = staged.pop(i)
-        if lookahead:
+        if lookahead and not gate:
             prepare(i + 1)                                # one batch of lookahead, as Trainer.train_epoch does
         for done in trainer._step_native(None, None, i, prepared=prep):   # results arrive one step late
             trainer.state.global_step += 1
             last_done[0] = done
+        if lookahead and gate:                            # the look-ahead input stage waits for this step's gate event
+            if trainer._in_stream is not None:
+                trainer._in_stream.wait_event(model.gate_event)
+            prepare(i + 1)
 
     def fence():
         if use_dist:

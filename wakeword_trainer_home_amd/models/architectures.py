@@ -96,6 +96,10 @@ class CNNSmallWakeword(nn.Module):
         self.dropout_seed = int(dropout_seed)
         self.dropout_step = 0        # advanced once per training-mode forward (counter of the Philox stream)
         self.sample_offset = 0       # first global sample index of this rank's shard (data parallel)
+        # experiment switch (tools/ab input gate, profiles/EXPERIMENTS.md): None = the next batch's input stage starts whenever
+        # its stream is free; "fwd" / "bwd" / "mid" = a HIP event recorded before this step's forward / after its loss /
+        # between the two halves of its backward, for the input stream to wait on
+        self.input_gate, self.gate_event = None, None
         self._pending_tracked = 0
         self._reset_caches()
         self.register_state_dict_pre_hook(CNNSmallWakeword._state_dict_hook)     # (a plain function: the module stays picklable)
@@ -346,8 +350,15 @@ class CNNSmallWakeword(nn.Module):
         if any(p.grad is not None for p in self._plist or ()):
             raise RuntimeError("train_step_native() writes fresh gradients: call optimizer.zero_grad(set_to_none=True) first")
         self._prepare(x.device)
+        gate = self.input_gate                     # where in this step the NEXT batch's input stage may start (Trainer)
+        if gate == "fwd":
+            self.gate_event.record()
         logits, slot, step = self._launch_forward(x, training=True)
         stats, dlogits = criterion.native_fwd_bwd(logits, targets, found_inf_out=found_inf_out)
+        if gate == "bwd":
+            self.gate_event.record()
+        if gate == "mid" and mid_hook is None:
+            mid_hook = self.gate_event.record
         self._launch_backward(x, dlogits, slot, step, mid_hook=mid_hook)
         return stats
 
