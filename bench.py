@@ -291,6 +291,13 @@ def main():
         for done in trainer._flush_pending():
             last_done[0] = done
 
+    # the cyclic garbage collector stays out of the timed region, as in timeit: one generation-2 pass over this process's heap
+    # (torch + its imports) is a 50-80 ms host pause -- 40-60 steps of this benchmark (seen in tools/bench_models.py: one 76 ms
+    # step among thirty 2.9 ms ones).  Collected HERE, ahead of the warm-up: between the warm-up and the first timed pass it left
+    # the GPU idle long enough to drop its clocks, and that pass read 6-8 % slower than the next two.
+    import gc
+    gc.collect()
+    gc.disable()
     # warm-up with HIP events on every kernel class; the first steps also tell which class dominates
     nat.prof_enable(dev, None)
     run_steps(0, args.warmup)
@@ -319,12 +326,6 @@ def main():
         nxt += 4
         assert trainer._graph is not None, "the HIP graph was not captured"
 
-    # the cyclic garbage collector stays out of the timed region, as in timeit: one generation-2 pass over this process's heap
-    # (torch + its imports) is a 50-80 ms host pause -- 40-60 steps of this benchmark (seen in tools/bench_models.py: one 76 ms
-    # step among thirty 2.9 ms ones)
-    import gc
-    gc.collect()
-    gc.disable()
     # SURVEY §8d protocol: the region of EXACTLY --steps steps is timed --passes times (barrier + synchronize on both
     # sides of each), no HIP events inside; the median pass is the reported one.
     pass_dt = []
