@@ -306,21 +306,36 @@ __global__ __launch_bounds__(512) void k_gru_bwd(GruBwdDir d0, GruBwdDir d1, lon
             keep[q] = dh * z;
             sar[q] += dar[q]; saz[q] += daz[q]; san[q] += dan[q]; shn[q] += dhn_[q];
         }
-        if (erow_ok) {
-            const size_t m3 = ((size_t)(b0 + erow) * T + t) * (3 * GH) + ec0;
-            *reinterpret_cast<float4 *>(dgi + m3) = make_float4(dar[0], dar[1], dar[2], dar[3]);
-            *reinterpret_cast<float4 *>(dgi + m3 + GH) = make_float4(daz[0], daz[1], daz[2], daz[3]);
-            *reinterpret_cast<float4 *>(dgi + m3 + 2 * GH) = make_float4(dan[0], dan[1], dan[2], dan[3]);
-            *reinterpret_cast<float4 *>(dgh + m3) = make_float4(dar[0], dar[1], dar[2], dar[3]);
-            *reinterpret_cast<float4 *>(dgh + m3 + GH) = make_float4(daz[0], daz[1], daz[2], daz[3]);
-            *reinterpret_cast<float4 *>(dgh + m3 + 2 * GH) = make_float4(dhn_[0], dhn_[1], dhn_[2], dhn_[3]);
-        }
+        const size_t m3 = ((size_t)(b0 + erow) * T + t) * (3 * GH) + ec0;
         if constexpr (BF16) {
+            // dGi / dGh leave in the matrix type: the weight-gradient and dX products round their operands to it while staging
+            // them anyway (ww_gemm, a16), so the results are bit-identical and those HBM-bound products read half the bytes
             typedef Act<H> A16;
-            *reinterpret_cast<uint2 *>(&dgb[erow][ec0]) = make_uint2(A16::pack2(dar[0], dar[1]), A16::pack2(dar[2], dar[3]));
-            *reinterpret_cast<uint2 *>(&dgb[erow][GH + ec0]) = make_uint2(A16::pack2(daz[0], daz[1]), A16::pack2(daz[2], daz[3]));
-            *reinterpret_cast<uint2 *>(&dgb[erow][2 * GH + ec0]) = make_uint2(A16::pack2(dhn_[0], dhn_[1]), A16::pack2(dhn_[2], dhn_[3]));
+            const uint2 qr = make_uint2(A16::pack2(dar[0], dar[1]), A16::pack2(dar[2], dar[3]));
+            const uint2 qz = make_uint2(A16::pack2(daz[0], daz[1]), A16::pack2(daz[2], daz[3]));
+            const uint2 qn = make_uint2(A16::pack2(dan[0], dan[1]), A16::pack2(dan[2], dan[3]));
+            const uint2 qh = make_uint2(A16::pack2(dhn_[0], dhn_[1]), A16::pack2(dhn_[2], dhn_[3]));
+            if (erow_ok) {
+                H *gi16 = reinterpret_cast<H *>(dgi) + m3, *gh16 = reinterpret_cast<H *>(dgh) + m3;
+                *reinterpret_cast<uint2 *>(gi16) = qr;
+                *reinterpret_cast<uint2 *>(gi16 + GH) = qz;
+                *reinterpret_cast<uint2 *>(gi16 + 2 * GH) = qn;
+                *reinterpret_cast<uint2 *>(gh16) = qr;
+                *reinterpret_cast<uint2 *>(gh16 + GH) = qz;
+                *reinterpret_cast<uint2 *>(gh16 + 2 * GH) = qh;
+            }
+            *reinterpret_cast<uint2 *>(&dgb[erow][ec0]) = qr;
+            *reinterpret_cast<uint2 *>(&dgb[erow][GH + ec0]) = qz;
+            *reinterpret_cast<uint2 *>(&dgb[erow][2 * GH + ec0]) = qh;
         } else {
+            if (erow_ok) {
+                *reinterpret_cast<float4 *>(dgi + m3) = make_float4(dar[0], dar[1], dar[2], dar[3]);
+                *reinterpret_cast<float4 *>(dgi + m3 + GH) = make_float4(daz[0], daz[1], daz[2], daz[3]);
+                *reinterpret_cast<float4 *>(dgi + m3 + 2 * GH) = make_float4(dan[0], dan[1], dan[2], dan[3]);
+                *reinterpret_cast<float4 *>(dgh + m3) = make_float4(dar[0], dar[1], dar[2], dar[3]);
+                *reinterpret_cast<float4 *>(dgh + m3 + GH) = make_float4(daz[0], daz[1], daz[2], daz[3]);
+                *reinterpret_cast<float4 *>(dgh + m3 + 2 * GH) = make_float4(dhn_[0], dhn_[1], dhn_[2], dhn_[3]);
+            }
             *reinterpret_cast<float4 *>(&dg[erow][ec0]) = make_float4(dar[0], dar[1], dar[2], dar[3]);
             *reinterpret_cast<float4 *>(&dg[erow][GH + ec0]) = make_float4(daz[0], daz[1], daz[2], daz[3]);
             *reinterpret_cast<float4 *>(&dg[erow][2 * GH + ec0]) = make_float4(dhn_[0], dhn_[1], dhn_[2], dhn_[3]);
@@ -590,13 +605,14 @@ int gru_layer_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const BwdDirH
         float *part_ih = defer ? part + (size_t)splits * 3 * GH * GH : part;
         const GruSaved sv = saved(h.ws, L);
         // dW_hh[c][k] = sum_m dGh[m][c] h_prev[m][k]   ;   dW_ih[c][i] = sum_m dGi[m][c] x[m][i]
-        if ((rc = ww_gemm(mode, dgh, 1, 3 * GH, 3 * GH, sv.hp, 1, GH, GH, M, h.dw_hh, GH, nullptr, 0, splits, part, st, defer ? ctx : nullptr))) return rc;
-        if ((rc = ww_gemm(mode, dgi, 1, 3 * GH, 3 * GH, x, 1, ldx, I, M, h.dw_ih, I, nullptr, 0, splits, part_ih, st, defer ? ctx : nullptr))) return rc;
+        // (16-bit modes: the recurrent kernel left dGi / dGh in the matrix type -- a16)
+        if ((rc = ww_gemm(mode, dgh, 1, 3 * GH, 3 * GH, sv.hp, 1, GH, GH, M, h.dw_hh, GH, nullptr, 0, splits, part, st, defer ? ctx : nullptr, 1))) return rc;
+        if ((rc = ww_gemm(mode, dgi, 1, 3 * GH, 3 * GH, x, 1, ldx, I, M, h.dw_ih, I, nullptr, 0, splits, part_ih, st, defer ? ctx : nullptr, 1))) return rc;
         // db_ih | db_hh: fixed-order sum of the per-block partials the recurrent kernel left (one launch for both: 768 columns)
         if (defer && h.db_hh == h.db_ih + 3 * GH) ww_defer(ctx, part + bpart_off, h.db_ih, 6 * GH, nblk, 0);
         else if ((rc = ww_colsum_pair(part + bpart_off, nblk, 3 * GH, h.db_ih, h.db_hh, st))) return rc;
         // dx[m][i] (+)= sum_c dGi[m][c] W_ih[c][i]   (the second direction adds to the first one's)
-        if (dx && (rc = ww_gemm(mode, dgi, 3 * GH, 1, M, h.w_ih, 1, I, I, 3 * GH, dx, lddx, nullptr, accumulate_dx || k > 0, 1, nullptr, st)))
+        if (dx && (rc = ww_gemm(mode, dgi, 3 * GH, 1, M, h.w_ih, 1, I, I, 3 * GH, dx, lddx, nullptr, accumulate_dx || k > 0, 1, nullptr, st, nullptr, 1)))
             return rc;
     }
     return WW_OK;

@@ -10,6 +10,7 @@
 // Dropout after the activation draws from the same Philox stream as the cnn_small classifier dropout (TAG_DROPOUT,
 // 4 features per draw, global sample index), so the oracle reproduces the mask exactly.
 #include "ww_internal.h"
+#include <type_traits>
 #include "ww_layers.h"
 #include "ww_act.h"
 #include <algorithm>
@@ -29,6 +30,8 @@ struct GemmOperand {
     const float *p;
     long s_row, s_k;    // element (i,k) = p[i*s_row + k*s_k]
     int rows;           // valid rows
+    int h16;            // 16-bit modes only: the elements in memory are ALREADY of the kernel's matrix type (p points at them; the
+                        // strides count elements) -- half the bytes of an operand the staging would round to that type anyway
 };
 struct Epilogue {
     const float *bias;          // per column j (nullable)
@@ -86,10 +89,11 @@ __device__ __forceinline__ bool drop_keep(const Epilogue &e, const DropCtx &d, l
 // ---- operand staging.  A tile is ROWS x 32 k (ROWS = 64 or 128).  It is kept in LDS in the operand's own memory orientation,
 // so both the global reads (float4) and the LDS writes are contiguous:  KC (k contiguous in memory): [row][k];  otherwise:
 // [k][row].  Each thread moves ROWS/32 float4 per tile; the next tile's float4s are fetched before the MFMAs of the current one.
-template <bool KC, int ROWS, int KT>
+template <typename H, bool KC, int ROWS, int KT>
 __device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k0, int K, bool vec_ok,
                                            float4 (&v)[ROWS * KT / 1024]) {
     const int tid = threadIdx.x;
+    constexpr bool h16 = sizeof(H) == 2;             // H = the element type in memory: float, or the kernel's 16-bit matrix type
 #pragma unroll
     for (int j = 0; j < ROWS * KT / 1024; ++j) {
         const int q = tid + 256 * j;                 // float4 index within the tile (ROWS * KT / 4 per tile)
@@ -98,11 +102,27 @@ __device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k
         else { k = k0 + q / (ROWS / 4); row = r0 + 4 * (q % (ROWS / 4)); }           // ROWS/4 float4 per k-line
         const long lim_c = KC ? K : op.rows, c = KC ? k : row;         // the contiguous coordinate and its bound
         const bool other_ok = KC ? row < op.rows : k < K;
-        const float *src = op.p + row * op.s_row + (long)k * op.s_k;
+        const long eoff = row * op.s_row + (long)k * op.s_k, st = KC ? op.s_k : op.s_row;
+        if constexpr (h16) {
+            // the four elements stay in their 16-bit form (as bit patterns in .x / .y): stage_tile<.., RAW> stores them as they are
+            const H *src = reinterpret_cast<const H *>(op.p) + eoff;
+            uint2 raw;
+            if (other_ok && vec_ok && c + 3 < lim_c) {
+                raw = Act<H>::ldraw4(src);
+            } else {
+                const H z = (H)0.f;
+                const H e0 = (other_ok && c < lim_c) ? src[0] : z, e1 = (other_ok && c + 1 < lim_c) ? src[st] : z;
+                const H e2 = (other_ok && c + 2 < lim_c) ? src[2 * st] : z, e3 = (other_ok && c + 3 < lim_c) ? src[3 * st] : z;
+                raw = make_uint2((uint32_t)__builtin_bit_cast(uint16_t, e0) | ((uint32_t)__builtin_bit_cast(uint16_t, e1) << 16),
+                                 (uint32_t)__builtin_bit_cast(uint16_t, e2) | ((uint32_t)__builtin_bit_cast(uint16_t, e3) << 16));
+            }
+            v[j] = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), 0.f, 0.f);
+            continue;
+        }
+        const float *src = op.p + eoff;
         if (other_ok && vec_ok && c + 3 < lim_c) {
             v[j] = *reinterpret_cast<const float4 *>(src);
         } else {
-            const long st = KC ? op.s_k : op.s_row;
             v[j].x = (other_ok && c < lim_c) ? src[0] : 0.f;
             v[j].y = (other_ok && c + 1 < lim_c) ? src[st] : 0.f;
             v[j].z = (other_ok && c + 2 < lim_c) ? src[2 * st] : 0.f;
@@ -111,7 +131,7 @@ __device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k
     }
 }
 // LDS strides: [row][k]: KT + 4 (fp32) / KT + 8 (bf16);  [k][row]: ROWS + 4 (fp32) / ROWS + 8 (bf16)
-template <int MODE, bool KC, int ROWS, int KT>
+template <int MODE, bool KC, int ROWS, int KT, bool RAW = false>
 __device__ __forceinline__ void stage_tile(void *lds, const float4 (&v)[ROWS * KT / 1024]) {
     constexpr bool BF16 = MODE != 0;
     typedef typename ModeH<MODE>::type H;
@@ -121,7 +141,9 @@ __device__ __forceinline__ void stage_tile(void *lds, const float4 (&v)[ROWS * K
         const int q = tid + 256 * j;
         const int off = KC ? (q / (KT / 4)) * (BF16 ? KT + 8 : KT + 4) + 4 * (q % (KT / 4))
                            : (q / (ROWS / 4)) * (BF16 ? ROWS + 8 : ROWS + 4) + 4 * (q % (ROWS / 4));
-        if (BF16) {
+        if (BF16 && RAW) {
+            *reinterpret_cast<uint2 *>(reinterpret_cast<H *>(lds) + off) = make_uint2(__float_as_uint(v[j].x), __float_as_uint(v[j].y));
+        } else if (BF16) {
             typedef Act<H> A16;
             *reinterpret_cast<uint2 *>(reinterpret_cast<H *>(lds) + off) =
                 make_uint2(A16::pack2(v[j].x, v[j].y), A16::pack2(v[j].z, v[j].w));
@@ -158,12 +180,13 @@ struct GemmLds {
     static constexpr int BYTES = A_BYTES + B_BYTES;
 };
 // one block tile of the product: block (bx, by) of split bz (of nz); lds >= GemmLds<...>::BYTES, 16-byte aligned
-template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS>
+template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS, bool A16 = false>
 __device__ __forceinline__ void gemm_block(const GemmOperand &A, const GemmOperand &B, int K, int k_per_split, float *__restrict__ C,
                                            long ldc, long split_stride, int vecA, int vecB, const Epilogue &e, unsigned char *lds,
                                            int bx, int by, int bz, int nz) {
     constexpr bool BF16 = MODE != 0;
     typedef typename ModeH<MODE>::type H;
+    typedef typename std::conditional<BF16 && A16, H, float>::type FA;    // A's element type in memory (A16: already the matrix type)
     typedef typename H16<H>::x8 bf16x8;
     constexpr int RA = 64 * TM, RB = 64 * TN;
     // K per LDS stage: the bf16 MFMA eats 16 k per instruction, so a 32-deep stage is two MFMAs between barrier pairs --
@@ -187,17 +210,17 @@ __device__ __forceinline__ void gemm_block(const GemmOperand &A, const GemmOpera
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = floatx16{0.f};
     float4 va[RA * KT / 1024], vb[RB * KT / 1024];
     if (kb < ke) {
-        fetch_tile<KCA, RA, KT>(A, m0, kb, ke, vecA, va);
-        fetch_tile<KCB, RB, KT>(B, n0, kb, ke, vecB, vb);
+        fetch_tile<FA, KCA, RA, KT>(A, m0, kb, ke, vecA, va);
+        fetch_tile<float, KCB, RB, KT>(B, n0, kb, ke, vecB, vb);
     }
     for (int k0 = kb; k0 < ke; k0 += KT) {
         __syncthreads();
-        stage_tile<MODE, KCA, RA, KT>(As, va);
+        stage_tile<MODE, KCA, RA, KT, (BF16 && A16)>(As, va);
         stage_tile<MODE, KCB, RB, KT>(Bs, vb);
         __syncthreads();
         if (k0 + KT < ke) {                        // next tile in flight under the MFMAs
-            fetch_tile<KCA, RA, KT>(A, m0, k0 + KT, ke, vecA, va);
-            fetch_tile<KCB, RB, KT>(B, n0, k0 + KT, ke, vecB, vb);
+            fetch_tile<FA, KCA, RA, KT>(A, m0, k0 + KT, ke, vecA, va);
+            fetch_tile<float, KCB, RB, KT>(B, n0, k0 + KT, ke, vecB, vb);
         }
         if (BF16) {
             const H *a = reinterpret_cast<const H *>(As), *b = reinterpret_cast<const H *>(Bs);
@@ -323,11 +346,11 @@ __device__ __forceinline__ void gemm_block(const GemmOperand &A, const GemmOpera
     }
 }
 
-template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS = 0>
+template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS = 0, bool A16 = false>
 __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int K, int k_per_split, float *__restrict__ C,
                                               long ldc, long split_stride, int vecA, int vecB, Epilogue e) {
     __shared__ __align__(16) unsigned char lds[GemmLds<MODE, KCA, KCB, TM, TN, KS>::BYTES];
-    gemm_block<MODE, KCA, KCB, EPI, TM, TN, KS>(A, B, K, k_per_split, C, ldc, split_stride, vecA, vecB, e, lds, blockIdx.x, blockIdx.y,
+    gemm_block<MODE, KCA, KCB, EPI, TM, TN, KS, A16>(A, B, K, k_per_split, C, ldc, split_stride, vecA, vecB, e, lds, blockIdx.x, blockIdx.y,
                                                 blockIdx.z, gridDim.z);
 }
 
@@ -456,12 +479,12 @@ int make_epilogue(const ww_ctx *ctx, const ww_linear_epi *epi, const float *bias
 }
 
 // splits > 1: partial products into `part` (splits x rows x cols), then summed in fixed order into C
-template <bool KCA, bool KCB, int EPI>
+template <bool KCA, bool KCB, int EPI, bool A16 = false>
 int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, float *C, long ldc, const Epilogue &e,
                 hipStream_t st, int splits = 1, float *part = nullptr, int *row_tile_out = nullptr, ww_ctx *defer_ctx = nullptr) {
     auto aligned = [](const GemmOperand &o, bool kc) {
         const long ld = kc ? o.s_row : o.s_k;
-        return (int)(((uintptr_t)o.p & 15) == 0 && (ld & 3) == 0);
+        return (int)(((uintptr_t)o.p & (o.h16 ? 7 : 15)) == 0 && (ld & 3) == 0);
     };
     const int vecA = aligned(A, KCA), vecB = aligned(B, KCB);
     int kps = K;
@@ -482,9 +505,9 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
     const long sstride = (long)A.rows * ldc;
 #define WW_GEMM_LAUNCH(BF, TM_, TN_) \
     do { if constexpr (!(EPI == 1 && TM_ * TN_ == 4)) \
-        hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, TN_>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e); } while (0)
+        hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, TN_, 0, (A16 && BF != 0)>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e); } while (0)
 #define WW_GEMM_LAUNCH_K32(BF, TM_) \
-    hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, 1, 32>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e)
+    hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, 1, 32, (A16 && BF != 0)>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e)
     const bool shallow = K <= 32 && nz == 1 && cfg != 2;       // 16-bit modes: one 32-deep stage instead of a 128-deep one
     if (mode == WW_ACT_BF16) {
         if (shallow) { if (cfg == 1) WW_GEMM_LAUNCH_K32(1, 2); else WW_GEMM_LAUNCH_K32(1, 1); }
@@ -541,7 +564,7 @@ int launch_gemm_pair(ww_ctx *ctx, int mode, const float *dpre, const float *x, c
     }
     auto aligned = [](const GemmOperand &o, bool kc) {
         const long ld = kc ? o.s_row : o.s_k;
-        return (int)(((uintptr_t)o.p & 15) == 0 && (ld & 3) == 0);
+        return (int)(((uintptr_t)o.p & (o.h16 ? 7 : 15)) == 0 && (ld & 3) == 0);
     };
     const int RAx = px.cfg ? 128 : 64;
     PairSide sw{Aw, Bw, M, pw.kps, pw.nz > 1 ? part : dw, (long)K, (long)N * K, aligned(Aw, false), aligned(Bw, false),
@@ -581,12 +604,19 @@ int check_dims(const char *who, int mode, int M, int K, int N) {
 
 // internal entry points for the recurrent layers (ww_gru.hip)
 int ww_gemm(int mode, const float *A, long a_srow, long a_sk, int a_rows, const float *B, long b_srow, long b_sk, int b_rows,
-            int K, float *C, long ldc, const float *bias, int accumulate, int splits, float *part, hipStream_t st, ww_ctx *defer_ctx) {
+            int K, float *C, long ldc, const float *bias, int accumulate, int splits, float *part, hipStream_t st, ww_ctx *defer_ctx,
+            int a16) {
     Epilogue e = {};
     e.bias = bias;
     e.accumulate = accumulate;
-    const GemmOperand a{A, a_srow, a_sk, a_rows}, b{B, b_srow, b_sk, b_rows};
+    const GemmOperand a{A, a_srow, a_sk, a_rows, (a16 && mode != WW_ACT_F32) ? 1 : 0}, b{B, b_srow, b_sk, b_rows, 0};
     const bool kca = a_sk == 1, kcb = b_sk == 1;
+    if (a.h16) {            // (the recurrent layers' dGi / dGh: never k-contiguous on both sides)
+        if (kca && !kcb) return launch_gemm<true, false, 2, true>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
+        if (!kca && !kcb) return launch_gemm<false, false, 2, true>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
+        ww_set_error("ww_gemm: a 16-bit A operand is built for B with contiguous rows only");
+        return WW_E_UNSUPPORTED;
+    }
     if (kca && kcb) return launch_gemm<true, true, 2>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
     if (kca && !kcb) return launch_gemm<true, false, 2>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
     if (!kca && kcb) return launch_gemm<false, true, 2>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
