@@ -71,7 +71,8 @@ def test_gru_direction_matches_torch(B, T, I, reverse, gru_rows):
 def test_gru_bidirectional_layer_in_one_launch(B, T, I, mode, gru_rows):
     """ww_gru_bidir_fwd/bwd (both directions as the two rows of ONE recurrent launch) against float64 torch.nn.GRU
     (bidirectional=True) in the fp32 mode, and BIT-identical to the two per-direction launches it replaces in either mode
-    (same kernels, same per-direction arithmetic; dx is the forward direction's product plus the reverse one's, in that order)."""
+    (same kernels, same per-direction arithmetic) -- except dx: one product over both directions' (dGi, W_ih) pairs here, a
+    product plus an accumulating one there: the same terms in another order of fp32 additions."""
     from wakeword_trainer_home_amd import _native as nat
     H = 128
     torch.manual_seed(B * T)
@@ -99,7 +100,10 @@ def test_gru_bidirectional_layer_in_one_launch(B, T, I, mode, gru_rows):
     dx1 = torch.zeros(B, T, I, device=DEV)
     g1 = [nat.gru_bwd(xd, params[d][0], params[d][1], dyd[:, :, d * H:(d + 1) * H], f(dhn[d]), ws1[d], reverse=(d == 1), dx=dx1,
                       accumulate_dx=(d == 1), mode=m) for d in range(2)]
-    assert torch.equal(y, y1) and torch.equal(h_n[0], h1[0]) and torch.equal(h_n[1], h1[1]) and torch.equal(dx, dx1)
+    assert torch.equal(y, y1) and torch.equal(h_n[0], h1[0]) and torch.equal(h_n[1], h1[1])
+    ddx = (dx - dx1).abs().max().item() / max(dx1.abs().max().item(), 1e-30)
+    print(f"bidirectional dx, one product vs product + accumulate: max |diff| / max |dx| = {ddx:.2e}")
+    assert ddx <= 2e-6
     for d in range(2):
         for a, b in zip(grads[d], g1[d][:4]):
             assert torch.equal(a, b)

@@ -611,10 +611,14 @@ int gru_layer_bwd(ww_ctx *ctx, int mode, const float *x, long ldx, const BwdDirH
         // db_ih | db_hh: fixed-order sum of the per-block partials the recurrent kernel left (one launch for both: 768 columns)
         if (defer && h.db_hh == h.db_ih + 3 * GH) ww_defer(ctx, part + bpart_off, h.db_ih, 6 * GH, nblk, 0);
         else if ((rc = ww_colsum_pair(part + bpart_off, nblk, 3 * GH, h.db_ih, h.db_hh, st))) return rc;
-        // dx[m][i] (+)= sum_c dGi[m][c] W_ih[c][i]   (the second direction adds to the first one's)
-        if (dx && (rc = ww_gemm(mode, dgi, 3 * GH, 1, M, h.w_ih, 1, I, I, 3 * GH, dx, lddx, nullptr, accumulate_dx || k > 0, 1, nullptr, st, nullptr, 1)))
+        // dx[m][i] (+)= sum_c dGi[m][c] W_ih[c][i]   (the second direction adds to the first one's; both directions of a
+        // layer: ONE product over the two (dGi, W_ih) pairs below instead)
+        if (dx && nd != 2 && (rc = ww_gemm(mode, dgi, 3 * GH, 1, M, h.w_ih, 1, I, I, 3 * GH, dx, lddx, nullptr, accumulate_dx || k > 0, 1, nullptr, st, nullptr, 1)))
             return rc;
     }
+    if (dx && nd == 2 && (rc = ww_gemm_seg2(mode, (float *)(d[0].ws + L.gi), (float *)(d[1].ws + L.gi), 3 * GH, M, d[0].w_ih, d[1].w_ih, I, I,
+                                            3 * GH, dx, lddx, accumulate_dx, st, 1)))
+        return rc;
     return WW_OK;
 }
 }  // namespace

@@ -137,6 +137,8 @@ int ww_launch_bwd_finalize(const float *stat, int rows, double count, const floa
 int ww_gemm(int mode, const float *A, long a_srow, long a_sk, int a_rows, const float *B, long b_srow, long b_sk, int b_rows,
             int K, float *C, long ldc, const float *bias, int accumulate, int splits, float *part, hipStream_t st,
             ww_ctx *defer_ctx = nullptr, int a16 = 0);     // a16 (16-bit modes): A already holds elements of the matrix type
+int ww_gemm_seg2(int mode, const float *A, const float *A2, long a_srow, int a_rows, const float *B, const float *B2, long b_sk,
+                 int b_rows, int kseg, float *C, long ldc, int accumulate, hipStream_t st, int a16);
 int ww_colsum_rows(const float *a, long rows, int cols, float *out, float *part, int chunks, hipStream_t st);
 int ww_colsum_pair(const float *a, int rows, int cols, float *out0, float *out1, hipStream_t st);
 int ww_colsum_rows_small(const float *a, int rows, int cols, float *out, hipStream_t st);

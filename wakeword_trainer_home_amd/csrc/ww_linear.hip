@@ -32,6 +32,8 @@ struct GemmOperand {
     int rows;           // valid rows
     int h16;            // 16-bit modes only: the elements in memory are ALREADY of the kernel's matrix type (p points at them; the
                         // strides count elements) -- half the bytes of an operand the staging would round to that type anyway
+    const float *p2;    // SEG kernels: element (i, k) for k >= kseg is p2[i*s_row + (k - kseg)*s_k] -- a contraction over two
+    int kseg;           // buffers (the two directions of a recurrent layer) in one product; kseg a multiple of the K stage
 };
 struct Epilogue {
     const float *bias;          // per column j (nullable)
@@ -89,11 +91,18 @@ __device__ __forceinline__ bool drop_keep(const Epilogue &e, const DropCtx &d, l
 // ---- operand staging.  A tile is ROWS x 32 k (ROWS = 64 or 128).  It is kept in LDS in the operand's own memory orientation,
 // so both the global reads (float4) and the LDS writes are contiguous:  KC (k contiguous in memory): [row][k];  otherwise:
 // [k][row].  Each thread moves ROWS/32 float4 per tile; the next tile's float4s are fetched before the MFMAs of the current one.
-template <typename H, bool KC, int ROWS, int KT>
-__device__ __forceinline__ void fetch_tile(const GemmOperand &op, long r0, int k0, int K, bool vec_ok,
+template <typename H, bool KC, int ROWS, int KT, bool SEG = false>
+__device__ __forceinline__ void fetch_tile(const GemmOperand &op_, long r0, int k0_, int K_, bool vec_ok,
                                            float4 (&v)[ROWS * KT / 1024]) {
     const int tid = threadIdx.x;
     constexpr bool h16 = sizeof(H) == 2;             // H = the element type in memory: float, or the kernel's 16-bit matrix type
+    // SEG: a stage lies in one of the two buffers (kseg is a multiple of the stage depth): pick it once per stage
+    GemmOperand op = op_;
+    int k0 = k0_, K = K_;
+    if constexpr (SEG) {
+        if (k0_ >= op_.kseg) { op.p = op_.p2; k0 = k0_ - op_.kseg; K = K_ - op_.kseg; }
+        else K = min(K_, op_.kseg);
+    }
 #pragma unroll
     for (int j = 0; j < ROWS * KT / 1024; ++j) {
         const int q = tid + 256 * j;                 // float4 index within the tile (ROWS * KT / 4 per tile)
@@ -180,7 +189,7 @@ struct GemmLds {
     static constexpr int BYTES = A_BYTES + B_BYTES;
 };
 // one block tile of the product: block (bx, by) of split bz (of nz); lds >= GemmLds<...>::BYTES, 16-byte aligned
-template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS, bool A16 = false>
+template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS, bool A16 = false, bool SEG = false>
 __device__ __forceinline__ void gemm_block(const GemmOperand &A, const GemmOperand &B, int K, int k_per_split, float *__restrict__ C,
                                            long ldc, long split_stride, int vecA, int vecB, const Epilogue &e, unsigned char *lds,
                                            int bx, int by, int bz, int nz) {
@@ -210,8 +219,8 @@ __device__ __forceinline__ void gemm_block(const GemmOperand &A, const GemmOpera
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = floatx16{0.f};
     float4 va[RA * KT / 1024], vb[RB * KT / 1024];
     if (kb < ke) {
-        fetch_tile<FA, KCA, RA, KT>(A, m0, kb, ke, vecA, va);
-        fetch_tile<float, KCB, RB, KT>(B, n0, kb, ke, vecB, vb);
+        fetch_tile<FA, KCA, RA, KT, SEG>(A, m0, kb, ke, vecA, va);
+        fetch_tile<float, KCB, RB, KT, SEG>(B, n0, kb, ke, vecB, vb);
     }
     for (int k0 = kb; k0 < ke; k0 += KT) {
         __syncthreads();
@@ -219,8 +228,8 @@ __device__ __forceinline__ void gemm_block(const GemmOperand &A, const GemmOpera
         stage_tile<MODE, KCB, RB, KT>(Bs, vb);
         __syncthreads();
         if (k0 + KT < ke) {                        // next tile in flight under the MFMAs
-            fetch_tile<FA, KCA, RA, KT>(A, m0, k0 + KT, ke, vecA, va);
-            fetch_tile<float, KCB, RB, KT>(B, n0, k0 + KT, ke, vecB, vb);
+            fetch_tile<FA, KCA, RA, KT, SEG>(A, m0, k0 + KT, ke, vecA, va);
+            fetch_tile<float, KCB, RB, KT, SEG>(B, n0, k0 + KT, ke, vecB, vb);
         }
         if (BF16) {
             const H *a = reinterpret_cast<const H *>(As), *b = reinterpret_cast<const H *>(Bs);
@@ -346,11 +355,11 @@ __device__ __forceinline__ void gemm_block(const GemmOperand &A, const GemmOpera
     }
 }
 
-template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS = 0, bool A16 = false>
+template <int MODE, bool KCA, bool KCB, int EPI, int TM, int TN, int KS = 0, bool A16 = false, bool SEG = false>
 __global__ __launch_bounds__(256) void k_gemm(GemmOperand A, GemmOperand B, int K, int k_per_split, float *__restrict__ C,
                                               long ldc, long split_stride, int vecA, int vecB, Epilogue e) {
     __shared__ __align__(16) unsigned char lds[GemmLds<MODE, KCA, KCB, TM, TN, KS>::BYTES];
-    gemm_block<MODE, KCA, KCB, EPI, TM, TN, KS, A16>(A, B, K, k_per_split, C, ldc, split_stride, vecA, vecB, e, lds, blockIdx.x, blockIdx.y,
+    gemm_block<MODE, KCA, KCB, EPI, TM, TN, KS, A16, SEG>(A, B, K, k_per_split, C, ldc, split_stride, vecA, vecB, e, lds, blockIdx.x, blockIdx.y,
                                                 blockIdx.z, gridDim.z);
 }
 
@@ -479,12 +488,12 @@ int make_epilogue(const ww_ctx *ctx, const ww_linear_epi *epi, const float *bias
 }
 
 // splits > 1: partial products into `part` (splits x rows x cols), then summed in fixed order into C
-template <bool KCA, bool KCB, int EPI, bool A16 = false>
+template <bool KCA, bool KCB, int EPI, bool A16 = false, bool SEG = false>
 int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, float *C, long ldc, const Epilogue &e,
                 hipStream_t st, int splits = 1, float *part = nullptr, int *row_tile_out = nullptr, ww_ctx *defer_ctx = nullptr) {
     auto aligned = [](const GemmOperand &o, bool kc) {
         const long ld = kc ? o.s_row : o.s_k;
-        return (int)(((uintptr_t)o.p & (o.h16 ? 7 : 15)) == 0 && (ld & 3) == 0);
+        return (int)((((uintptr_t)o.p | (uintptr_t)o.p2) & (o.h16 ? 7 : 15)) == 0 && (ld & 3) == 0);
     };
     const int vecA = aligned(A, KCA), vecB = aligned(B, KCB);
     int kps = K;
@@ -505,9 +514,9 @@ int launch_gemm(int mode, const GemmOperand &A, const GemmOperand &B, int K, flo
     const long sstride = (long)A.rows * ldc;
 #define WW_GEMM_LAUNCH(BF, TM_, TN_) \
     do { if constexpr (!(EPI == 1 && TM_ * TN_ == 4)) \
-        hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, TN_, 0, (A16 && BF != 0)>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e); } while (0)
+        hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, TN_, 0, (A16 && BF != 0), SEG>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e); } while (0)
 #define WW_GEMM_LAUNCH_K32(BF, TM_) \
-    hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, 1, 32, (A16 && BF != 0)>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e)
+    hipLaunchKernelGGL((k_gemm<BF, KCA, KCB, EPI, TM_, 1, 32, (A16 && BF != 0), SEG>), grid, dim3(256), 0, st, A, B, K, kps, dst, ldc, sstride, vecA, vecB, e)
     const bool shallow = K <= 32 && nz == 1 && cfg != 2;       // 16-bit modes: one 32-deep stage instead of a 128-deep one
     if (mode == WW_ACT_BF16) {
         if (shallow) { if (cfg == 1) WW_GEMM_LAUNCH_K32(1, 2); else WW_GEMM_LAUNCH_K32(1, 1); }
@@ -564,7 +573,7 @@ int launch_gemm_pair(ww_ctx *ctx, int mode, const float *dpre, const float *x, c
     }
     auto aligned = [](const GemmOperand &o, bool kc) {
         const long ld = kc ? o.s_row : o.s_k;
-        return (int)(((uintptr_t)o.p & (o.h16 ? 7 : 15)) == 0 && (ld & 3) == 0);
+        return (int)((((uintptr_t)o.p | (uintptr_t)o.p2) & (o.h16 ? 7 : 15)) == 0 && (ld & 3) == 0);
     };
     const int RAx = px.cfg ? 128 : 64;
     PairSide sw{Aw, Bw, M, pw.kps, pw.nz > 1 ? part : dw, (long)K, (long)N * K, aligned(Aw, false), aligned(Bw, false),
@@ -621,6 +630,18 @@ int ww_gemm(int mode, const float *A, long a_srow, long a_sk, int a_rows, const 
     if (kca && !kcb) return launch_gemm<true, false, 2>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
     if (!kca && kcb) return launch_gemm<false, true, 2>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
     return launch_gemm<false, false, 2>(mode, a, b, K, C, ldc, e, st, splits, part, nullptr, defer_ctx);
+}
+// C[i][j] (+)= sum_{k < kseg} A(i,k) B(j,k) + sum_{k < kseg} A2(i,k) B2(j,k): one product over two buffer pairs of the same
+// shapes and strides (the dX of a bidirectional recurrent layer: both directions' dGi against both W_ih) instead of a product
+// and an accumulating one; A k-contiguous, B row-contiguous, kseg a multiple of 128
+int ww_gemm_seg2(int mode, const float *A, const float *A2, long a_srow, int a_rows, const float *B, const float *B2, long b_sk,
+                 int b_rows, int kseg, float *C, long ldc, int accumulate, hipStream_t st, int a16) {
+    WW_REQUIRE(kseg % GKH == 0, WW_E_INVALID, "ww_gemm_seg2: kseg=%d must be a multiple of %d", kseg, GKH);
+    Epilogue e = {};
+    e.accumulate = accumulate;
+    const GemmOperand a{A, a_srow, 1, a_rows, (a16 && mode != WW_ACT_F32) ? 1 : 0, A2, kseg}, b{B, 1, b_sk, b_rows, 0, B2, kseg};
+    if (a.h16) return launch_gemm<true, false, 2, true, true>(mode, a, b, 2 * kseg, C, ldc, e, st);
+    return launch_gemm<true, false, 2, false, true>(mode, a, b, 2 * kseg, C, ldc, e, st);
 }
 // a: rows x (2*cols) row-major; out0 = column sums of the left half, out1 of the right half (one launch)
 __global__ __launch_bounds__(1024) void k_colsum_pair(const float *__restrict__ a, int rows, int cols, float *__restrict__ out0,
