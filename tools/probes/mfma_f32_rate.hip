@@ -88,5 +88,10 @@ int main() {
     printf("%-34s %7.1f ticks per instruction per wave (4 waves per SIMD)\n", name, (double)h / N);
     RUN16("v_fma_f32 (asm) x8, 16 waves", (kfma2<8>)); RUN16("v_pk_fma_f32 x8, 16 waves", (kpk<8>));
     RUN16("mfma_f32_4x4x1 x4, 16 waves", (k4x4<4>));
+    // every CU full: 512 blocks of 1024 threads = 8 waves per SIMD where the registers allow -- the SIMD's VALU capacity
+    (void)hipFree(o); (void)hipMalloc(&o, 512 * 4096);
+#define RUNFULL(name, K) for (int r = 0; r < 2; ++r) { hipLaunchKernelGGL(K, dim3(512), dim3(1024), 0, 0, 1.f, 2.f, o, t); (void)hipMemcpy(&h, t, 8, hipMemcpyDeviceToHost); } \
+    printf("%-34s %7.1f ticks per instruction per wave (8 waves per SIMD, all CUs)\n", name, (double)h / N);
+    RUNFULL("v_fma_f32 (asm) x8, full", (kfma2<8>)); RUNFULL("v_pk_fma_f32 x8, full", (kpk<8>));
     return 0;
 }
